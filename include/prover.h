@@ -1,0 +1,145 @@
+/*
+ * prover.h -- outer C-ABI of libultragroth_hip.so.
+ *
+ * Drop-in for the extern "C" prover API of rarimo/ultragroth (src/prover.h): same symbol names, argument
+ * order, types, return codes and error-message strings, so that every existing binding of the reference
+ * (its own CLIs src/main_prover.cpp:39-65 and src/main_prover_ultra_groth.cpp:39-65, and the Go / iOS /
+ * Android / React-Native / Flutter wrappers listed in README.md:158-168) links against this library
+ * unchanged. The MSMs and the H-polynomial block run on one MI355X; everything else is host code.
+ *
+ * Reference declarations mirrored here (src/prover.h):
+ *   groth16_public_size_for_zkey_buf :18-25      ultra_groth_public_size_for_zkey_buf :26-33
+ *   groth16_public_size_for_zkey_file :44-50     ultra_groth_public_size_for_zkey_file :51-57
+ *   groth16_proof_size :62-65                    ultra_groth_proof_size :69-72
+ *   groth16_prover_create :80-87                 ultra_groth_prover_create :89-96
+ *   groth16_prover_create_zkey_file :104-110     ultra_groth_prover_create_zkey_file :112-118
+ *   groth16_prover_prove :127-138                ultra_groth_prover_prove :140-151
+ *   groth16_prover_destroy :156-159              ultra_groth_prover_destroy :161-164
+ *   groth16_prover :173-185                      ultra_groth_prover :187-199
+ *   groth16_prover_zkey_file :208-219            ultra_groth_prover_zkey_file :221-232
+ *
+ * Behavioural notes (all as in src/prover.cpp unless stated):
+ *   - error_msg receives at most error_msg_maxsize bytes via strncpy (may be unterminated when full);
+ *   - proof_size / public_size are inputs only: buffers shorter than the minimum (810 / 1400 bytes for
+ *     the proof, 82 * nPublic + 4 for the public signals) give PROVER_ERROR_SHORT_BUFFER;
+ *   - *_create uploads and converts the zkey's base points and coefficients to HBM, so -- unlike the
+ *     reference, which keeps raw pointers into the caller's zkey buffer -- the buffer may be released as
+ *     soon as *_create returns (this also removes the reference's dangling-mapping defect in
+ *     *_create_zkey_file, src/prover.cpp:449-473);
+ *   - one prove at a time per prover object; a prover object is bound to one HIP device
+ *     (environment variable ULTRAGROTH_DEVICE, default 0).
+ *
+ * Additions (not in the reference), all prefixed ug_: deterministic blinding for tests, per-phase
+ * timings, and the sharded entry points a multi-GPU launcher uses (one process per GPU).
+ */
+#ifndef ULTRAGROTH_PROVER_H
+#define ULTRAGROTH_PROVER_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PROVER_OK                     0x0
+#define PROVER_ERROR                  0x1
+#define PROVER_ERROR_SHORT_BUFFER     0x2
+#define PROVER_INVALID_WITNESS_LENGTH 0x3
+
+int groth16_public_size_for_zkey_buf(const void *zkey_buffer, unsigned long long zkey_size,
+                                     unsigned long long *public_size,
+                                     char *error_msg, unsigned long long error_msg_maxsize);
+int ultra_groth_public_size_for_zkey_buf(const void *zkey_buffer, unsigned long long zkey_size,
+                                         unsigned long long *public_size,
+                                         char *error_msg, unsigned long long error_msg_maxsize);
+
+int groth16_public_size_for_zkey_file(const char *zkey_fname, unsigned long long *public_size,
+                                      char *error_msg, unsigned long long error_msg_maxsize);
+int ultra_groth_public_size_for_zkey_file(const char *zkey_fname, unsigned long long *public_size,
+                                          char *error_msg, unsigned long long error_msg_maxsize);
+
+void groth16_proof_size(unsigned long long *proof_size);
+void ultra_groth_proof_size(unsigned long long *proof_size);
+
+int groth16_prover_create(void **prover_object, const void *zkey_buffer, unsigned long long zkey_size,
+                          char *error_msg, unsigned long long error_msg_maxsize);
+int ultra_groth_prover_create(void **prover_object, const void *zkey_buffer, unsigned long long zkey_size,
+                              char *error_msg, unsigned long long error_msg_maxsize);
+
+int groth16_prover_create_zkey_file(void **prover_object, const char *zkey_file_path,
+                                    char *error_msg, unsigned long long error_msg_maxsize);
+int ultra_groth_prover_create_zkey_file(void **prover_object, const char *zkey_file_path,
+                                        char *error_msg, unsigned long long error_msg_maxsize);
+
+int groth16_prover_prove(void *prover_object, const void *wtns_buffer, unsigned long long wtns_size,
+                         char *proof_buffer, unsigned long long *proof_size,
+                         char *public_buffer, unsigned long long *public_size,
+                         char *error_msg, unsigned long long error_msg_maxsize);
+int ultra_groth_prover_prove(void *prover_object, const void *wtns_buffer, unsigned long long wtns_size,
+                             char *proof_buffer, unsigned long long *proof_size,
+                             char *public_buffer, unsigned long long *public_size,
+                             char *error_msg, unsigned long long error_msg_maxsize);
+
+void groth16_prover_destroy(void *prover_object);
+void ultra_groth_prover_destroy(void *prover_object);
+
+int groth16_prover(const void *zkey_buffer, unsigned long long zkey_size,
+                   const void *wtns_buffer, unsigned long long wtns_size,
+                   char *proof_buffer, unsigned long long *proof_size,
+                   char *public_buffer, unsigned long long *public_size,
+                   char *error_msg, unsigned long long error_msg_maxsize);
+int ultra_groth_prover(const void *zkey_buffer, unsigned long long zkey_size,
+                       const void *wtns_buffer, unsigned long long wtns_size,
+                       char *proof_buffer, unsigned long long *proof_size,
+                       char *public_buffer, unsigned long long *public_size,
+                       char *error_msg, unsigned long long error_msg_maxsize);
+
+int groth16_prover_zkey_file(const char *zkey_file_path,
+                             const void *wtns_buffer, unsigned long long wtns_size,
+                             char *proof_buffer, unsigned long long *proof_size,
+                             char *public_buffer, unsigned long long *public_size,
+                             char *error_msg, unsigned long long error_msg_maxsize);
+int ultra_groth_prover_zkey_file(const char *zkey_file_path,
+                                 const void *wtns_buffer, unsigned long long wtns_size,
+                                 char *proof_buffer, unsigned long long *proof_size,
+                                 char *public_buffer, unsigned long long *public_size,
+                                 char *error_msg, unsigned long long error_msg_maxsize);
+
+/* ---- additions ------------------------------------------------------------------------------------ */
+
+/* Test hook: the next draws of blinding randomness (31 bytes each: r then s for Groth16;
+ * r_k, r, s for UltraGroth -- src/groth16.cpp:165-166, src/ultra_groth.cpp:173,345-346) are taken from
+ * `bytes` instead of the operating system. n = 0 restores OS entropy. Process-wide. */
+void ug_test_set_blinding(const void *bytes, unsigned long long n);
+
+/* Device milliseconds of the last prove on this prover object: MSM part, H-polynomial ("FFT") part, and
+ * host wall-clock milliseconds of the whole prove call. */
+int ug_prover_last_timings(void *prover_object, double *msm_ms, double *fft_ms, double *total_ms);
+/* average duration (ms), launch count and (point, window) entries of the bucket-accumulation kernel
+ * since the prover was created or the counters were last reset */
+int ug_prover_kernel_stats(void *prover_object, double *accumulate_ms_avg, unsigned long long *launches,
+                           unsigned long long *entries, int reset);
+
+/* Sharded Groth16 proving, one process per GPU. Rank `shard_rank` of `shard_count` holds the base points
+ * [rank * n / count, (rank + 1) * n / count) of every section and produces partial sums; the partial
+ * sums of all ranks are added (ug_groth16_partials_add) and finished on one rank.
+ * partials layout: MSM_A (64) | MSM_B1 (64) | MSM_B2 (128) | MSM_C (64) | MSM_H (64) affine records. */
+#define UG_GROTH16_PARTIALS_SIZE 384
+int ug_groth16_prover_create_sharded(void **prover_object, const void *zkey_buffer, unsigned long long zkey_size,
+                                     int device, int shard_rank, int shard_count,
+                                     char *error_msg, unsigned long long error_msg_maxsize);
+/* upload the witness (wtns file buffer) to the device; returns PROVER_INVALID_WITNESS_LENGTH etc. */
+int ug_groth16_prover_load_witness(void *prover_object, const void *wtns_buffer, unsigned long long wtns_size,
+                                   char *error_msg, unsigned long long error_msg_maxsize);
+/* device part of the prove on the resident witness: the five MSMs over this rank's slice + H polynomial */
+int ug_groth16_prover_run(void *prover_object, void *partials_out,
+                          char *error_msg, unsigned long long error_msg_maxsize);
+int ug_groth16_partials_add(void *partials_acc, const void *partials_other);
+/* blinding + JSON from summed partials (host only) */
+int ug_groth16_prover_finish(void *prover_object, const void *partials_sum,
+                             char *proof_buffer, unsigned long long *proof_size,
+                             char *public_buffer, unsigned long long *public_size,
+                             char *error_msg, unsigned long long error_msg_maxsize);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

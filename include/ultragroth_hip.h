@@ -1,0 +1,121 @@
+/*
+ * ultragroth_hip.h -- inner C-ABI of libultragroth_hip.so: the MI355X (gfx950) replacement for the
+ * arithmetic layer that rarimo/ultragroth's prover reaches through the un-vendored iden3/ffiasm
+ * submodule. Plain pointers and sizes only; no exceptions cross this boundary (every function returns
+ * UG_OK or UG_ERROR and ug_last_error() gives the message for the calling thread).
+ *
+ * Reference interface each group replaces (paths relative to the reference repository):
+ *
+ *   ug_bases_*  + ug_schedule_* + ug_msm_g1 / ug_msm_g2
+ *       Curve::multiMulByScalarMSM(Point& r, PointAffine* bases, uint8_t* scalars, 32, n)
+ *       call sites src/groth16.cpp:55,58,61,64,154 ; src/ultra_groth.cpp:168,201,214,227,234,322
+ *       (the base arrays are the zkey sections handed to makeProver, src/groth16.cpp:9-46,
+ *        src/prover.cpp:162-178)
+ *
+ *   ug_hpoly_create / ug_hpoly_run
+ *       FFT<Fr>(2 * domainSize) ctor            src/groth16.hpp:109
+ *       the a/b/c block of Prover::prove        src/groth16.cpp:66-148
+ *         (zero, sparse coefficient scatter-add, a o b, 3 x {ifft, root(.) twist, fft}, a o b - c,
+ *          fromMontgomery), twin in src/ultra_groth.cpp:243-320
+ *
+ *   ug_fr_ntt            FFT<Fr>::fft / ifft on a host buffer    (src/groth16.cpp:112,120)
+ *   ug_field_op          F{r,q}_rawMMul / rawAdd / rawSub        (build/fr_raw_generic.cpp:11-39,107-148)
+ *
+ * Byte formats are the reference's: field elements are 32-byte little-endian; "Montgomery" means
+ * value * 2^256 mod p (build/fr_raw_generic.cpp:192); G1 affine records are (x, y) Montgomery, 64 bytes;
+ * G2 records are (x.a, x.b, y.a, y.b), 128 bytes; an all-zero record is the point at infinity; MSM
+ * scalars and witness values are plain integers. Inputs may be unaligned (zkey sections start at
+ * 4 mod 8); outputs are written with memcpy semantics.
+ */
+#ifndef ULTRAGROTH_HIP_H
+#define ULTRAGROTH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UG_OK 0
+#define UG_ERROR 1
+
+#define UG_FIELD_FR 0
+#define UG_FIELD_FQ 1
+#define UG_OP_MUL 0
+#define UG_OP_ADD 1
+#define UG_OP_SUB 2
+#define UG_OP_SQR 3
+
+typedef struct ug_ctx ug_ctx;            /* one device + one stream + reusable workspaces           */
+typedef struct ug_bases ug_bases;        /* a G1 or G2 base-point array resident in HBM              */
+typedef struct ug_dvec ug_dvec;          /* a device vector of 32-byte elements (witness, h, ...)    */
+typedef struct ug_schedule ug_schedule;  /* signed-digit bucket schedule of a range of a ug_dvec     */
+typedef struct ug_hpoly ug_hpoly;        /* coefficient matrix + NTT tables of one circuit           */
+
+/* message of the last failing call on this thread ("" if none) */
+const char* ug_last_error(void);
+/* number of visible HIP devices, or -1 when the HIP runtime cannot be initialised */
+int ug_device_count(void);
+
+int  ug_ctx_create(ug_ctx** ctx, int device);
+void ug_ctx_destroy(ug_ctx* ctx);
+/* block until all work queued on the context's stream has finished */
+int  ug_ctx_sync(ug_ctx* ctx);
+
+/* Upload n affine points (zkey record format) and convert them to the device form. The array stands for
+ * the global point indices [global_first, global_first + n) of its zkey section, so that a rank of a
+ * sharded prover can hold a slice. */
+int  ug_bases_create_g1(ug_ctx* ctx, const void* host_points, uint64_t n, uint64_t global_first, ug_bases** out);
+int  ug_bases_create_g2(ug_ctx* ctx, const void* host_points, uint64_t n, uint64_t global_first, ug_bases** out);
+void ug_bases_destroy(ug_bases* b);
+
+/* device vectors of n 32-byte elements */
+int  ug_dvec_create(ug_ctx* ctx, uint64_t n, ug_dvec** out);
+int  ug_dvec_upload(ug_dvec* v, const void* host, uint64_t n);           /* host -> device, n <= capacity */
+int  ug_dvec_download(const ug_dvec* v, void* host, uint64_t first, uint64_t n);
+/* out[i] = src[index[i]] for i < n (UltraGroth round / final witness gathers, src/ultra_groth.cpp:415-445) */
+int  ug_dvec_gather(ug_dvec* out, const ug_dvec* src, const uint32_t* host_index, uint64_t n);
+uint64_t ug_dvec_size(const ug_dvec* v);
+void ug_dvec_destroy(ug_dvec* v);
+
+/* Decompose scalars [first, first + count) of `scalars` (plain 32-byte integers) into signed window
+ * digits grouped by bucket. One schedule serves every base set multiplied by the same scalars. */
+int  ug_schedule_create(ug_ctx* ctx, ug_schedule** out);
+int  ug_schedule_build(ug_schedule* s, const ug_dvec* scalars, uint64_t first, uint64_t count);
+void ug_schedule_destroy(ug_schedule* s);
+
+/* out = sum over the schedule's scalars s_i (global index i) of s_i * P_{i - index_shift}; points whose
+ * global index falls outside the uploaded slice are skipped. out is an affine record in the reference
+ * format (64 bytes for G1, 128 for G2; all zero = infinity). */
+int  ug_msm_g1(ug_ctx* ctx, const ug_bases* bases, const ug_schedule* s, int64_t index_shift, void* out_affine);
+int  ug_msm_g2(ug_ctx* ctx, const ug_bases* bases, const ug_schedule* s, int64_t index_shift, void* out_affine);
+
+/* coefs: n_coefs packed 44-byte records {u32 m, u32 c, u32 s, Fr coef} (zkey section 4 past its 4-byte
+ * count, src/groth16.cpp:38). Builds the row-sorted matrix and the NTT tables for domain_size. */
+int  ug_hpoly_create(ug_ctx* ctx, const void* host_coefs, uint64_t n_coefs, uint32_t domain_size,
+                     uint32_t n_vars, ug_hpoly** out);
+/* h (domain_size plain integers) from the witness (n_vars plain integers), all on the device */
+int  ug_hpoly_run(ug_hpoly* hp, const ug_dvec* witness, ug_dvec* h_out);
+/* optional: also return the three coset evaluation vectors (reference Montgomery form), for tests */
+int  ug_hpoly_debug_abc(ug_hpoly* hp, void* host_a, void* host_b, void* host_c);
+void ug_hpoly_destroy(ug_hpoly* hp);
+
+/* In-place size-2^logn transform of a host buffer of Montgomery Fr elements, natural order in and out.
+ * inverse != 0 also scales by 1/n. */
+int  ug_fr_ntt(ug_ctx* ctx, void* host_data, int logn, int inverse);
+/* out[i] = a[i] (op) b[i] on n Montgomery elements of the chosen field (host buffers) */
+int  ug_field_op(ug_ctx* ctx, int field, int op, void* out, const void* a, const void* b, uint64_t n);
+
+/* milliseconds of device time spent in the MSM and H-polynomial parts since the last reset
+ * (the MSM | FFT split the reference prints in src/ultra_groth.cpp:199-335) */
+int  ug_ctx_timings(ug_ctx* ctx, double* msm_ms, double* fft_ms, int reset);
+
+/* HIP events over one kernel of the hot path for roofline reporting: average duration in ms of the
+ * bucket-accumulation launches since the last reset, their count, and the points they processed */
+int  ug_ctx_kernel_stats(ug_ctx* ctx, double* accumulate_ms_avg, uint64_t* launches, uint64_t* entries, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

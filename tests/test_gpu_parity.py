@@ -1,0 +1,172 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI, against the CPU oracle on the same inputs."""
+import hashlib
+import json
+import random
+
+import pytest
+
+import oracle as O
+from oracle import pairing
+from conftest import fixed_rs
+
+pytestmark = pytest.mark.gpu
+
+
+def _sec(buf, ftype, sid):
+    off, sz = O.section(buf, ftype, sid)
+    return buf[off:off + sz]
+
+
+def _rand_elems(rng, mod, n):
+    edge = [0, 1, 2, mod - 1, mod - 2, (1 << 256) % mod, (1 << 255) % mod]
+    vals = edge + [rng.randrange(mod) for _ in range(n - len(edge))]
+    return vals
+
+
+@pytest.mark.parametrize("field,mod", [(O.FR, O.R_MOD), (O.FQ, O.Q_MOD)])
+def test_field_ops_bit_exact(device, field, mod):
+    import ultragroth_amd as ug
+    rng = random.Random(11 + field)
+    n = 4096
+    a = _rand_elems(rng, mod, n)
+    b = list(reversed(_rand_elems(rng, mod, n)))
+    ab = b"".join(O.to_le(x) for x in a)
+    bb = b"".join(O.to_le(x) for x in b)
+    for op, name in ((ug.OP_MUL, "mul"), (ug.OP_ADD, "add"), (ug.OP_SUB, "sub")):
+        got = device.field_op(field, op, ab, bb)
+        for i in range(n):
+            exp = O.f_op(name, field, a[i], b[i])
+            assert O.from_le(got[32 * i:32 * i + 32]) == exp, (name, i)
+
+
+@pytest.mark.parametrize("logn", [0, 1, 2, 5, 10, 11, 12, 14, 17])
+def test_ntt_matches_oracle(device, logn):
+    rng = random.Random(100 + logn)
+    n = 1 << logn
+    data = b"".join(O.to_le(rng.randrange(O.R_MOD)) for _ in range(n))
+    fwd = device.ntt(data, logn, inverse=False)
+    assert fwd == O.ntt(data, logn, inverse=False)
+    inv = device.ntt(data, logn, inverse=True)
+    assert inv == O.ntt(data, logn, inverse=True)
+    assert device.ntt(fwd, logn, inverse=True) == data            # round trip
+
+
+def test_ntt_root_convention(device):
+    """omega_2048 = 5^((r-1)/2^11): the transform of the delta at index 1 is [omega^k]."""
+    logn = 11
+    one_m = O.to_le((1 << 256) % O.R_MOD)
+    data = bytes(32) + one_m + bytes(32 * ((1 << logn) - 2))
+    out = device.ntt(data, logn)
+    w = O.mont_decode(out[32:64], O.R_MOD)
+    assert w == 1120550406532664055539694724667294622065367841900378087843176726913374367458
+
+
+def test_msm_g1_fixture_sections(device, zkey, wtns):
+    """Raw MSMs over the reference fixture's own sections: SURVEY.md Appendix A known answers."""
+    info = O.zkey_info(zkey)
+    w = _sec(wtns, "wtns", 2)
+    n = info["nVars"]
+    got = device.msm_g1(_sec(zkey, "zkey", 5), w, n)
+    assert got == O.g1_msm(_sec(zkey, "zkey", 5), w, n)
+    assert O.mont_decode(got[:32]) == 21344626350637401086172020791957193447896122895487902080665101052945368184094
+    assert O.mont_decode(got[32:]) == 6713982217719299172625616378045403143338774554356668389789068804132537304884
+    got = device.msm_g1(_sec(zkey, "zkey", 6), w, n)                      # B1 has 3 points at infinity
+    assert O.mont_decode(got[:32]) == 8193048668315265143422292719263587730195930046948232152095219516163543912381
+
+
+def test_msm_g2_fixture_section(device, zkey, wtns):
+    info = O.zkey_info(zkey)
+    w = _sec(wtns, "wtns", 2)
+    got = device.msm_g2(_sec(zkey, "zkey", 7), w, info["nVars"])
+    assert got == O.g2_msm(_sec(zkey, "zkey", 7), w, info["nVars"])
+    assert O.mont_decode(got[:32]) == 7062321476789293854033358658370016416373968873586528291130727575191400769869
+
+
+def _scalar_mix(rng, n):
+    """edge-heavy scalars: zeros, ones, small, r-1, values >= r, all-ones windows, uniform"""
+    out = []
+    for i in range(n):
+        k = rng.randrange(10)
+        if k == 0: v = 0
+        elif k == 1: v = 1
+        elif k == 2: v = rng.randrange(1 << 32)
+        elif k == 3: v = O.R_MOD - 1 - rng.randrange(3)
+        elif k == 4: v = O.R_MOD + rng.randrange(1 << 200)        # malformed witness value >= r
+        elif k == 5: v = (1 << 254) - 1
+        else: v = rng.randrange(O.R_MOD)
+        out.append(v)
+    return out
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 500, 1000])
+def test_msm_g1_edge_scalars(device, zkey, n):
+    rng = random.Random(7 * n + 1)
+    pts = _sec(zkey, "zkey", 9)[:64 * n]                     # H points
+    sc = b"".join(O.to_le(v) for v in _scalar_mix(rng, n))
+    assert device.msm_g1(pts, sc, n) == O.g1_msm(pts, sc, n)
+
+
+def test_msm_heavy_bucket_and_duplicates(device, zkey):
+    """many equal scalars on equal points: one giant bucket (block-parallel path) and the doubling branch"""
+    rng = random.Random(5)
+    base = _sec(zkey, "zkey", 5)
+    n = 6000
+    pts = b"".join(base[64 * (i % 7 + 2):64 * (i % 7 + 3)] for i in range(n))     # 7 distinct points repeated
+    sc = b"".join(O.to_le(1 if i % 3 else rng.randrange(4)) for i in range(n))
+    assert device.msm_g1(pts, sc, n) == O.g1_msm(pts, sc, n)
+    # P and -P with the same scalar cancel
+    p = base[64 * 4:64 * 5]
+    negp = p[:32] + O.to_le((O.Q_MOD - O.from_le(p[32:])) % O.Q_MOD)
+    assert device.msm_g1(p + negp, O.to_le(12345) * 2, 2) == bytes(64)
+
+
+@pytest.mark.parametrize("n", [1, 300])
+def test_msm_g2_edge_scalars(device, zkey, n):
+    rng = random.Random(3 * n + 2)
+    pts = _sec(zkey, "zkey", 7)[:128 * n]
+    sc = b"".join(O.to_le(v) for v in _scalar_mix(rng, n))
+    assert device.msm_g2(pts, sc, n) == O.g2_msm(pts, sc, n)
+
+
+def test_hpoly_matches_oracle_and_known_answers(device, zkey, wtns):
+    info = O.zkey_info(zkey)
+    coefs = _sec(zkey, "zkey", 4)[4:]
+    w = _sec(wtns, "wtns", 2)
+    hp = device.hpoly(coefs, info["nCoefs"], info["domainSize"], info["nVars"])
+    hv = hp.run(device.dvec(info["nVars"], w))
+    h = device.download(hv, 0, info["domainSize"])
+    h_exp, abc = O.hpoly(coefs, info["nCoefs"], w, info["nVars"], info["domainSize"], want_abc=True)
+    assert h == h_exp
+    assert hashlib.sha256(h).hexdigest() == "44ca2358066ca82cffac3cc7f58f163f8cd806059850dea84e12cde01ff3b872"
+    a, b, c = hp.debug_abc()
+    n = info["domainSize"] * 32
+    assert a == abc[:n] and b == abc[n:2 * n] and c == abc[2 * n:]
+
+
+def test_groth16_proof_bit_exact_and_valid(zkey, wtns, vkey):
+    """Full prove through the reference's C API with the Appendix A blinding: byte-identical to the oracle and to
+    the committed known answer, and accepted by the reference's acceptance test (pairing check)."""
+    import ultragroth_amd as ug
+    r, s = fixed_rs()
+    ug.set_test_blinding(r + s)
+    try:
+        with ug.Groth16Prover(zkey) as p:
+            proof, pub = p.prove(wtns)
+            proof2, pub2 = p.prove(wtns)                  # the handle is reusable
+    finally:
+        ug.set_test_blinding(b"")
+    exp_proof, exp_pub = O.groth16_prove(zkey, wtns, int.from_bytes(r, "little"), int.from_bytes(s, "little"))
+    assert proof == exp_proof and pub == exp_pub
+    assert proof2 == proof and pub2 == pub
+    assert hashlib.sha256(proof.encode()).hexdigest() == "11767e6c2a13edf5c87e282bc652346b4e62e0faa4156275edbef96c25762592"
+    assert pub == '["7713112592372404476342535432037683616424591277138491596200192981572885523208"]'
+    assert pairing.groth16_verify(vkey, pub, proof)
+    tampered = json.loads(pub)
+    tampered[0] = str(int(tampered[0]) - 1)
+    assert not pairing.groth16_verify(vkey, tampered, proof)
+
+
+def test_groth16_random_blinding_still_verifies(zkey, wtns, vkey):
+    import ultragroth_amd as ug
+    proof, pub = ug.groth16_prover(zkey, wtns)
+    assert pairing.groth16_verify(vkey, pub, proof)

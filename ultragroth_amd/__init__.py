@@ -1,0 +1,354 @@
+"""ultragroth_amd -- MI355X-native drop-in for the prover hot path of rarimo/ultragroth.
+
+Host-side mirror (Python) of the C interfaces in ``include/``:
+
+* :class:`Groth16Prover`, :class:`UltraGrothProver`, :func:`groth16_prover` ... mirror the reference's
+  ``extern "C"`` prover API (src/prover.h) -- same names, argument meaning and error behaviour,
+  with the status codes raised as :class:`ProverError` carrying ``code`` and the reference's message.
+* :class:`Device` exposes the inner ABI (``include/ultragroth_hip.h``): MSM, NTT, H polynomial and
+  field ops, in the reference's byte formats.
+
+All compute goes through ``libultragroth_hip.so`` (hand-written HIP for gfx950). There is no CPU
+fallback: without the library or without a GPU every call raises.
+"""
+import ctypes as C
+
+from . import _lib
+from ._lib import build, load, LIB_PATH
+
+PROVER_OK = 0
+PROVER_ERROR = 1
+PROVER_ERROR_SHORT_BUFFER = 2
+PROVER_INVALID_WITNESS_LENGTH = 3
+
+FR, FQ = 0, 1
+OP_MUL, OP_ADD, OP_SUB, OP_SQR = 0, 1, 2, 3
+GROTH16_PARTIALS_SIZE = 384
+
+
+class ProverError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(message)
+        self.code = code
+        self.message = message
+
+
+class DeviceError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise DeviceError(load().ug_last_error().decode(errors="replace"))
+
+
+def device_count():
+    return load().ug_device_count()
+
+
+def set_test_blinding(data):
+    """Queue bytes for the prover's blinding draws (31 bytes each); b'' restores OS entropy."""
+    data = bytes(data)
+    load().ug_test_set_blinding(data if data else None, len(data))
+
+
+def _buf(b):
+    return (C.c_char * len(b)).from_buffer_copy(b) if not isinstance(b, C.Array) else b
+
+
+# ---------------------------------------------------------------------------------------------------
+# outer API mirror (src/prover.h)
+
+def groth16_proof_size():
+    v = C.c_ulonglong()
+    load().groth16_proof_size(C.byref(v))
+    return v.value
+
+
+def ultra_groth_proof_size():
+    v = C.c_ulonglong()
+    load().ultra_groth_proof_size(C.byref(v))
+    return v.value
+
+
+def _public_size(fn, zkey):
+    v = C.c_ulonglong()
+    err = C.create_string_buffer(1024)
+    rc = fn(zkey, len(zkey), C.byref(v), err, len(err) - 1)
+    if rc != PROVER_OK:
+        raise ProverError(rc, err.value.decode(errors="replace"))
+    return v.value
+
+
+def groth16_public_size_for_zkey_buf(zkey):
+    return _public_size(load().groth16_public_size_for_zkey_buf, zkey)
+
+
+def ultra_groth_public_size_for_zkey_buf(zkey):
+    return _public_size(load().ultra_groth_public_size_for_zkey_buf, zkey)
+
+
+class _ProverBase:
+    _create = _prove = _destroy = _public_size_fn = None
+    _proof_size = staticmethod(groth16_proof_size)
+
+    def __init__(self, zkey):
+        L = load()
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(1024)
+        rc = getattr(L, self._create)(C.byref(self._h), zkey, len(zkey), err, len(err) - 1)
+        if rc != PROVER_OK:
+            self._h = None
+            raise ProverError(rc, err.value.decode(errors="replace"))
+        self._public_size = _public_size(getattr(L, self._public_size_fn), zkey)
+
+    def prove(self, wtns, proof_size=None, public_size=None):
+        """Returns (proof_json, public_json) -- the buffers up to their first NUL, as the CLI writes them."""
+        L = load()
+        psz = C.c_ulonglong(self._proof_size() if proof_size is None else proof_size)
+        qsz = C.c_ulonglong(self._public_size if public_size is None else public_size)
+        proof = C.create_string_buffer(max(psz.value, 1))
+        pub = C.create_string_buffer(max(qsz.value, 1))
+        err = C.create_string_buffer(1024)
+        rc = getattr(L, self._prove)(self._h, wtns, len(wtns), proof, C.byref(psz), pub, C.byref(qsz), err, len(err) - 1)
+        if rc != PROVER_OK:
+            raise ProverError(rc, err.value.decode(errors="replace"))
+        return proof.raw.split(b"\0", 1)[0].decode(), pub.raw.split(b"\0", 1)[0].decode()
+
+    def last_timings(self):
+        """(msm_ms, fft_ms, total_ms) of the last prove: device time of the MSM and H-polynomial parts, host wall time."""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        load().ug_prover_last_timings(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def kernel_stats(self, reset=False):
+        """(avg ms, launches, entries) of the bucket-accumulation kernel since creation / last reset."""
+        a, l, e = C.c_double(), C.c_ulonglong(), C.c_ulonglong()
+        load().ug_prover_kernel_stats(self._h, C.byref(a), C.byref(l), C.byref(e), 1 if reset else 0)
+        return a.value, l.value, e.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            getattr(load(), self._destroy)(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class Groth16Prover(_ProverBase):
+    """groth16_prover_create / _prove / _destroy (src/prover.h:80-87,127-138,156-159)."""
+    _create, _prove, _destroy = "groth16_prover_create", "groth16_prover_prove", "groth16_prover_destroy"
+    _public_size_fn = "groth16_public_size_for_zkey_buf"
+
+
+class UltraGrothProver(_ProverBase):
+    """ultra_groth_prover_create / _prove / _destroy (src/prover.h:89-96,140-151,161-164)."""
+    _create, _prove, _destroy = "ultra_groth_prover_create", "ultra_groth_prover_prove", "ultra_groth_prover_destroy"
+    _public_size_fn = "ultra_groth_public_size_for_zkey_buf"
+    _proof_size = staticmethod(ultra_groth_proof_size)
+
+
+def groth16_prover(zkey, wtns):
+    """One-shot groth16_prover (src/prover.h:173-185)."""
+    with Groth16Prover(zkey) as p:
+        return p.prove(wtns)
+
+
+def ultra_groth_prover(zkey, wtns):
+    with UltraGrothProver(zkey) as p:
+        return p.prove(wtns)
+
+
+class ShardedGroth16Prover:
+    """One rank of a base-point-sharded Groth16 prover (one process per GPU): see include/prover.h."""
+
+    def __init__(self, zkey, device, rank, world):
+        L = load()
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(1024)
+        rc = L.ug_groth16_prover_create_sharded(C.byref(self._h), zkey, len(zkey), device, rank, world, err, len(err) - 1)
+        if rc != PROVER_OK:
+            self._h = None
+            raise ProverError(rc, err.value.decode(errors="replace"))
+        self._public_size = groth16_public_size_for_zkey_buf(zkey)
+
+    def load_witness(self, wtns):
+        err = C.create_string_buffer(1024)
+        rc = load().ug_groth16_prover_load_witness(self._h, wtns, len(wtns), err, len(err) - 1)
+        if rc != PROVER_OK:
+            raise ProverError(rc, err.value.decode(errors="replace"))
+
+    def run(self):
+        """Device part on the resident witness; returns this rank's 384-byte partial sums."""
+        out = C.create_string_buffer(GROTH16_PARTIALS_SIZE)
+        err = C.create_string_buffer(1024)
+        rc = load().ug_groth16_prover_run(self._h, out, err, len(err) - 1)
+        if rc != PROVER_OK:
+            raise ProverError(rc, err.value.decode(errors="replace"))
+        return out.raw
+
+    @staticmethod
+    def add_partials(acc, other):
+        a = C.create_string_buffer(bytes(acc), GROTH16_PARTIALS_SIZE)
+        if load().ug_groth16_partials_add(a, bytes(other)) != PROVER_OK:
+            raise ProverError(PROVER_ERROR, "partials add failed")
+        return a.raw
+
+    def finish(self, partials_sum):
+        psz = C.c_ulonglong(groth16_proof_size())
+        qsz = C.c_ulonglong(self._public_size)
+        proof = C.create_string_buffer(psz.value)
+        pub = C.create_string_buffer(max(qsz.value, 1))
+        err = C.create_string_buffer(1024)
+        rc = load().ug_groth16_prover_finish(self._h, bytes(partials_sum), proof, C.byref(psz), pub, C.byref(qsz), err, len(err) - 1)
+        if rc != PROVER_OK:
+            raise ProverError(rc, err.value.decode(errors="replace"))
+        return proof.raw.split(b"\0", 1)[0].decode(), pub.raw.split(b"\0", 1)[0].decode()
+
+    last_timings = _ProverBase.last_timings
+    kernel_stats = _ProverBase.kernel_stats
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().groth16_prover_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------------
+# inner ABI (include/ultragroth_hip.h)
+
+class Device:
+    """A ug_ctx plus convenience wrappers in the reference's byte formats."""
+
+    def __init__(self, device=0):
+        self._L = load()
+        self._h = C.c_void_p()
+        _check(self._L.ug_ctx_create(C.byref(self._h), device))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ug_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- raw handles
+    def bases(self, points, n, g2=False, global_first=0):
+        h = C.c_void_p()
+        fn = self._L.ug_bases_create_g2 if g2 else self._L.ug_bases_create_g1
+        _check(fn(self._h, points, n, global_first, C.byref(h)))
+        return _Handle(h, self._L.ug_bases_destroy, self)
+
+    def dvec(self, n, data=None):
+        h = C.c_void_p()
+        _check(self._L.ug_dvec_create(self._h, n, C.byref(h)))
+        v = _Handle(h, self._L.ug_dvec_destroy, self)
+        if data is not None:
+            _check(self._L.ug_dvec_upload(h, data, len(data) // 32))
+        return v
+
+    def download(self, dvec, first, n):
+        out = C.create_string_buffer(n * 32)
+        _check(self._L.ug_dvec_download(dvec.h, out, first, n))
+        return out.raw
+
+    def schedule(self, dvec, first, count):
+        h = C.c_void_p()
+        _check(self._L.ug_schedule_create(self._h, C.byref(h)))
+        s = _Handle(h, self._L.ug_schedule_destroy, self)
+        _check(self._L.ug_schedule_build(h, dvec.h, first, count))
+        return s
+
+    def msm(self, bases, schedule, index_shift=0, g2=False):
+        out = C.create_string_buffer(128 if g2 else 64)
+        fn = self._L.ug_msm_g2 if g2 else self._L.ug_msm_g1
+        _check(fn(self._h, bases.h, schedule.h, index_shift, out))
+        return out.raw
+
+    # -- one-shot helpers
+    def msm_g1(self, points, scalars, n):
+        """sum scalars[i] * points[i]; points n x 64 B zkey records, scalars n x 32 B plain integers."""
+        b = self.bases(points, n)
+        s = self.schedule(self.dvec(max(n, 1), scalars if n else None), 0, n)
+        return self.msm(b, s)
+
+    def msm_g2(self, points, scalars, n):
+        b = self.bases(points, n, g2=True)
+        s = self.schedule(self.dvec(max(n, 1), scalars if n else None), 0, n)
+        return self.msm(b, s, g2=True)
+
+    def ntt(self, data, logn, inverse=False):
+        buf = C.create_string_buffer(bytes(data), len(data))
+        _check(self._L.ug_fr_ntt(self._h, buf, logn, 1 if inverse else 0))
+        return buf.raw
+
+    def field_op(self, field, op, a, b):
+        n = len(a) // 32
+        out = C.create_string_buffer(max(len(a), 1))
+        _check(self._L.ug_field_op(self._h, field, op, out, bytes(a), bytes(b), n))
+        return out.raw[:len(a)]
+
+    def hpoly(self, coefs, ncoefs, domain, nvars):
+        h = C.c_void_p()
+        _check(self._L.ug_hpoly_create(self._h, coefs, ncoefs, domain, nvars, C.byref(h)))
+        return _HPoly(h, self, domain)
+
+    def timings(self, reset=False):
+        a, b = C.c_double(), C.c_double()
+        _check(self._L.ug_ctx_timings(self._h, C.byref(a), C.byref(b), 1 if reset else 0))
+        return a.value, b.value
+
+    def kernel_stats(self, reset=False):
+        a, l, e = C.c_double(), C.c_uint64(), C.c_uint64()
+        _check(self._L.ug_ctx_kernel_stats(self._h, C.byref(a), C.byref(l), C.byref(e), 1 if reset else 0))
+        return a.value, l.value, e.value
+
+
+class _Handle:
+    def __init__(self, h, destroy, owner):
+        self.h, self._destroy, self._owner = h, destroy, owner
+
+    def __del__(self):
+        try:
+            if self.h and getattr(self._owner, "_h", None):
+                self._destroy(self.h)
+            self.h = None
+        except Exception:
+            pass
+
+
+class _HPoly(_Handle):
+    def __init__(self, h, dev, domain):
+        super().__init__(h, dev._L.ug_hpoly_destroy, dev)
+        self.dev, self.domain = dev, domain
+
+    def run(self, wtns_dvec):
+        """h vector (domain x 32 B plain integers) as a device vector"""
+        out = self.dev.dvec(self.domain)
+        _check(self.dev._L.ug_hpoly_run(self.h, wtns_dvec.h, out.h))
+        return out
+
+    def debug_abc(self):
+        bufs = [C.create_string_buffer(self.domain * 32) for _ in range(3)]
+        _check(self.dev._L.ug_hpoly_debug_abc(self.h, *bufs))
+        return [b.raw for b in bufs]

@@ -1,0 +1,115 @@
+"""ctypes loader for libultragroth_hip.so (built in-tree by ultragroth_amd/csrc/Makefile).
+
+The product path has no CPU fallback: if the shared library is missing or the HIP runtime has no
+device, every compute entry point fails loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libultragroth_hip.so")
+
+# every symbol that include/ultragroth_hip.h and include/prover.h declare
+INNER_SYMBOLS = [
+    "ug_last_error", "ug_device_count", "ug_ctx_create", "ug_ctx_destroy", "ug_ctx_sync",
+    "ug_bases_create_g1", "ug_bases_create_g2", "ug_bases_destroy",
+    "ug_dvec_create", "ug_dvec_upload", "ug_dvec_download", "ug_dvec_gather", "ug_dvec_size", "ug_dvec_destroy",
+    "ug_schedule_create", "ug_schedule_build", "ug_schedule_destroy",
+    "ug_msm_g1", "ug_msm_g2",
+    "ug_hpoly_create", "ug_hpoly_run", "ug_hpoly_debug_abc", "ug_hpoly_destroy",
+    "ug_fr_ntt", "ug_field_op", "ug_ctx_timings", "ug_ctx_kernel_stats",
+]
+OUTER_SYMBOLS = [
+    "groth16_public_size_for_zkey_buf", "ultra_groth_public_size_for_zkey_buf",
+    "groth16_public_size_for_zkey_file", "ultra_groth_public_size_for_zkey_file",
+    "groth16_proof_size", "ultra_groth_proof_size",
+    "groth16_prover_create", "ultra_groth_prover_create",
+    "groth16_prover_create_zkey_file", "ultra_groth_prover_create_zkey_file",
+    "groth16_prover_prove", "ultra_groth_prover_prove",
+    "groth16_prover_destroy", "ultra_groth_prover_destroy",
+    "groth16_prover", "ultra_groth_prover",
+    "groth16_prover_zkey_file", "ultra_groth_prover_zkey_file",
+    "ug_test_set_blinding", "ug_prover_last_timings", "ug_prover_kernel_stats",
+    "ug_groth16_prover_create_sharded", "ug_groth16_prover_load_witness", "ug_groth16_prover_run",
+    "ug_groth16_partials_add", "ug_groth16_prover_finish",
+]
+
+
+def build(jobs=4):
+    """Compile every HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-C", _CSRC, "-j%d" % jobs])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libultragroth_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C ultragroth_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i64, u32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_uint32
+    pp = C.POINTER(C.c_void_p)
+    ull, pull = C.c_ulonglong, C.POINTER(C.c_ulonglong)
+    L.ug_last_error.restype = C.c_char_p
+    L.ug_device_count.restype = C.c_int
+    L.ug_ctx_create.argtypes = [pp, C.c_int]
+    L.ug_ctx_destroy.argtypes = [vp]; L.ug_ctx_destroy.restype = None
+    L.ug_ctx_sync.argtypes = [vp]
+    for n in ("ug_bases_create_g1", "ug_bases_create_g2"):
+        getattr(L, n).argtypes = [vp, vp, u64, u64, pp]
+    L.ug_bases_destroy.argtypes = [vp]; L.ug_bases_destroy.restype = None
+    L.ug_dvec_create.argtypes = [vp, u64, pp]
+    L.ug_dvec_upload.argtypes = [vp, vp, u64]
+    L.ug_dvec_download.argtypes = [vp, vp, u64, u64]
+    L.ug_dvec_gather.argtypes = [vp, vp, vp, u64]
+    L.ug_dvec_size.argtypes = [vp]; L.ug_dvec_size.restype = u64
+    L.ug_dvec_destroy.argtypes = [vp]; L.ug_dvec_destroy.restype = None
+    L.ug_schedule_create.argtypes = [vp, pp]
+    L.ug_schedule_build.argtypes = [vp, vp, u64, u64]
+    L.ug_schedule_destroy.argtypes = [vp]; L.ug_schedule_destroy.restype = None
+    L.ug_msm_g1.argtypes = [vp, vp, vp, i64, vp]
+    L.ug_msm_g2.argtypes = [vp, vp, vp, i64, vp]
+    L.ug_hpoly_create.argtypes = [vp, vp, u64, u32, u32, pp]
+    L.ug_hpoly_run.argtypes = [vp, vp, vp]
+    L.ug_hpoly_debug_abc.argtypes = [vp, vp, vp, vp]
+    L.ug_hpoly_destroy.argtypes = [vp]; L.ug_hpoly_destroy.restype = None
+    L.ug_fr_ntt.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.ug_field_op.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, u64]
+    L.ug_ctx_timings.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
+    L.ug_ctx_kernel_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64), C.c_int]
+    # outer API (include/prover.h)
+    for n in ("groth16_public_size_for_zkey_buf", "ultra_groth_public_size_for_zkey_buf"):
+        getattr(L, n).argtypes = [vp, ull, pull, vp, ull]
+    for n in ("groth16_public_size_for_zkey_file", "ultra_groth_public_size_for_zkey_file"):
+        getattr(L, n).argtypes = [C.c_char_p, pull, vp, ull]
+    for n in ("groth16_proof_size", "ultra_groth_proof_size"):
+        getattr(L, n).argtypes = [pull]; getattr(L, n).restype = None
+    for n in ("groth16_prover_create", "ultra_groth_prover_create"):
+        getattr(L, n).argtypes = [pp, vp, ull, vp, ull]
+    for n in ("groth16_prover_create_zkey_file", "ultra_groth_prover_create_zkey_file"):
+        getattr(L, n).argtypes = [pp, C.c_char_p, vp, ull]
+    for n in ("groth16_prover_prove", "ultra_groth_prover_prove"):
+        getattr(L, n).argtypes = [vp, vp, ull, vp, pull, vp, pull, vp, ull]
+    for n in ("groth16_prover_destroy", "ultra_groth_prover_destroy"):
+        getattr(L, n).argtypes = [vp]; getattr(L, n).restype = None
+    for n in ("groth16_prover", "ultra_groth_prover"):
+        getattr(L, n).argtypes = [vp, ull, vp, ull, vp, pull, vp, pull, vp, ull]
+    for n in ("groth16_prover_zkey_file", "ultra_groth_prover_zkey_file"):
+        getattr(L, n).argtypes = [C.c_char_p, vp, ull, vp, pull, vp, pull, vp, ull]
+    L.ug_test_set_blinding.argtypes = [vp, ull]; L.ug_test_set_blinding.restype = None
+    L.ug_prover_last_timings.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ug_prover_kernel_stats.argtypes = [vp, C.POINTER(C.c_double), pull, pull, C.c_int]
+    L.ug_groth16_prover_create_sharded.argtypes = [pp, vp, ull, C.c_int, C.c_int, C.c_int, vp, ull]
+    L.ug_groth16_prover_load_witness.argtypes = [vp, vp, ull, vp, ull]
+    L.ug_groth16_prover_run.argtypes = [vp, vp, vp, ull]
+    L.ug_groth16_partials_add.argtypes = [vp, vp]
+    L.ug_groth16_prover_finish.argtypes = [vp, vp, vp, pull, vp, pull, vp, ull]
+    _lib = L
+    return L

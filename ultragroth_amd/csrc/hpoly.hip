@@ -1,0 +1,210 @@
+// hpoly.hip -- the Fr-side kernels of the H-polynomial block around the NTTs.
+//
+// Replaces these loops of Groth16::Prover::prove (src/groth16.cpp):
+//   :77-99   a = A.w, b = B.w   sparse scatter-add under 1024 striped mutexes
+//   :100-108 c = a o b
+//   :142-148 h = a o b - c, fromMontgomery
+// The reference's scatter with locks becomes a gather: the coefficient records are sorted by
+// (matrix, row) once at create time (hipcub radix sort on the device) into CSR form, and one lane
+// sums one row -- deterministic and atomic-free. Rows are written at their bit-reversed position so
+// that the first NTT pass reads contiguously.
+#include <hipcub/hipcub.hpp>
+#include "dev_common.hpp"
+#include "internal.hpp"
+
+namespace ug {
+
+namespace {
+
+__global__ void coef_keys_kernel(const uint8_t* raw, u64 ncoefs, u32 domain, u32 nvars, u32* keys, u32* idx, u32* bad) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncoefs) return;
+    const u32* rec = reinterpret_cast<const u32*>(raw + i * 44);
+    u32 m = rec[0], c = rec[1], s = rec[2];
+    if (m > 1 || c >= domain || s >= nvars) { atomicOr(bad, 1u); m = 0; c = 0; }
+    keys[i] = m * domain + c;
+    idx[i] = (u32)i;
+}
+__global__ void coef_gather_kernel(const uint8_t* raw, u64 ncoefs, const u32* idx, u32* sig, u32* val) {
+    u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= ncoefs) return;
+    const u32* rec = reinterpret_cast<const u32*>(raw + (u64)idx[p] * 44);
+    sig[p] = rec[2];
+    u32 w[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = rec[3 + k];
+    // stored value is coef * 2^512; bring it to coef * 2^522 so that
+    // mul(w_plain, val) = w * coef * 2^261
+    Fr v = cond_sub_q(mul(unpack256<FrParams>(w), fp_from<FrParams>(FrParams::coef512)));
+    st_packed(val + p * 8, v);
+}
+__global__ void row_ptr_kernel(const u32* keys, u64 ncoefs, u32 nrows, u32* row_ptr) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nrows) return;
+    u64 lo = 0, hi = ncoefs;                     // first position with key >= r
+    while (lo < hi) {
+        u64 mid = (lo + hi) >> 1;
+        if (keys[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    row_ptr[r] = (u32)lo;
+}
+
+__global__ __launch_bounds__(256) void matvec_kernel(u32* a_br, u32* b_br, const u32* row_ptr, const u32* sig,
+                                                     const u32* val, const u32* wtns, u32 domain, int logn) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= 2 * domain) return;
+    u32 s = row_ptr[r], e = row_ptr[r + 1];
+    Fr acc = fp_zero<FrParams>();
+    u32 since = 0;
+    for (u32 p = s; p < e; p++) {
+        Fr w = ld_packed<FrParams>(wtns + (size_t)sig[p] * 8);       // plain integer, any value < 2^256
+        Fr v = ld_packed<FrParams>(val + (size_t)p * 8);
+        acc = add(acc, mul(w, v));                                    // + < 2q
+        if (++since == 24) { acc = contract(acc); since = 0; }        // keep below 64 q
+    }
+    acc = contract(acc);
+    u32 c = r >= domain ? r - domain : r;
+    u32* dst = (r >= domain ? b_br : a_br) + (size_t)bit_reverse(c, logn) * 8;
+    st_packed(dst, acc);
+}
+
+__global__ void mul_pointwise_kernel(u32* out, const u32* x, const u32* y, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st_packed(out + i * 8, mul(ld_packed<FrParams>(x + i * 8), ld_packed<FrParams>(y + i * 8)));
+}
+__global__ void h_final_kernel(u32* h, const u32* a, const u32* b, const u32* c, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr t = mul(ld_packed<FrParams>(a + i * 8), ld_packed<FrParams>(b + i * 8));    // < 2q
+    Fr u = sub<6>(t, ld_packed<FrParams>(c + i * 8));                               // c < 2^256 < 5.3 q
+    u32 w[8];
+    to_normal(w, u);
+    store8(h + i * 8, w);
+}
+__global__ void from_mont256_kernel(u32* out, const u32* in, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[8];
+    load8(w, in + i * 8);
+    st_packed(out + i * 8, from_mont256<FrParams>(w));
+}
+__global__ void to_mont256_kernel(u32* out, const u32* in, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[8];
+    to_mont256(w, ld_packed<FrParams>(in + i * 8));
+    store8(out + i * 8, w);
+}
+template <class P>
+__global__ void f_op_mont256_kernel(int op, u32* out, const u32* a, const u32* b, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 wa[8], wb[8], wo[8];
+    load8(wa, a + i * 8); load8(wb, b + i * 8);
+    Fp<P> x = from_mont256<P>(wa), y = from_mont256<P>(wb), r;
+    switch (op) {
+        case 0: r = mul(x, y); break;
+        case 1: r = add(x, y); break;
+        case 2: r = sub<2>(x, y); break;
+        default: r = sqr(x); break;
+    }
+    to_mont256(wo, r);
+    store8(out + i * 8, wo);
+}
+
+__global__ void gather_kernel(u32* out, const u32* src, const u32* index, u64 n, u64 src_n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 j = index[i];
+    if (j < src_n) load8(w, src + j * 8);
+    store8(out + i * 8, w);
+}
+
+template <class T> void dev_alloc(T*& p, size_t bytes) { if (p) hipFree(p); p = nullptr; UG_HIP(hipMalloc(&p, bytes ? bytes : 4)); }
+inline unsigned grid_for(u64 n, int block) { return (unsigned)((n + block - 1) / block); }
+
+}  // namespace
+
+bool CoefMatrix::build(const uint8_t* raw44_dev, u64 ncoefs_, u32 domain_, u32 nvars, hipStream_t stream) {
+    release();
+    ncoefs = ncoefs_; domain = domain_;
+    logn = 0;
+    while ((1u << logn) < domain) logn++;
+    if (ncoefs >= ((u64)1 << 31)) throw std::invalid_argument("coefficient count exceeds 2^31");
+    u32 nrows = 2 * domain;
+    u32 *keys_a = nullptr, *keys_b = nullptr, *idx_a = nullptr, *idx_b = nullptr, *bad = nullptr;
+    void* tmp = nullptr;
+    dev_alloc(keys_a, ncoefs * 4); dev_alloc(keys_b, ncoefs * 4);
+    dev_alloc(idx_a, ncoefs * 4); dev_alloc(idx_b, ncoefs * 4);
+    dev_alloc(bad, 4);
+    dev_alloc(row_ptr, ((size_t)nrows + 1) * 4);
+    dev_alloc(sig, ncoefs * 4);
+    dev_alloc(val, ncoefs * 32);
+    UG_HIP(hipMemsetAsync(bad, 0, 4, stream));
+    u32 bad_host = 0;
+    if (ncoefs) {
+        hipLaunchKernelGGL(coef_keys_kernel, dim3(grid_for(ncoefs, 256)), dim3(256), 0, stream, raw44_dev, ncoefs, domain, nvars, keys_a, idx_a, bad);
+        UG_KERNEL_CHECK();
+        int end_bit = 1;
+        while (((u64)1 << end_bit) < nrows) end_bit++;
+        hipcub::DoubleBuffer<u32> dk(keys_a, keys_b), dv(idx_a, idx_b);
+        size_t need = 0;
+        UG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, dk, dv, (int)ncoefs, 0, end_bit, stream));
+        dev_alloc(tmp, need);
+        UG_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, need, dk, dv, (int)ncoefs, 0, end_bit, stream));
+        hipLaunchKernelGGL(coef_gather_kernel, dim3(grid_for(ncoefs, 256)), dim3(256), 0, stream, raw44_dev, ncoefs, dv.Current(), sig, val);
+        UG_KERNEL_CHECK();
+        hipLaunchKernelGGL(row_ptr_kernel, dim3(grid_for((u64)nrows + 1, 256)), dim3(256), 0, stream, dk.Current(), ncoefs, nrows, row_ptr);
+        UG_KERNEL_CHECK();
+        UG_HIP(hipMemcpyAsync(&bad_host, bad, 4, hipMemcpyDeviceToHost, stream));
+    } else {
+        UG_HIP(hipMemsetAsync(row_ptr, 0, ((size_t)nrows + 1) * 4, stream));
+    }
+    UG_HIP(hipStreamSynchronize(stream));
+    hipFree(keys_a); hipFree(keys_b); hipFree(idx_a); hipFree(idx_b); hipFree(bad);
+    if (tmp) hipFree(tmp);
+    return bad_host == 0;
+}
+
+void CoefMatrix::release() {
+    if (row_ptr) hipFree(row_ptr);
+    if (sig) hipFree(sig);
+    if (val) hipFree(val);
+    row_ptr = sig = val = nullptr;
+}
+
+void coef_matvec(u32* a_br, u32* b_br, const CoefMatrix& m, const u32* wtns_dev, hipStream_t stream) {
+    hipLaunchKernelGGL(matvec_kernel, dim3(grid_for((u64)2 * m.domain, 256)), dim3(256), 0, stream,
+                       a_br, b_br, m.row_ptr, m.sig, m.val, wtns_dev, m.domain, m.logn);
+    UG_KERNEL_CHECK();
+}
+void fr_mul_pointwise(u32* out, const u32* x, const u32* y, u64 n, hipStream_t stream) {
+    hipLaunchKernelGGL(mul_pointwise_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, out, x, y, n);
+    UG_KERNEL_CHECK();
+}
+void fr_h_final(u32* h, const u32* a, const u32* b, const u32* c, u64 n, hipStream_t stream) {
+    hipLaunchKernelGGL(h_final_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, h, a, b, c, n);
+    UG_KERNEL_CHECK();
+}
+void fr_from_mont256(u32* out, const u32* in, u64 n, hipStream_t stream) {
+    hipLaunchKernelGGL(from_mont256_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, out, in, n);
+    UG_KERNEL_CHECK();
+}
+void fr_to_mont256(u32* out, const u32* in, u64 n, hipStream_t stream) {
+    hipLaunchKernelGGL(to_mont256_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, out, in, n);
+    UG_KERNEL_CHECK();
+}
+void gather_elements(u32* out, const u32* src, const u32* index_dev, u64 n, u64 src_n, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(gather_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, out, src, index_dev, n, src_n);
+    UG_KERNEL_CHECK();
+}
+void f_op_mont256(int which, int op, u32* out, const u32* a, const u32* b, u64 n, hipStream_t stream) {
+    if (which == 0) hipLaunchKernelGGL(f_op_mont256_kernel<FrParams>, dim3(grid_for(n, 256)), dim3(256), 0, stream, op, out, a, b, n);
+    else hipLaunchKernelGGL(f_op_mont256_kernel<FqParams>, dim3(grid_for(n, 256)), dim3(256), 0, stream, op, out, a, b, n);
+    UG_KERNEL_CHECK();
+}
+
+}  // namespace ug

@@ -1,0 +1,117 @@
+// internal.hpp -- host-side interfaces between the translation units of libultragroth_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+#include <vector>
+#include "ec.hpp"
+
+namespace ug {
+
+// ---- ntt.hip ------------------------------------------------------------------------------------------
+Fr fr_root_of_unity(int s);
+void bitrev_copy(u32* out, const u32* in, int logn, hipStream_t stream);
+
+struct NttPlan {
+    int logn = -1;
+    u32* tw_fwd = nullptr;    // omega_n^i,   i < n/2
+    u32* tw_inv = nullptr;    // omega_n^-i,  i < n/2
+    u32* twist = nullptr;     // n^-1 * omega_{2n}^i, i < n   (coset twist with the ifft scale folded in)
+    u32* ninv = nullptr;      // n^-1 (one element)
+    void init(int logn, hipStream_t stream);
+    void release();
+    // DIT transform; see ntt.hip for the buffer rules. post / post_const are optional multipliers
+    // applied in the last pass: out[i] *= post[i], or out[i] *= *post_const.
+    void transform(u32* out, const u32* in, bool inverse, bool gather_bitrev, bool scatter_bitrev,
+                   const u32* post, const u32* post_const, hipStream_t stream) const;
+    ~NttPlan() { release(); }
+};
+
+// ---- msm.hip ------------------------------------------------------------------------------------------
+struct MsmGeometry {
+    u64 n = 0;          // number of scalars
+    int c = 0;          // window bits
+    int windows = 0;    // ceil(255 / c)
+    u32 buckets = 0;    // per window: 2^(c-1)
+    static MsmGeometry choose(u64 n, int force_c = 0);
+    u64 total_buckets() const { return (u64)windows * buckets; }
+};
+
+struct HeavyTask { u32 bucket, start, len, slot; };          // a slice of a heavy bucket's entries
+struct HeavyBucket { u32 bucket, first_slot, nslots, pad; };  // the task partials that make up one bucket
+
+// Signed-digit decomposition of n scalars, grouped by (window, bucket): shared by every base set that
+// is multiplied by the same scalars (A, B1, B2 and C all use the witness, src/groth16.cpp:55-64).
+struct MsmSchedule {
+    MsmGeometry geo;
+    const u32* vals = nullptr;    // sorted entries: scalar index | sign << 31
+    u32* bucket_start = nullptr;  // per bucket: first entry
+    u32* bucket_count = nullptr;  // per bucket: number of entries
+    // buckets with more than HEAVY entries, cut into workgroup-sized tasks
+    u32 n_tasks = 0, n_heavy = 0;
+    HeavyTask* heavy_tasks_dev = nullptr;
+    HeavyBucket* heavy_buckets_dev = nullptr;
+    // workspace
+    u32 *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
+    u32* heavy_list = nullptr;    // device: [count, (bucket, start, count) * MAX_HEAVY]
+    void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+    u64 capacity_n = 0; u64 capacity_buckets = 0;
+    void reserve(const MsmGeometry& g);
+    void build(const u32* scalars_dev, const MsmGeometry& g, hipStream_t stream);   // scalars: n x 32 B plain integers
+    void release();
+    ~MsmSchedule() { release(); }
+};
+
+struct MsmWorkspace {
+    u32* bucket_pts = nullptr;   // total_buckets XYZZ records
+    u32* chunk_pts = nullptr;    // reduction scratch
+    u32* chunk_pts2 = nullptr;
+    u32* task_pts = nullptr;     // heavy-task partial sums
+    size_t bucket_bytes = 0, chunk_bytes = 0, task_bytes = 0;
+    void reserve(const MsmGeometry& g, bool g2, u32 n_tasks);
+    void release();
+    ~MsmWorkspace() { release(); }
+};
+
+struct MsmStats {                 // HIP-event timing of the bucket-accumulation launches
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double accumulate_ms = 0; u64 launches = 0; u64 entries = 0;
+};
+
+// sum over the schedule's scalars (local index i) of scalar_i * base[i + delta]; bases is a device array
+// of n_bases packed affine records in device Montgomery form ((0,0) = infinity); entries whose base
+// index falls outside [0, n_bases) are skipped. Result is a host XYZZ point.
+G1XYZZ msm_g1(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta, hipStream_t stream, MsmStats* stats);
+G2XYZZ msm_g2(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta, hipStream_t stream, MsmStats* stats);
+
+// zkey affine records (reference Montgomery form, R = 2^256) -> device form, in place on the device
+void convert_points_g1(u32* pts, u64 n, hipStream_t stream);
+void convert_points_g2(u32* pts, u64 n, hipStream_t stream);
+
+// ---- hpoly.hip ----------------------------------------------------------------------------------------
+struct CoefMatrix {
+    u64 ncoefs = 0; u32 domain = 0; int logn = 0;
+    u32* row_ptr = nullptr;     // 2*domain + 1 offsets, rows = m * domain + c
+    u32* sig = nullptr;         // signal index per entry
+    u32* val = nullptr;         // packed coefficient per entry (device form, pre-scaled so that
+                                //   mul(w_plain, val) = w * coef in device Montgomery form)
+    // raw44: ncoefs packed 44-byte records {u32 m, u32 c, u32 s, 32-byte coef} already on the device
+    // (src/groth16.hpp:41-49). Returns false when a record is out of range.
+    bool build(const uint8_t* raw44_dev, u64 ncoefs, u32 domain, u32 nvars, hipStream_t stream);
+    void release();
+    ~CoefMatrix() { release(); }
+};
+
+// a_br[bitrev(c)] = sum coef * w  over m = 0 rows, b_br likewise for m = 1 (device form, packed)
+void coef_matvec(u32* a_br, u32* b_br, const CoefMatrix& m, const u32* wtns_dev, hipStream_t stream);
+// out[i] = x[i] * y[i]
+void fr_mul_pointwise(u32* out, const u32* x, const u32* y, u64 n, hipStream_t stream);
+// h[i] = plain integer of (a[i] * b[i] - c[i])      (src/groth16.cpp:142-148)
+void fr_h_final(u32* h, const u32* a, const u32* b, const u32* c, u64 n, hipStream_t stream);
+// element-wise format changes, n elements of 32 bytes
+void fr_from_mont256(u32* out, const u32* in, u64 n, hipStream_t stream);
+void fr_to_mont256(u32* out, const u32* in, u64 n, hipStream_t stream);
+void f_op_mont256(int which, int op, u32* out, const u32* a, const u32* b, u64 n, hipStream_t stream);
+void gather_elements(u32* out, const u32* src, const u32* index_dev, u64 n, u64 src_n, hipStream_t stream);
+
+}  // namespace ug

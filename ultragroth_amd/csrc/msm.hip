@@ -1,0 +1,466 @@
+// msm.hip -- Pippenger bucket multi-scalar multiplication in BN254 G1 and G2 for gfx950.
+//
+// Replaces Curve::multiMulByScalarMSM(r, bases, scalars, 32, n) of the reference's un-vendored
+// ffiasm submodule at its five call sites in the prover (src/groth16.cpp:55,58,61,64,154;
+// UltraGroth twins src/ultra_groth.cpp:168,201,214,227,234,322). Scalars are 32-byte plain integers.
+//
+// Pipeline (one "schedule" per scalar vector, shared by every base set multiplied by it):
+//   1. msm_digits_kernel     scalar -> signed c-bit digits (carry recoding), one (key,val) pair per
+//                            window: key = window * 2^(c-1) + |digit| - 1, val = index | sign << 31;
+//                            zero digits get a sentinel key and fall off the end of the sort
+//   2. hipcub radix sort     groups pairs by bucket                (coalesced, no atomics)
+//   3. bucket_bounds_kernel  first entry and entry count of every bucket; heavy buckets are listed
+//   4. bucket_accumulate     one lane per bucket: gather affine bases, mixed-add into XYZZ registers
+//      heavy_partial/final   buckets with more than HEAVY entries (witnesses are full of 0/1 values)
+//                            are cut into block-sized tasks and tree-reduced through LDS
+//   5. bucket_chunk_reduce   running-sum trick on chunks of 32 buckets + ec_sum_groups tree
+//   6. host                  Horner over the <= 64 window sums (c doublings each)
+//
+// Arithmetic volume dominates: each of the n * windows gathered bases costs one mixed addition
+// (G1: 8 mul + 2 sqr in Fq, G2: the same in Fq2). Algorithmic HBM bytes: 96 n (G1) / 160 n (G2).
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <cstring>
+#include "dev_common.hpp"
+#include "internal.hpp"
+
+namespace ug {
+
+namespace {
+
+constexpr u32 HEAVY = 256;            // buckets above this many entries take the block-parallel path
+constexpr u32 TASK_ENTRIES = 8192;    // entries per heavy task (one workgroup)
+constexpr u32 MAX_HEAVY = 8192;       // capacity of the heavy-bucket list
+constexpr int CHUNK = 32;             // buckets per running-sum chunk
+
+// ---- curve configurations -------------------------------------------------------------------------
+struct G1Cfg {
+    typedef Fq F;
+    static constexpr int AFF_WORDS = 16, PT_WORDS = 36, BLOCK = 256;
+    static __device__ __forceinline__ bool load_affine(const u32* p, F& x, F& y) {
+        u32 w[16];
+        load8(w, p); load8(w + 8, p + 8);
+        u32 o = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) o |= w[i];
+        if (o == 0) return false;
+        x = unpack256<FqParams>(w); y = unpack256<FqParams>(w + 8);
+        return true;
+    }
+    static __host__ __device__ __forceinline__ void to_words(u32* p, const XYZZ<F>& a, size_t stride) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            p[(size_t)i * stride] = a.x.l[i]; p[(size_t)(NL + i) * stride] = a.y.l[i];
+            p[(size_t)(2 * NL + i) * stride] = a.zz.l[i]; p[(size_t)(3 * NL + i) * stride] = a.zzz.l[i];
+        }
+    }
+    static __host__ __device__ __forceinline__ XYZZ<F> from_words(const u32* p, size_t stride) {
+        XYZZ<F> a;
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            a.x.l[i] = p[(size_t)i * stride]; a.y.l[i] = p[(size_t)(NL + i) * stride];
+            a.zz.l[i] = p[(size_t)(2 * NL + i) * stride]; a.zzz.l[i] = p[(size_t)(3 * NL + i) * stride];
+        }
+        return a;
+    }
+};
+struct G2Cfg {
+    typedef Fq2 F;
+    static constexpr int AFF_WORDS = 32, PT_WORDS = 72, BLOCK = 128;
+    static __device__ __forceinline__ bool load_affine(const u32* p, F& x, F& y) {
+        u32 w[32];
+        load8(w, p); load8(w + 8, p + 8); load8(w + 16, p + 16); load8(w + 24, p + 24);
+        u32 o = 0;
+#pragma unroll
+        for (int i = 0; i < 32; i++) o |= w[i];
+        if (o == 0) return false;
+        x.a = unpack256<FqParams>(w); x.b = unpack256<FqParams>(w + 8);
+        y.a = unpack256<FqParams>(w + 16); y.b = unpack256<FqParams>(w + 24);
+        return true;
+    }
+    static __host__ __device__ __forceinline__ void to_words(u32* p, const XYZZ<F>& a, size_t stride) {
+        const Fq* f[8] = {&a.x.a, &a.x.b, &a.y.a, &a.y.b, &a.zz.a, &a.zz.b, &a.zzz.a, &a.zzz.b};
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+#pragma unroll
+            for (int i = 0; i < NL; i++) p[(size_t)(k * NL + i) * stride] = f[k]->l[i];
+    }
+    static __host__ __device__ __forceinline__ XYZZ<F> from_words(const u32* p, size_t stride) {
+        XYZZ<F> a;
+        Fq* f[8] = {&a.x.a, &a.x.b, &a.y.a, &a.y.b, &a.zz.a, &a.zz.b, &a.zzz.a, &a.zzz.b};
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+#pragma unroll
+            for (int i = 0; i < NL; i++) f[k]->l[i] = p[(size_t)(k * NL + i) * stride];
+        return a;
+    }
+};
+
+// ---- 1. digits ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool geq_r(const u32* s) {
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+        if (s[i] > FrParams::q32[i]) return true;
+        if (s[i] < FrParams::q32[i]) return false;
+    }
+    return true;
+}
+__global__ void msm_digits_kernel(const u32* scalars, u64 n, int c, int windows, u32 buckets, u32 sentinel,
+                                  u32* keys, u32* vals) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 s[10];
+    load8(s, scalars + i * 8);
+    s[8] = 0; s[9] = 0;
+    // the group has order r: scalars >= r (never produced by a well-formed witness) are reduced
+    for (int it = 0; it < 6 && geq_r(s); it++) {
+        u64 borrow = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            u64 d = (u64)s[k] - FrParams::q32[k] - borrow;
+            s[k] = (u32)d; borrow = (d >> 32) & 1;
+        }
+    }
+    u32 carry = 0;
+    const u32 half = 1u << (c - 1), full = 1u << c, mask = full - 1;
+    for (int w = 0; w < windows; w++) {
+        int bit = w * c, word = bit >> 5, sh = bit & 31;
+        u64 two = (u64)s[word] | ((u64)s[word + 1] << 32);
+        u32 raw = ((u32)(two >> sh) & mask) + carry;
+        u32 key, val;
+        if (raw > half) {                       // negative digit raw - 2^c, carry into the next window
+            u32 mag = full - raw;               // 0 when the window was all ones and a carry came in
+            carry = 1;
+            key = mag ? (u32)w * buckets + mag - 1 : sentinel;
+            val = (u32)i | 0x80000000u;
+        }
+        else { carry = 0; key = raw ? (u32)w * buckets + raw - 1 : sentinel; val = (u32)i; }
+        keys[(u64)w * n + i] = key;
+        vals[(u64)w * n + i] = val;
+    }
+}
+
+// ---- 3. bucket bounds -----------------------------------------------------------------------------------
+__global__ void bucket_bounds_kernel(const u32* keys, u64 total, u32 sentinel, u32* start, u32* count) {
+    u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    u32 k = keys[p];
+    if (k == sentinel) return;
+    if (p == 0 || keys[p - 1] != k) start[k] = (u32)p;
+    if (p + 1 == total || keys[p + 1] != k) count[k] = (u32)p + 1;      // end for now
+}
+__global__ void bucket_counts_kernel(u32* start, u32* count, u32 nb, u32* heavy_list) {
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    u32 e = count[b];
+    u32 c = e ? e - start[b] : 0;
+    count[b] = c;
+    if (c > HEAVY) {
+        u32 pos = atomicAdd(&heavy_list[0], 1u);
+        if (pos < MAX_HEAVY) { heavy_list[1 + 3 * pos] = b; heavy_list[2 + 3 * pos] = start[b]; heavy_list[3 + 3 * pos] = c; }
+    }
+}
+
+// ---- 4. bucket accumulation -----------------------------------------------------------------------------
+template <class Cfg>
+__device__ __forceinline__ void accumulate_entry(XYZZ<typename Cfg::F>& acc, const u32* bases, u64 n_bases,
+                                                 int64_t delta, u32 v) {
+    typedef typename Cfg::F F;
+    int64_t sidx = (int64_t)(v & 0x7fffffffu) + delta;      // scalar index -> index into this base slice
+    if (sidx < 0 || (u64)sidx >= n_bases) return;
+    u64 idx = (u64)sidx;
+    F x, y;
+    if (!Cfg::load_affine(bases + idx * Cfg::AFF_WORDS, x, y)) return;
+    if (v >> 31) y = neg<1>(y);
+    acc = xyzz_madd(acc, x, y);
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(256) void bucket_accumulate_kernel(const u32* bases, u64 n_bases, int64_t delta,
+                                                                const u32* vals, const u32* start, const u32* count,
+                                                                u32 nb, u32* out) {
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    typedef typename Cfg::F F;
+    XYZZ<F> acc = xyzz_inf<F>();
+    u32 cnt = count[b];
+    if (cnt && cnt <= HEAVY) {
+        u32 s = start[b];
+        for (u32 k = 0; k < cnt; k++) accumulate_entry<Cfg>(acc, bases, n_bases, delta, vals[s + k]);
+    }
+    Cfg::to_words(out + (size_t)b * Cfg::PT_WORDS, acc, 1);
+}
+
+// workgroup tree reduction of one XYZZ per thread through LDS ([word][thread] planes); result in thread 0
+template <class Cfg>
+__device__ __forceinline__ XYZZ<typename Cfg::F> block_reduce(XYZZ<typename Cfg::F> acc, u32* lds) {
+    const int tid = threadIdx.x, nth = Cfg::BLOCK;
+    for (int stride = nth / 2; stride > 0; stride >>= 1) {
+        if (tid >= stride && tid < 2 * stride) Cfg::to_words(lds + (tid - stride), acc, stride);
+        __syncthreads();
+        if (tid < stride) acc = xyzz_add(acc, Cfg::from_words(lds + tid, stride));
+        __syncthreads();
+    }
+    return acc;
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::BLOCK) void heavy_partial_kernel(const u32* bases, u64 n_bases, int64_t delta,
+                                                                   const u32* vals, const HeavyTask* tasks, u32* partial) {
+    __shared__ u32 lds[Cfg::PT_WORDS * Cfg::BLOCK / 2];
+    typedef typename Cfg::F F;
+    HeavyTask t = tasks[blockIdx.x];
+    XYZZ<F> acc = xyzz_inf<F>();
+    for (u32 k = threadIdx.x; k < t.len; k += Cfg::BLOCK) accumulate_entry<Cfg>(acc, bases, n_bases, delta, vals[t.start + k]);
+    acc = block_reduce<Cfg>(acc, lds);
+    if (threadIdx.x == 0) Cfg::to_words(partial + (size_t)t.slot * Cfg::PT_WORDS, acc, 1);
+}
+// one workgroup per heavy bucket: sum its task partials, write the bucket
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::BLOCK) void heavy_final_kernel(const HeavyBucket* hb, const u32* partial, u32* buckets) {
+    __shared__ u32 lds[Cfg::PT_WORDS * Cfg::BLOCK / 2];
+    typedef typename Cfg::F F;
+    HeavyBucket h = hb[blockIdx.x];
+    XYZZ<F> acc = xyzz_inf<F>();
+    for (u32 k = threadIdx.x; k < h.nslots; k += Cfg::BLOCK)
+        acc = xyzz_add(acc, Cfg::from_words(partial + (size_t)(h.first_slot + k) * Cfg::PT_WORDS, 1));
+    acc = block_reduce<Cfg>(acc, lds);
+    if (threadIdx.x == 0) Cfg::to_words(buckets + (size_t)h.bucket * Cfg::PT_WORDS, acc, 1);
+}
+
+// ---- 5. bucket reduction --------------------------------------------------------------------------------
+// thread = (window, chunk of `chunk` buckets): P = sum_k (k_global + 1) * bucket_k over the chunk
+template <class Cfg>
+__global__ __launch_bounds__(128) void bucket_chunk_reduce_kernel(const u32* buckets, u32 per_window, int chunk,
+                                                                  u32 nchunks_total, int scalar_bits, u32* out) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks_total) return;
+    typedef typename Cfg::F F;
+    u32 chunks_per_window = per_window / chunk;
+    u32 w = t / chunks_per_window, j = t % chunks_per_window;
+    const u32* base = buckets + ((size_t)w * per_window + (size_t)j * chunk) * Cfg::PT_WORDS;
+    XYZZ<F> run = xyzz_inf<F>(), acc = xyzz_inf<F>();
+    for (int k = chunk - 1; k >= 0; k--) {
+        run = xyzz_add(run, Cfg::from_words(base + (size_t)k * Cfg::PT_WORDS, 1));
+        acc = xyzz_add(acc, run);
+    }
+    u32 off = j * (u32)chunk;                  // weight offset of the chunk
+    if (off) acc = xyzz_add(acc, xyzz_mul_scalar(run, &off, scalar_bits));
+    Cfg::to_words(out + (size_t)t * Cfg::PT_WORDS, acc, 1);
+}
+template <class Cfg>
+__global__ __launch_bounds__(128) void ec_sum_groups_kernel(const u32* in, u32* out, u32 n_out, int group) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_out) return;
+    typedef typename Cfg::F F;
+    XYZZ<F> acc = Cfg::from_words(in + (size_t)t * group * Cfg::PT_WORDS, 1);
+    for (int g = 1; g < group; g++) acc = xyzz_add(acc, Cfg::from_words(in + ((size_t)t * group + g) * Cfg::PT_WORDS, 1));
+    Cfg::to_words(out + (size_t)t * Cfg::PT_WORDS, acc, 1);
+}
+
+// ---- zkey point conversion ------------------------------------------------------------------------------
+__global__ void convert_coords_kernel(u32* pts, u64 n_coords_groups, int coords_per_point) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_coords_groups) return;
+    u32* p = pts + i * 8 * coords_per_point;
+    u32 o = 0;
+    for (int k = 0; k < 8 * coords_per_point; k++) o |= p[k];
+    if (o == 0) return;                                     // infinity stays (0,0)
+    for (int k = 0; k < coords_per_point; k++) {
+        u32 w[8];
+        load8(w, p + 8 * k);
+        Fq v = cond_sub_q(from_mont256<FqParams>(w));
+        pack256(w, v);
+        store8(p + 8 * k, w);
+    }
+}
+
+template <class T> void dev_alloc(T*& p, size_t bytes) { if (p) hipFree(p); p = nullptr; UG_HIP(hipMalloc(&p, bytes ? bytes : 4)); }
+template <class T> void dev_free(T*& p) { if (p) hipFree(p); p = nullptr; }
+
+}  // namespace
+
+// ---- geometry ---------------------------------------------------------------------------------------------
+MsmGeometry MsmGeometry::choose(u64 n, int force_c) {
+    MsmGeometry g;
+    g.n = n;
+    int lg = 0;
+    while (((u64)1 << lg) < n) lg++;
+    int c = force_c ? force_c : lg - 4;
+    if (c < 6) c = 6;
+    if (c > 22) c = 22;
+    g.c = c;
+    g.windows = (255 + c - 1) / c;
+    g.buckets = 1u << (c - 1);
+    return g;
+}
+
+// ---- schedule -----------------------------------------------------------------------------------------------
+void MsmSchedule::reserve(const MsmGeometry& g) {
+    u64 total = g.n * g.windows;
+    if (total > capacity_n) {
+        dev_alloc(keys_a, total * 4); dev_alloc(keys_b, total * 4);
+        dev_alloc(vals_a, total * 4); dev_alloc(vals_b, total * 4);
+        size_t need = 0;
+        hipcub::DoubleBuffer<u32> dk(keys_a, keys_b), dv(vals_a, vals_b);
+        UG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, dk, dv, (int)total, 0, 32));
+        if (need > sort_tmp_bytes) { dev_alloc(sort_tmp, need); sort_tmp_bytes = need; }
+        capacity_n = total;
+    }
+    if (g.total_buckets() > capacity_buckets) {
+        dev_alloc(bucket_start, g.total_buckets() * 4);
+        dev_alloc(bucket_count, g.total_buckets() * 4);
+        capacity_buckets = g.total_buckets();
+    }
+    if (!heavy_list) dev_alloc(heavy_list, (3 * MAX_HEAVY + 1) * 4);
+}
+
+void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_t stream) {
+    geo = g;
+    reserve(g);
+    n_tasks = 0; n_heavy = 0;
+    if (g.n == 0) return;
+    u64 total = g.n * g.windows;
+    if (total >= ((u64)1 << 31)) throw std::invalid_argument("msm: n * windows exceeds 2^31 entries");
+    u32 nb = (u32)g.total_buckets();
+    u32 sentinel = nb;
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, stream,
+                       scalars_dev, g.n, g.c, g.windows, g.buckets, sentinel, keys_a, vals_a);
+    UG_KERNEL_CHECK();
+    int end_bit = 1;
+    while (((u64)1 << end_bit) <= sentinel) end_bit++;
+    hipcub::DoubleBuffer<u32> dk(keys_a, keys_b), dv(vals_a, vals_b);
+    size_t tmp = sort_tmp_bytes;
+    UG_HIP(hipcub::DeviceRadixSort::SortPairs(sort_tmp, tmp, dk, dv, (int)total, 0, end_bit, stream));
+    const u32* sorted_keys = dk.Current();
+    vals = dv.Current();
+    UG_HIP(hipMemsetAsync(bucket_start, 0, (size_t)nb * 4, stream));
+    UG_HIP(hipMemsetAsync(bucket_count, 0, (size_t)nb * 4, stream));
+    UG_HIP(hipMemsetAsync(heavy_list, 0, 4, stream));
+    hipLaunchKernelGGL(bucket_bounds_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       sorted_keys, total, sentinel, bucket_start, bucket_count);
+    UG_KERNEL_CHECK();
+    hipLaunchKernelGGL(bucket_counts_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, bucket_start, bucket_count, nb, heavy_list);
+    UG_KERNEL_CHECK();
+    // heavy buckets -> tasks (host round trip; the list is tiny)
+    u32 nh = 0;
+    UG_HIP(hipMemcpyAsync(&nh, heavy_list, 4, hipMemcpyDeviceToHost, stream));
+    UG_HIP(hipStreamSynchronize(stream));
+    if (nh > MAX_HEAVY) throw std::runtime_error("msm: too many heavy buckets");
+    if (nh) {
+        std::vector<u32> trip((size_t)nh * 3);
+        UG_HIP(hipMemcpy(trip.data(), heavy_list + 1, trip.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<HeavyTask> tasks;
+        std::vector<HeavyBucket> hbs;
+        u32 slot = 0;
+        for (u32 i = 0; i < nh; i++) {
+            u32 id = trip[3 * i], st = trip[3 * i + 1], ct = trip[3 * i + 2], first = slot;
+            for (u32 off = 0; off < ct; off += TASK_ENTRIES) tasks.push_back({id, st + off, std::min(TASK_ENTRIES, ct - off), slot++});
+            hbs.push_back({id, first, slot - first, 0});
+        }
+        n_tasks = slot; n_heavy = nh;
+        dev_alloc(heavy_tasks_dev, (size_t)n_tasks * sizeof(HeavyTask));
+        dev_alloc(heavy_buckets_dev, (size_t)n_heavy * sizeof(HeavyBucket));
+        UG_HIP(hipMemcpy(heavy_tasks_dev, tasks.data(), (size_t)n_tasks * sizeof(HeavyTask), hipMemcpyHostToDevice));
+        UG_HIP(hipMemcpy(heavy_buckets_dev, hbs.data(), (size_t)n_heavy * sizeof(HeavyBucket), hipMemcpyHostToDevice));
+    }
+}
+
+void MsmSchedule::release() {
+    dev_free(keys_a); dev_free(keys_b); dev_free(vals_a); dev_free(vals_b); dev_free(sort_tmp);
+    dev_free(bucket_start); dev_free(bucket_count); dev_free(heavy_list);
+    dev_free(heavy_tasks_dev); dev_free(heavy_buckets_dev);
+    capacity_n = capacity_buckets = 0; sort_tmp_bytes = 0; vals = nullptr;
+}
+
+// ---- workspace ------------------------------------------------------------------------------------------------
+void MsmWorkspace::reserve(const MsmGeometry& g, bool g2, u32 n_tasks) {
+    size_t ptw = g2 ? G2Cfg::PT_WORDS : G1Cfg::PT_WORDS;
+    size_t need = (size_t)g.total_buckets() * ptw * 4;
+    if (need > bucket_bytes) { dev_alloc(bucket_pts, need); bucket_bytes = need; }
+    int chunk = g.buckets < (u32)CHUNK ? (int)g.buckets : CHUNK;
+    size_t cneed = (size_t)g.windows * (g.buckets / chunk) * ptw * 4;
+    if (cneed > chunk_bytes) { dev_alloc(chunk_pts, cneed); dev_alloc(chunk_pts2, cneed); chunk_bytes = cneed; }
+    size_t tneed = (size_t)n_tasks * ptw * 4;
+    if (tneed > task_bytes) { dev_alloc(task_pts, tneed); task_bytes = tneed; }
+}
+void MsmWorkspace::release() {
+    dev_free(bucket_pts); dev_free(chunk_pts); dev_free(chunk_pts2); dev_free(task_pts);
+    bucket_bytes = chunk_bytes = task_bytes = 0;
+}
+
+// ---- driver -------------------------------------------------------------------------------------------------------
+namespace {
+template <class Cfg>
+XYZZ<typename Cfg::F> msm_run(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta,
+                              hipStream_t stream, MsmStats* stats) {
+    typedef typename Cfg::F F;
+    const MsmGeometry& g = s.geo;
+    if (g.n == 0 || n_bases == 0) return xyzz_inf<F>();
+    ws.reserve(g, Cfg::PT_WORDS == G2Cfg::PT_WORDS, s.n_tasks);
+    u32 nb = (u32)g.total_buckets();
+    if (stats) UG_HIP(hipEventRecord(stats->ev0, stream));
+    hipLaunchKernelGGL(bucket_accumulate_kernel<Cfg>, dim3((nb + 255) / 256), dim3(256), 0, stream,
+                       bases, n_bases, delta, s.vals, s.bucket_start, s.bucket_count, nb, ws.bucket_pts);
+    UG_KERNEL_CHECK();
+    if (stats) UG_HIP(hipEventRecord(stats->ev1, stream));
+    if (s.n_tasks) {
+        hipLaunchKernelGGL(heavy_partial_kernel<Cfg>, dim3(s.n_tasks), dim3(Cfg::BLOCK), 0, stream,
+                           bases, n_bases, delta, s.vals, s.heavy_tasks_dev, ws.task_pts);
+        UG_KERNEL_CHECK();
+        hipLaunchKernelGGL(heavy_final_kernel<Cfg>, dim3(s.n_heavy), dim3(Cfg::BLOCK), 0, stream,
+                           s.heavy_buckets_dev, ws.task_pts, ws.bucket_pts);
+        UG_KERNEL_CHECK();
+    }
+    int chunk = g.buckets < (u32)CHUNK ? (int)g.buckets : CHUNK;
+    u32 cpw = g.buckets / chunk;                       // chunks per window
+    u32 nchunks = cpw * g.windows;
+    hipLaunchKernelGGL(bucket_chunk_reduce_kernel<Cfg>, dim3((nchunks + 127) / 128), dim3(128), 0, stream,
+                       ws.bucket_pts, g.buckets, chunk, nchunks, g.c, ws.chunk_pts);
+    UG_KERNEL_CHECK();
+    u32* cur = ws.chunk_pts; u32* nxt = ws.chunk_pts2;
+    while (cpw > 1) {
+        int group = cpw >= 16 ? 16 : (int)cpw;
+        u32 n_out = (cpw / group) * g.windows;
+        hipLaunchKernelGGL(ec_sum_groups_kernel<Cfg>, dim3((n_out + 127) / 128), dim3(128), 0, stream, cur, nxt, n_out, group);
+        UG_KERNEL_CHECK();
+        std::swap(cur, nxt);
+        cpw /= group;
+    }
+    std::vector<u32> host((size_t)g.windows * Cfg::PT_WORDS);
+    UG_HIP(hipMemcpyAsync(host.data(), cur, host.size() * 4, hipMemcpyDeviceToHost, stream));
+    UG_HIP(hipStreamSynchronize(stream));
+    if (stats) {
+        float ms = 0;
+        UG_HIP(hipEventElapsedTime(&ms, stats->ev0, stats->ev1));
+        stats->accumulate_ms += ms; stats->launches++; stats->entries += g.n * g.windows;
+    }
+    // Horner over the windows, top first
+    XYZZ<F> acc = xyzz_inf<F>();
+    for (int w = g.windows - 1; w >= 0; w--) {
+        for (int k = 0; k < g.c; k++) acc = xyzz_dbl(acc);
+        acc = xyzz_add(acc, Cfg::from_words(host.data() + (size_t)w * Cfg::PT_WORDS, 1));
+    }
+    return acc;
+}
+}  // namespace
+
+G1XYZZ msm_g1(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta, hipStream_t stream, MsmStats* stats) {
+    return msm_run<G1Cfg>(s, ws, bases, n_bases, delta, stream, stats);
+}
+G2XYZZ msm_g2(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta, hipStream_t stream, MsmStats* stats) {
+    return msm_run<G2Cfg>(s, ws, bases, n_bases, delta, stream, stats);
+}
+
+void convert_points_g1(u32* pts, u64 n, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(convert_coords_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pts, n, 2);
+    UG_KERNEL_CHECK();
+}
+void convert_points_g2(u32* pts, u64 n, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(convert_coords_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pts, n, 4);
+    UG_KERNEL_CHECK();
+}
+
+}  // namespace ug

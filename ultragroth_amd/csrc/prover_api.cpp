@@ -1,0 +1,724 @@
+// prover_api.cpp -- outer C-ABI (include/prover.h): Groth16 and UltraGroth provers on top of the inner
+// ug_* device ABI. Host side of the hot path only: parsing, orchestration, blinding, JSON.
+//
+// Follows, step for step, the reference's
+//   Groth16Prover / UltraGrothProver wrappers     src/prover.cpp:144-309
+//   Groth16::Prover::prove                        src/groth16.cpp:48-203      (S1..S13)
+//   UltraGroth::Prover::{execute_round, execute_final_round, prove, compute_lookup, derive_challenge}
+//                                                 src/ultra_groth.cpp:33-106,161-462
+//   Proof::toJson, BuildPublicString              src/groth16.cpp:217-250, src/ultra_groth.cpp:476-513,
+//                                                 src/prover.cpp:89-117
+//   extern "C" entry points and error mapping     src/prover.cpp:311-891
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+#include "ec.hpp"
+#include "host_util.hpp"
+#include "../../include/prover.h"
+#include "../../include/ultragroth_hip.h"
+
+using namespace ug;
+using namespace ughost;
+
+namespace {
+
+class ShortBufferException : public std::invalid_argument {
+public:
+    explicit ShortBufferException(const std::string& m) : std::invalid_argument(m) {}
+};
+class InvalidWitnessLengthException : public std::invalid_argument {
+public:
+    explicit InvalidWitnessLengthException(const std::string& m) : std::invalid_argument(m) {}
+};
+
+void copyError(char* error_msg, unsigned long long maxsize, const char* what) {
+    if (error_msg) strncpy(error_msg, what, maxsize);
+}
+void ugCheck(int rc) {
+    if (rc != UG_OK) throw std::runtime_error(ug_last_error());
+}
+
+constexpr unsigned long long PROOF_MIN_GROTH16 = 810, PROOF_MIN_ULTRA = 1400;
+unsigned long long publicMin(unsigned long long count) { return count * 82 + 4; }
+
+void checkBufferSizes(unsigned long long proofCalc, const unsigned long long* proofSize,
+                      unsigned long long publicCalc, const unsigned long long* publicSize, const std::string& type) {
+    if (*proofSize < proofCalc)
+        throw ShortBufferException("Proof buffer is too short. " + type + " size: " + std::to_string(proofCalc) +
+                                   ", actual size: " + std::to_string(*proofSize));
+    if (*publicSize < publicCalc)
+        throw ShortBufferException("Public buffer is too short. " + type + " size: " + std::to_string(publicCalc) +
+                                   ", actual size: " + std::to_string(*publicSize));
+}
+
+// ---- host curve helpers on reference-format records ---------------------------------------------------
+G1XYZZ g1FromRecord(const uint8_t* rec) {
+    u32 w[16];
+    memcpy(w, rec, 64);
+    u32 o = 0;
+    for (int i = 0; i < 16; i++) o |= w[i];
+    if (!o) return xyzz_inf<Fq>();
+    return xyzz_from_affine(from_mont256<FqParams>(w), from_mont256<FqParams>(w + 8));
+}
+G2XYZZ g2FromRecord(const uint8_t* rec) {
+    u32 w[32];
+    memcpy(w, rec, 128);
+    u32 o = 0;
+    for (int i = 0; i < 32; i++) o |= w[i];
+    if (!o) return xyzz_inf<Fq2>();
+    Fq2 x, y;
+    x.a = from_mont256<FqParams>(w); x.b = from_mont256<FqParams>(w + 8);
+    y.a = from_mont256<FqParams>(w + 16); y.b = from_mont256<FqParams>(w + 24);
+    return xyzz_from_affine(x, y);
+}
+void g1ToRecord(uint8_t* rec, const G1XYZZ& p) {
+    if (is_inf(p)) { memset(rec, 0, 64); return; }
+    Fq x, y;
+    xyzz_to_affine(x, y, p);
+    u32 w[16];
+    to_mont256(w, x); to_mont256(w + 8, y);
+    memcpy(rec, w, 64);
+}
+void g2ToRecord(uint8_t* rec, const G2XYZZ& p) {
+    if (is_inf(p)) { memset(rec, 0, 128); return; }
+    Fq2 x, y;
+    xyzz_to_affine(x, y, p);
+    u32 w[32];
+    to_mont256(w, x.a); to_mont256(w + 8, x.b); to_mont256(w + 16, y.a); to_mont256(w + 24, y.b);
+    memcpy(rec, w, 128);
+}
+// E.f1.toString of a Montgomery coordinate: plain value, decimal
+std::string coordString(const uint8_t* mont32) {
+    u32 w[8], n[8];
+    memcpy(w, mont32, 32);
+    to_normal(n, from_mont256<FqParams>(w));
+    return toDecimal(reinterpret_cast<const uint8_t*>(n));
+}
+std::string g1Json(const uint8_t* rec) {
+    return "[\"" + coordString(rec) + "\",\"" + coordString(rec + 32) + "\",\"1\"]";
+}
+std::string g2Json(const uint8_t* rec) {
+    return "[[\"" + coordString(rec) + "\",\"" + coordString(rec + 32) + "\"],[\"" + coordString(rec + 64) + "\",\"" +
+           coordString(rec + 96) + "\"],[\"1\",\"0\"]]";
+}
+
+// one blinding scalar: 31 random bytes, top byte zero (src/groth16.cpp:158-166)
+void drawBlinding(uint8_t out[32]) {
+    memset(out, 0, 32);
+    randomBytes(out, 31);
+}
+
+// S12: the seven single scalar multiplications and the sums (src/groth16.cpp:168-195). All five sums come
+// in as affine records; outputs are the affine records of pi_a, pi_b, pi_c.
+void blind(uint8_t* outA, uint8_t* outB, uint8_t* outC, const uint8_t* sumA, const uint8_t* sumB1, const uint8_t* sumB2,
+           const uint8_t* sumC, const uint8_t* sumH, const ZkeyHeader& h, const uint8_t r[32], const uint8_t s[32],
+           const G1XYZZ* extraSubtract) {
+    u32 rw[8], sw[8];
+    memcpy(rw, r, 32); memcpy(sw, s, 32);
+    G1XYZZ pi_a = g1FromRecord(sumA), pib1 = g1FromRecord(sumB1), pi_c = g1FromRecord(sumC), pih = g1FromRecord(sumH);
+    G2XYZZ pi_b = g2FromRecord(sumB2);
+    G1XYZZ alpha1 = g1FromRecord(h.alpha1), beta1 = g1FromRecord(h.beta1), delta1 = g1FromRecord(h.delta1);
+    G2XYZZ beta2 = g2FromRecord(h.beta2), delta2 = g2FromRecord(h.delta2);
+
+    pi_a = xyzz_add(pi_a, alpha1);                                        // :171
+    pi_a = xyzz_add(pi_a, xyzz_mul_scalar(delta1, rw, 256));              // :172-173
+    pi_b = xyzz_add(pi_b, beta2);                                         // :175
+    pi_b = xyzz_add(pi_b, xyzz_mul_scalar(delta2, sw, 256));              // :176-177
+    pib1 = xyzz_add(pib1, beta1);                                         // :179
+    pib1 = xyzz_add(pib1, xyzz_mul_scalar(delta1, sw, 256));              // :180-181
+    pi_c = xyzz_add(pi_c, pih);                                           // :183
+    pi_c = xyzz_add(pi_c, xyzz_mul_scalar(pi_a, sw, 256));                // :185-186
+    pi_c = xyzz_add(pi_c, xyzz_mul_scalar(pib1, rw, 256));                // :188-189
+    // :191-192  rs = toMontgomery(MMul(r, s)) = r * s mod q as a plain integer
+    u32 rsw[8];
+    to_normal(rsw, mul(from_normal<FrParams>(rw), from_normal<FrParams>(sw)));
+    pi_c = xyzz_add(pi_c, xyzz_neg(xyzz_mul_scalar(delta1, rsw, 256)));   // :194-195
+    if (extraSubtract) pi_c = xyzz_add(pi_c, xyzz_neg(*extraSubtract));   // ultra_groth.cpp:386-388
+    g1ToRecord(outA, pi_a); g2ToRecord(outB, pi_b); g1ToRecord(outC, pi_c);   // :197-200
+}
+
+// BuildPublicString (src/prover.cpp:106-117; UltraGroth variant :89-105 skips rand_indx):
+// toMontgomery + toString = the value reduced mod r, printed in decimal. An empty list dumps as "null".
+std::string publicJson(const uint8_t* w, uint32_t nPublic, uint32_t skip) {
+    std::string out = "[";
+    bool first = true;
+    for (uint32_t i = 1; i <= nPublic; i++) {
+        if (i == skip) continue;
+        u32 v[8], n[8];
+        memcpy(v, w + (size_t)i * 32, 32);
+        to_normal(n, from_normal<FrParams>(v));
+        if (!first) out += ",";
+        first = false;
+        out += "\"" + toDecimal(reinterpret_cast<const uint8_t*>(n)) + "\"";
+    }
+    if (first) return "null";
+    return out + "]";
+}
+
+int deviceFromEnv() {
+    const char* e = getenv("ULTRAGROTH_DEVICE");
+    return e ? atoi(e) : 0;
+}
+
+struct Range { uint64_t lo, hi; };
+Range shardRange(uint64_t n, int rank, int count) {
+    return Range{n * (uint64_t)rank / (uint64_t)count, n * (uint64_t)(rank + 1) / (uint64_t)count};
+}
+
+// ---- common device-side state of a prover -------------------------------------------------------------------
+struct DeviceProver {
+    ug_ctx* ctx = nullptr;
+    ug_bases *A = nullptr, *B1 = nullptr, *B2 = nullptr, *C = nullptr, *H = nullptr, *roundC = nullptr;
+    ug_hpoly* hp = nullptr;
+    ug_dvec *w = nullptr, *h = nullptr, *aux = nullptr;
+    ug_schedule *sw = nullptr, *sh = nullptr, *saux = nullptr;
+    ~DeviceProver() {
+        ug_schedule_destroy(sw); ug_schedule_destroy(sh); ug_schedule_destroy(saux);
+        ug_dvec_destroy(w); ug_dvec_destroy(h); ug_dvec_destroy(aux);
+        ug_hpoly_destroy(hp);
+        ug_bases_destroy(A); ug_bases_destroy(B1); ug_bases_destroy(B2); ug_bases_destroy(C); ug_bases_destroy(H);
+        ug_bases_destroy(roundC);
+        ug_ctx_destroy(ctx);
+    }
+};
+
+struct ProverBase {        // what the extern "C" layer stores behind the opaque handle
+    virtual ~ProverBase() {}
+    virtual void prove(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub) = 0;
+    virtual unsigned long long proofBufferMinSize() const = 0;
+    virtual unsigned long long publicBufferMinSize() const = 0;
+    virtual void timings(double* msm, double* fft, double* total) const = 0;
+    virtual ug_ctx* ctx() = 0;
+};
+
+const uint8_t* checkedSection(const BinFile& f, uint32_t id, uint64_t needBytes) {
+    if (f.sectionSize(id) < needBytes)
+        throw std::range_error("Section " + std::to_string(id) + " is shorter than the header implies");
+    return f.sectionData(id);
+}
+
+}  // namespace
+
+// =================================================================================================================
+class Groth16Prover : public ProverBase {
+public:
+    Groth16Prover(const void* zkey, unsigned long long zkeySize, int device, int rank, int count)
+        : rank_(rank), count_(count) {
+        if (count < 1 || rank < 0 || rank >= count) throw std::invalid_argument("invalid shard rank / count");
+        BinFile f(zkey, zkeySize, "zkey", 1);
+        hdr_ = loadZkeyHeader(f, false);
+        if (!hdr_.rIsBn254) throw std::invalid_argument("zkey curve not supported");
+        if (hdr_.nVars < hdr_.nPublic + 1) throw std::invalid_argument("zkey header: nVars smaller than nPublic + 1");
+        // the prover keeps its own copy of the verification-key points it needs (the reference keeps pointers)
+        vk_.assign(hdr_.alpha1, hdr_.alpha1 + 64 + 64 + 128 + 128 + 64 + 128);
+        hdr_.alpha1 = vk_.data(); hdr_.beta1 = vk_.data() + 64; hdr_.beta2 = vk_.data() + 128; hdr_.gamma2 = vk_.data() + 256;
+        hdr_.delta1 = vk_.data() + 384; hdr_.delta2 = vk_.data() + 448;
+
+        const uint64_t M = hdr_.nVars, N = hdr_.domainSize, nC = M - hdr_.nPublic - 1;
+        const uint8_t* coefs = checkedSection(f, 4, 4 + hdr_.nCoefs * 44) + 4;       // src/groth16.cpp:38
+        const uint8_t* pA = checkedSection(f, 5, M * 64);
+        const uint8_t* pB1 = checkedSection(f, 6, M * 64);
+        const uint8_t* pB2 = checkedSection(f, 7, M * 128);
+        const uint8_t* pC = checkedSection(f, 8, nC * 64);
+        const uint8_t* pH = checkedSection(f, 9, N * 64);
+
+        wr_ = shardRange(M, rank, count);        // witness scalars (and A/B1/B2 points) of this rank
+        hr_ = shardRange(N, rank, count);        // h scalars (and H points) of this rank
+        const uint64_t shift = (uint64_t)hdr_.nPublic + 1;
+        uint64_t cLo = wr_.lo > shift ? wr_.lo - shift : 0, cHi = wr_.hi > shift ? wr_.hi - shift : 0;
+        if (cHi > nC) cHi = nC;
+        if (cLo > cHi) cLo = cHi;
+
+        ugCheck(ug_ctx_create(&d_.ctx, device));
+        ugCheck(ug_bases_create_g1(d_.ctx, pA + wr_.lo * 64, wr_.hi - wr_.lo, wr_.lo, &d_.A));
+        ugCheck(ug_bases_create_g1(d_.ctx, pB1 + wr_.lo * 64, wr_.hi - wr_.lo, wr_.lo, &d_.B1));
+        ugCheck(ug_bases_create_g2(d_.ctx, pB2 + wr_.lo * 128, wr_.hi - wr_.lo, wr_.lo, &d_.B2));
+        ugCheck(ug_bases_create_g1(d_.ctx, pC + cLo * 64, cHi - cLo, cLo, &d_.C));
+        ugCheck(ug_bases_create_g1(d_.ctx, pH + hr_.lo * 64, hr_.hi - hr_.lo, hr_.lo, &d_.H));
+        ugCheck(ug_hpoly_create(d_.ctx, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
+        ugCheck(ug_dvec_create(d_.ctx, M, &d_.w));
+        ugCheck(ug_dvec_create(d_.ctx, N, &d_.h));
+        ugCheck(ug_schedule_create(d_.ctx, &d_.sw));
+        ugCheck(ug_schedule_create(d_.ctx, &d_.sh));
+    }
+
+    const ZkeyHeader& header() const { return hdr_; }
+
+    void loadWitness(const void* wtns, unsigned long long wtnsSize) {
+        BinFile f(wtns, wtnsSize, "wtns", 2);
+        WtnsHeader wh = loadWtnsHeader(f);
+        if (hdr_.nVars != wh.nVars)
+            throw InvalidWitnessLengthException("Invalid witness length. Circuit: " + std::to_string(hdr_.nVars) +
+                                                ", witness: " + std::to_string(wh.nVars));
+        if (!wh.primeIsBn254) throw std::invalid_argument("different wtns curve");
+        const uint8_t* data = checkedSection(f, 2, (uint64_t)hdr_.nVars * 32);
+        publicPart_.assign(data, data + ((size_t)hdr_.nPublic + 1) * 32);
+        ugCheck(ug_dvec_upload(d_.w, data, hdr_.nVars));
+        witnessLoaded_ = true;
+    }
+
+    // S1-S10 on this rank's slices; partials = A | B1 | B2 | C | H affine records
+    void run(uint8_t* partials) {
+        if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
+        ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1));
+        ugCheck(ug_schedule_build(d_.sw, d_.w, wr_.lo, wr_.hi - wr_.lo));
+        ugCheck(ug_msm_g1(d_.ctx, d_.A, d_.sw, 0, partials));                                  // S1  :55
+        ugCheck(ug_msm_g1(d_.ctx, d_.B1, d_.sw, 0, partials + 64));                            // S2  :58
+        ugCheck(ug_msm_g2(d_.ctx, d_.B2, d_.sw, 0, partials + 128));                           // S3  :61
+        ugCheck(ug_msm_g1(d_.ctx, d_.C, d_.sw, (int64_t)hdr_.nPublic + 1, partials + 256));    // S4  :64
+        ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                              // S5-S9 :66-148
+        ugCheck(ug_schedule_build(d_.sh, d_.h, hr_.lo, hr_.hi - hr_.lo));
+        ugCheck(ug_msm_g1(d_.ctx, d_.H, d_.sh, 0, partials + 320));                            // S10 :154
+        ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
+    }
+
+    void finish(const uint8_t* sums, std::string& proof, std::string& pub) {
+        uint8_t r[32], s[32];
+        drawBlinding(r); drawBlinding(s);                                                      // S11 :158-166
+        uint8_t A[64], B[128], C[64];
+        blind(A, B, C, sums, sums + 64, sums + 128, sums + 256, sums + 320, hdr_, r, s, nullptr);
+        // nlohmann dump(): keys in lexicographic order, no whitespace (src/groth16.cpp:217-250)
+        proof = "{\"pi_a\":" + g1Json(A) + ",\"pi_b\":" + g2Json(B) + ",\"pi_c\":" + g1Json(C) + ",\"protocol\":\"groth16\"}";
+        pub = publicJson(publicPart_.data(), hdr_.nPublic, 0);
+    }
+
+    void prove(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub) override {
+        auto t0 = std::chrono::steady_clock::now();
+        loadWitness(wtns, wtnsSize);
+        uint8_t partials[UG_GROTH16_PARTIALS_SIZE];
+        run(partials);
+        finish(partials, proof, pub);
+        totalMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+
+    unsigned long long proofBufferMinSize() const override { return PROOF_MIN_GROTH16; }
+    unsigned long long publicBufferMinSize() const override { return publicMin(hdr_.nPublic); }
+    void timings(double* msm, double* fft, double* total) const override {
+        if (msm) *msm = msmMs_;
+        if (fft) *fft = fftMs_;
+        if (total) *total = totalMs_;
+    }
+    ug_ctx* ctx() override { return d_.ctx; }
+
+private:
+    int rank_, count_;
+    ZkeyHeader hdr_;
+    std::vector<uint8_t> vk_, publicPart_;
+    Range wr_{0, 0}, hr_{0, 0};
+    DeviceProver d_;
+    bool witnessLoaded_ = false;
+    double msmMs_ = 0, fftMs_ = 0, totalMs_ = 0;
+};
+
+// =================================================================================================================
+class UltraGrothProver : public ProverBase {
+public:
+    UltraGrothProver(const void* zkey, unsigned long long zkeySize, int device) {
+        BinFile f(zkey, zkeySize, "zkey", 1);
+        hdr_ = loadZkeyHeader(f, true);
+        if (!hdr_.rIsBn254) throw std::invalid_argument("zkey curve not supported");
+        vk_.assign(hdr_.alpha1, hdr_.alpha1 + 64 + 64 + 128 + 128 + 64 + 128 + 64 + 128);
+        uint8_t* v = vk_.data();
+        hdr_.alpha1 = v; hdr_.beta1 = v + 64; hdr_.beta2 = v + 128; hdr_.gamma2 = v + 256;
+        hdr_.roundDelta1 = v + 384; hdr_.roundDelta2 = v + 448; hdr_.delta1 = v + 576; hdr_.delta2 = v + 640;
+
+        const uint64_t M = hdr_.nVars, N = hdr_.domainSize;
+        const uint8_t* coefs = checkedSection(f, 4, 4 + hdr_.nCoefs * 44) + 4;
+        // section map of protocol 1337 (src/prover.cpp:242-259)
+        const uint8_t* pA = checkedSection(f, 5, M * 64);
+        const uint8_t* pB1 = checkedSection(f, 6, M * 64);
+        const uint8_t* pB2 = checkedSection(f, 7, M * 128);
+        const uint8_t* pRoundC = checkedSection(f, 8, (uint64_t)hdr_.numIndexesC1 * 64);
+        const uint8_t* pFinalC = checkedSection(f, 9, (uint64_t)hdr_.numIndexesC2 * 64);
+        const uint8_t* idx1 = checkedSection(f, 10, (uint64_t)hdr_.numIndexesC1 * 4);
+        const uint8_t* idx2 = checkedSection(f, 11, (uint64_t)hdr_.numIndexesC2 * 4);
+        const uint8_t* pH = checkedSection(f, 12, N * 64);
+        roundIdx_.resize(hdr_.numIndexesC1); finalIdx_.resize(hdr_.numIndexesC2);
+        memcpy(roundIdx_.data(), idx1, roundIdx_.size() * 4);
+        memcpy(finalIdx_.data(), idx2, finalIdx_.size() * 4);
+        for (uint32_t i : roundIdx_) if (i >= M) throw std::range_error("round index outside the witness");
+        for (uint32_t i : finalIdx_) if (i >= M) throw std::range_error("final round index outside the witness");
+
+        ugCheck(ug_ctx_create(&d_.ctx, device));
+        ugCheck(ug_bases_create_g1(d_.ctx, pA, M, 0, &d_.A));
+        ugCheck(ug_bases_create_g1(d_.ctx, pB1, M, 0, &d_.B1));
+        ugCheck(ug_bases_create_g2(d_.ctx, pB2, M, 0, &d_.B2));
+        ugCheck(ug_bases_create_g1(d_.ctx, pFinalC, hdr_.numIndexesC2, 0, &d_.C));
+        ugCheck(ug_bases_create_g1(d_.ctx, pRoundC, hdr_.numIndexesC1, 0, &d_.roundC));
+        ugCheck(ug_bases_create_g1(d_.ctx, pH, N, 0, &d_.H));
+        ugCheck(ug_hpoly_create(d_.ctx, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
+        ugCheck(ug_dvec_create(d_.ctx, M, &d_.w));
+        ugCheck(ug_dvec_create(d_.ctx, N, &d_.h));
+        uint64_t auxN = hdr_.numIndexesC1 > hdr_.numIndexesC2 ? hdr_.numIndexesC1 : hdr_.numIndexesC2;
+        ugCheck(ug_dvec_create(d_.ctx, auxN ? auxN : 1, &d_.aux));
+        ugCheck(ug_schedule_create(d_.ctx, &d_.sw));
+        ugCheck(ug_schedule_create(d_.ctx, &d_.sh));
+        ugCheck(ug_schedule_create(d_.ctx, &d_.saux));
+    }
+
+    const ZkeyHeader& header() const { return hdr_; }
+
+    void prove(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub) override {
+        auto t0 = std::chrono::steady_clock::now();
+        BinFile f(wtns, wtnsSize, "wtns", 2);
+        WtnsHeader wh = loadWtnsHeader(f);
+        if (hdr_.nVars != wh.nVars)
+            throw InvalidWitnessLengthException("Invalid witness length. Circuit: " + std::to_string(hdr_.nVars) +
+                                                ", witness: " + std::to_string(wh.nVars));
+        if (!wh.primeIsBn254) throw std::invalid_argument("different wtns curve");
+        const uint64_t M = hdr_.nVars;
+        std::vector<uint8_t> signals(checkedSection(f, 2, M * 32), checkedSection(f, 2, M * 32) + M * 32);   // prover.cpp:283-285
+        auto u32Section = [&](uint32_t id) {
+            std::vector<uint32_t> v(f.sectionSize(id) >> 2);
+            memcpy(v.data(), f.sectionData(id), v.size() * 4);
+            return v;
+        };
+        std::vector<uint32_t> chunks = u32Section(3), freq = u32Section(4), wIdx = u32Section(5), pIdx = u32Section(6);
+        if (wIdx.size() != pIdx.size()) throw std::range_error("uwtns: wtns_indxs and push_indxs differ in length");
+
+        ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1));
+        // ---- round 1: commitment to the round witnesses (ultra_groth.cpp:415-419, execute_round :161-184)
+        ugCheck(ug_dvec_upload(d_.w, signals.data(), M));
+        ugCheck(ug_dvec_gather(d_.aux, d_.w, roundIdx_.data(), roundIdx_.size()));
+        ugCheck(ug_schedule_build(d_.saux, d_.aux, 0, roundIdx_.size()));
+        uint8_t commitRec[64];
+        ugCheck(ug_msm_g1(d_.ctx, d_.roundC, d_.saux, 0, commitRec));
+        uint8_t rk[32];
+        drawBlinding(rk);                                                                   // :173
+        u32 rkw[8];
+        memcpy(rkw, rk, 32);
+        G1XYZZ commit = xyzz_add(g1FromRecord(commitRec), xyzz_mul_scalar(g1FromRecord(hdr_.delta1), rkw, 256));   // :176 final_delta1
+        g1ToRecord(commitRec, commit);
+
+        // ---- Fiat-Shamir challenge (derive_challenge :33-58): keccak256(x_BE32 || y_BE32) as a big-endian integer
+        u32 cx[8], cy[8], w8[8];
+        memcpy(w8, commitRec, 32); to_normal(cx, from_mont256<FqParams>(w8));
+        memcpy(w8, commitRec + 32, 32); to_normal(cy, from_mont256<FqParams>(w8));
+        uint8_t buf[64], ch[32];
+        for (int i = 0; i < 32; i++) {
+            buf[i] = (uint8_t)(cx[7 - (i >> 2)] >> (24 - 8 * (i & 3)));
+            buf[32 + i] = (uint8_t)(cy[7 - (i >> 2)] >> (24 - 8 * (i & 3)));
+        }
+        keccak256(ch, buf, 64);
+        u32 chw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 32; i++) chw[7 - (i >> 2)] |= (u32)ch[i] << (24 - 8 * (i & 3));
+        Fr rand = from_normal<FrParams>(chw);              // reduces values >= r, like fromMpz + toMontgomery
+
+        // ---- lookup signals (compute_lookup :62-106): batched inversion instead of one GMP call each
+        computeLookup(signals, chunks, freq, wIdx, pIdx, rand);
+
+        // ---- final round (execute_final_round :187-399)
+        ugCheck(ug_dvec_upload(d_.w, signals.data(), M));
+        ugCheck(ug_schedule_build(d_.sw, d_.w, 0, M));
+        uint8_t sums[UG_GROTH16_PARTIALS_SIZE];
+        ugCheck(ug_msm_g1(d_.ctx, d_.A, d_.sw, 0, sums));                                   // MSM1 :201
+        ugCheck(ug_msm_g1(d_.ctx, d_.B1, d_.sw, 0, sums + 64));                             // MSM2 :214
+        ugCheck(ug_msm_g2(d_.ctx, d_.B2, d_.sw, 0, sums + 128));                            // MSM3 :227
+        ugCheck(ug_dvec_gather(d_.aux, d_.w, finalIdx_.data(), finalIdx_.size()));          // :439-445
+        ugCheck(ug_schedule_build(d_.saux, d_.aux, 0, finalIdx_.size()));
+        ugCheck(ug_msm_g1(d_.ctx, d_.C, d_.saux, 0, sums + 256));                           // MSM4 :234
+        ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                           // FFT block :243-320
+        ugCheck(ug_schedule_build(d_.sh, d_.h, 0, hdr_.domainSize));
+        ugCheck(ug_msm_g1(d_.ctx, d_.H, d_.sh, 0, sums + 320));                             // MSM5 :322
+        ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
+
+        uint8_t r[32], s[32];
+        drawBlinding(r); drawBlinding(s);                                                   // :345-346
+        G1XYZZ roundTerm = xyzz_mul_scalar(g1FromRecord(hdr_.roundDelta1), rkw, 256);       // :386-388
+        uint8_t A[64], B[128], C[64];
+        blind(A, B, C, sums, sums + 64, sums + 128, sums + 256, sums + 320, hdr_, r, s, &roundTerm);
+        // keys pi_a, pi_b, pi_f, pi_r, protocol (src/ultra_groth.cpp:476-513)
+        proof = "{\"pi_a\":" + g1Json(A) + ",\"pi_b\":" + g2Json(B) + ",\"pi_f\":" + g1Json(C) + ",\"pi_r\":" + g1Json(commitRec) +
+                ",\"protocol\":\"ultragroth\"}";
+        pub = publicJson(signals.data(), hdr_.nPublic, hdr_.randIndx);                      // prover.cpp:89-105
+        totalMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+
+    unsigned long long proofBufferMinSize() const override { return PROOF_MIN_ULTRA; }
+    unsigned long long publicBufferMinSize() const override { return publicMin((unsigned long long)hdr_.nPublic - 1); }
+    void timings(double* msm, double* fft, double* total) const override {
+        if (msm) *msm = msmMs_;
+        if (fft) *fft = fftMs_;
+        if (total) *total = totalMs_;
+    }
+    ug_ctx* ctx() override { return d_.ctx; }
+
+private:
+    static void putPlain(uint8_t* dst, const Fr& v) { u32 w[8]; to_normal(w, v); memcpy(dst, w, 32); }
+    void computeLookup(std::vector<uint8_t>& signals, const std::vector<uint32_t>& chunks, const std::vector<uint32_t>& freq,
+                       const std::vector<uint32_t>& wIdx, const std::vector<uint32_t>& pIdx, const Fr& rand) {
+        const size_t L = freq.size(), Cn = chunks.size();
+        // push_vector = [rand | inv1 (chunks) | inv2 (lookup) | prod (lookup)], plain integers
+        std::vector<uint8_t> push((2 * L + Cn + 1) * 32);
+        putPlain(push.data(), rand);
+        uint8_t* inv1 = push.data() + 32;
+        uint8_t* inv2 = inv1 + Cn * 32;
+        uint8_t* prod = inv2 + L * 32;
+        // sums i + rand, then Montgomery's trick: prefix products, one inversion, unwind
+        std::vector<Fr> sum(L), pre(L);
+        Fr acc = fp_one<FrParams>();
+        for (size_t i = 0; i < L; i++) {
+            u32 iw[8] = {(u32)i, 0, 0, 0, 0, 0, 0, 0};
+            sum[i] = mul(add(from_normal<FrParams>(iw), rand), fp_one<FrParams>());   // < 2q
+            pre[i] = acc;
+            if (!is_zero(sum[i])) acc = mul(acc, sum[i]);
+        }
+        Fr inv_acc = inv(acc);
+        for (size_t i = L; i-- > 0;) {
+            Fr inv_i;
+            if (is_zero(sum[i])) inv_i = fp_zero<FrParams>();
+            else { inv_i = mul(inv_acc, pre[i]); inv_acc = mul(inv_acc, sum[i]); }
+            putPlain(inv2 + i * 32, inv_i);
+            u32 fw[8] = {freq[i], 0, 0, 0, 0, 0, 0, 0};
+            putPlain(prod + i * 32, mul(from_normal<FrParams>(fw), inv_i));
+        }
+        for (size_t j = 0; j < Cn; j++) {
+            if (chunks[j] >= L) throw std::range_error("uwtns: chunk index outside the lookup table");
+            memcpy(inv1 + j * 32, inv2 + (size_t)chunks[j] * 32, 32);
+        }
+        const size_t total = 2 * L + Cn + 1;
+        for (size_t i = 0; i < wIdx.size(); i++) {
+            if (wIdx[i] >= hdr_.nVars || pIdx[i] >= total) throw std::range_error("uwtns: lookup index out of range");
+            memcpy(signals.data() + (size_t)wIdx[i] * 32, push.data() + (size_t)pIdx[i] * 32, 32);
+        }
+    }
+
+    ZkeyHeader hdr_;
+    std::vector<uint8_t> vk_;
+    std::vector<uint32_t> roundIdx_, finalIdx_;
+    DeviceProver d_;
+    double msmMs_ = 0, fftMs_ = 0, totalMs_ = 0;
+};
+
+// =================================================================================================================
+// extern "C" surface. Error mapping as in src/prover.cpp:556-576.
+#define API_TRY try {
+#define API_CATCH                                                                                              \
+    } catch (InvalidWitnessLengthException& e) { copyError(error_msg, error_msg_maxsize, e.what()); return PROVER_INVALID_WITNESS_LENGTH; } \
+    catch (ShortBufferException& e) { copyError(error_msg, error_msg_maxsize, e.what()); return PROVER_ERROR_SHORT_BUFFER; }              \
+    catch (std::exception& e) { copyError(error_msg, error_msg_maxsize, e.what()); return PROVER_ERROR; }                                 \
+    catch (...) { copyError(error_msg, error_msg_maxsize, "unknown error"); return PROVER_ERROR; }                                        \
+    return PROVER_OK;
+
+namespace {
+int proveImpl(void* prover_object, const void* wtns_buffer, unsigned long long wtns_size, char* proof_buffer,
+              unsigned long long* proof_size, char* public_buffer, unsigned long long* public_size, char* error_msg,
+              unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL) throw std::invalid_argument("Null prover object");
+    if (wtns_buffer == NULL) throw std::invalid_argument("Null witness buffer");
+    if (proof_buffer == NULL) throw std::invalid_argument("Null proof buffer");
+    if (proof_size == NULL) throw std::invalid_argument("Null proof size");
+    if (public_buffer == NULL) throw std::invalid_argument("Null public buffer");
+    if (public_size == NULL) throw std::invalid_argument("Null public size");
+    ProverBase* prover = static_cast<ProverBase*>(prover_object);
+    checkBufferSizes(prover->proofBufferMinSize(), proof_size, prover->publicBufferMinSize(), public_size, "Minimum");
+    std::string stringProof, stringPublic;
+    prover->prove(wtns_buffer, wtns_size, stringProof, stringPublic);
+    checkBufferSizes(stringProof.length(), proof_size, stringPublic.length(), public_size, "Required");
+    std::strncpy(proof_buffer, stringProof.c_str(), *proof_size);
+    std::strncpy(public_buffer, stringPublic.c_str(), *public_size);
+    API_CATCH
+}
+int publicSizeImpl(const void* zkey, unsigned long long size, bool ultra, unsigned long long* public_size, char* error_msg,
+                   unsigned long long error_msg_maxsize) {
+    API_TRY
+    BinFile f(zkey, size, "zkey", 1);
+    ZkeyHeader h = loadZkeyHeader(f, ultra);
+    *public_size = publicMin(h.nPublic);
+    API_CATCH
+}
+}  // namespace
+
+extern "C" {
+
+int groth16_public_size_for_zkey_buf(const void* zkey_buffer, unsigned long long zkey_size, unsigned long long* public_size,
+                                     char* error_msg, unsigned long long error_msg_maxsize) {
+    return publicSizeImpl(zkey_buffer, zkey_size, false, public_size, error_msg, error_msg_maxsize);
+}
+int ultra_groth_public_size_for_zkey_buf(const void* zkey_buffer, unsigned long long zkey_size, unsigned long long* public_size,
+                                         char* error_msg, unsigned long long error_msg_maxsize) {
+    return publicSizeImpl(zkey_buffer, zkey_size, true, public_size, error_msg, error_msg_maxsize);
+}
+int groth16_public_size_for_zkey_file(const char* zkey_fname, unsigned long long* public_size, char* error_msg,
+                                      unsigned long long error_msg_maxsize) {
+    API_TRY
+    FileMap m(zkey_fname);
+    BinFile f(m.data(), m.size(), "zkey", 1);
+    *public_size = publicMin(loadZkeyHeader(f, false).nPublic);
+    API_CATCH
+}
+int ultra_groth_public_size_for_zkey_file(const char* zkey_fname, unsigned long long* public_size, char* error_msg,
+                                          unsigned long long error_msg_maxsize) {
+    API_TRY
+    FileMap m(zkey_fname);
+    BinFile f(m.data(), m.size(), "zkey", 1);
+    *public_size = publicMin(loadZkeyHeader(f, true).nPublic);
+    API_CATCH
+}
+
+void groth16_proof_size(unsigned long long* proof_size) { *proof_size = PROOF_MIN_GROTH16; }
+void ultra_groth_proof_size(unsigned long long* proof_size) { *proof_size = PROOF_MIN_ULTRA; }
+
+int groth16_prover_create(void** prover_object, const void* zkey_buffer, unsigned long long zkey_size, char* error_msg,
+                          unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL) throw std::invalid_argument("Null prover object");
+    if (zkey_buffer == NULL) throw std::invalid_argument("Null zkey buffer");
+    *prover_object = static_cast<ProverBase*>(new Groth16Prover(zkey_buffer, zkey_size, deviceFromEnv(), 0, 1));
+    API_CATCH
+}
+int ultra_groth_prover_create(void** prover_object, const void* zkey_buffer, unsigned long long zkey_size, char* error_msg,
+                              unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL) throw std::invalid_argument("Null prover object");
+    if (zkey_buffer == NULL) throw std::invalid_argument("Null zkey buffer");
+    *prover_object = static_cast<ProverBase*>(new UltraGrothProver(zkey_buffer, zkey_size, deviceFromEnv()));
+    API_CATCH
+}
+int groth16_prover_create_zkey_file(void** prover_object, const char* zkey_file_path, char* error_msg,
+                                    unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL) throw std::invalid_argument("Null prover object");
+    FileMap m(zkey_file_path);
+    *prover_object = static_cast<ProverBase*>(new Groth16Prover(m.data(), m.size(), deviceFromEnv(), 0, 1));
+    API_CATCH
+}
+int ultra_groth_prover_create_zkey_file(void** prover_object, const char* zkey_file_path, char* error_msg,
+                                        unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL) throw std::invalid_argument("Null prover object");
+    FileMap m(zkey_file_path);
+    *prover_object = static_cast<ProverBase*>(new UltraGrothProver(m.data(), m.size(), deviceFromEnv()));
+    API_CATCH
+}
+
+int groth16_prover_prove(void* prover_object, const void* wtns_buffer, unsigned long long wtns_size, char* proof_buffer,
+                         unsigned long long* proof_size, char* public_buffer, unsigned long long* public_size, char* error_msg,
+                         unsigned long long error_msg_maxsize) {
+    return proveImpl(prover_object, wtns_buffer, wtns_size, proof_buffer, proof_size, public_buffer, public_size,
+                                    error_msg, error_msg_maxsize);
+}
+int ultra_groth_prover_prove(void* prover_object, const void* wtns_buffer, unsigned long long wtns_size, char* proof_buffer,
+                             unsigned long long* proof_size, char* public_buffer, unsigned long long* public_size, char* error_msg,
+                             unsigned long long error_msg_maxsize) {
+    return proveImpl(prover_object, wtns_buffer, wtns_size, proof_buffer, proof_size, public_buffer,
+                                       public_size, error_msg, error_msg_maxsize);
+}
+
+void groth16_prover_destroy(void* prover_object) { delete static_cast<ProverBase*>(prover_object); }
+void ultra_groth_prover_destroy(void* prover_object) { delete static_cast<ProverBase*>(prover_object); }
+
+int groth16_prover(const void* zkey_buffer, unsigned long long zkey_size, const void* wtns_buffer, unsigned long long wtns_size,
+                   char* proof_buffer, unsigned long long* proof_size, char* public_buffer, unsigned long long* public_size,
+                   char* error_msg, unsigned long long error_msg_maxsize) {
+    void* prover = NULL;
+    int error = groth16_prover_create(&prover, zkey_buffer, zkey_size, error_msg, error_msg_maxsize);
+    if (error != PROVER_OK) return error;
+    error = groth16_prover_prove(prover, wtns_buffer, wtns_size, proof_buffer, proof_size, public_buffer, public_size, error_msg,
+                                 error_msg_maxsize);
+    groth16_prover_destroy(prover);
+    return error;
+}
+int ultra_groth_prover(const void* zkey_buffer, unsigned long long zkey_size, const void* wtns_buffer, unsigned long long wtns_size,
+                       char* proof_buffer, unsigned long long* proof_size, char* public_buffer, unsigned long long* public_size,
+                       char* error_msg, unsigned long long error_msg_maxsize) {
+    void* prover = NULL;
+    int error = ultra_groth_prover_create(&prover, zkey_buffer, zkey_size, error_msg, error_msg_maxsize);
+    if (error != PROVER_OK) return error;
+    error = ultra_groth_prover_prove(prover, wtns_buffer, wtns_size, proof_buffer, proof_size, public_buffer, public_size,
+                                     error_msg, error_msg_maxsize);
+    ultra_groth_prover_destroy(prover);
+    return error;
+}
+
+int groth16_prover_zkey_file(const char* zkey_file_path, const void* wtns_buffer, unsigned long long wtns_size, char* proof_buffer,
+                             unsigned long long* proof_size, char* public_buffer, unsigned long long* public_size, char* error_msg,
+                             unsigned long long error_msg_maxsize) {
+    std::unique_ptr<FileMap> m;
+    try { m.reset(new FileMap(zkey_file_path)); }
+    catch (std::exception& e) { copyError(error_msg, error_msg_maxsize, e.what()); return PROVER_ERROR; }
+    return groth16_prover(m->data(), m->size(), wtns_buffer, wtns_size, proof_buffer, proof_size, public_buffer, public_size,
+                          error_msg, error_msg_maxsize);
+}
+int ultra_groth_prover_zkey_file(const char* zkey_file_path, const void* wtns_buffer, unsigned long long wtns_size,
+                                 char* proof_buffer, unsigned long long* proof_size, char* public_buffer,
+                                 unsigned long long* public_size, char* error_msg, unsigned long long error_msg_maxsize) {
+    std::unique_ptr<FileMap> m;
+    try { m.reset(new FileMap(zkey_file_path)); }
+    catch (std::exception& e) { copyError(error_msg, error_msg_maxsize, e.what()); return PROVER_ERROR; }
+    return ultra_groth_prover(m->data(), m->size(), wtns_buffer, wtns_size, proof_buffer, proof_size, public_buffer, public_size,
+                              error_msg, error_msg_maxsize);
+}
+
+// ---- additions ----------------------------------------------------------------------------------------------
+void ug_test_set_blinding(const void* bytes, unsigned long long n) { setRandomOverride(bytes, (size_t)n); }
+
+int ug_prover_last_timings(void* prover_object, double* msm_ms, double* fft_ms, double* total_ms) {
+    if (!prover_object) return PROVER_ERROR;
+    static_cast<ProverBase*>(prover_object)->timings(msm_ms, fft_ms, total_ms);
+    return PROVER_OK;
+}
+int ug_prover_kernel_stats(void* prover_object, double* accumulate_ms_avg, unsigned long long* launches,
+                           unsigned long long* entries, int reset) {
+    if (!prover_object) return PROVER_ERROR;
+    uint64_t l = 0, e = 0;
+    int rc = ug_ctx_kernel_stats(static_cast<ProverBase*>(prover_object)->ctx(), accumulate_ms_avg, &l, &e, reset);
+    if (launches) *launches = l;
+    if (entries) *entries = e;
+    return rc == UG_OK ? PROVER_OK : PROVER_ERROR;
+}
+
+int ug_groth16_prover_create_sharded(void** prover_object, const void* zkey_buffer, unsigned long long zkey_size, int device,
+                                     int shard_rank, int shard_count, char* error_msg, unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL) throw std::invalid_argument("Null prover object");
+    if (zkey_buffer == NULL) throw std::invalid_argument("Null zkey buffer");
+    *prover_object = static_cast<ProverBase*>(new Groth16Prover(zkey_buffer, zkey_size, device, shard_rank, shard_count));
+    API_CATCH
+}
+int ug_groth16_prover_load_witness(void* prover_object, const void* wtns_buffer, unsigned long long wtns_size, char* error_msg,
+                                   unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL) throw std::invalid_argument("Null prover object");
+    if (wtns_buffer == NULL) throw std::invalid_argument("Null witness buffer");
+    static_cast<Groth16Prover*>(static_cast<ProverBase*>(prover_object))->loadWitness(wtns_buffer, wtns_size);
+    API_CATCH
+}
+int ug_groth16_prover_run(void* prover_object, void* partials_out, char* error_msg, unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL) throw std::invalid_argument("Null prover object");
+    if (partials_out == NULL) throw std::invalid_argument("Null partials buffer");
+    static_cast<Groth16Prover*>(static_cast<ProverBase*>(prover_object))->run(static_cast<uint8_t*>(partials_out));
+    API_CATCH
+}
+int ug_groth16_partials_add(void* partials_acc, const void* partials_other) {
+    try {
+        uint8_t* a = static_cast<uint8_t*>(partials_acc);
+        const uint8_t* b = static_cast<const uint8_t*>(partials_other);
+        const int g1off[4] = {0, 64, 256, 320};
+        for (int k = 0; k < 4; k++) g1ToRecord(a + g1off[k], xyzz_add(g1FromRecord(a + g1off[k]), g1FromRecord(b + g1off[k])));
+        g2ToRecord(a + 128, xyzz_add(g2FromRecord(a + 128), g2FromRecord(b + 128)));
+    } catch (...) { return PROVER_ERROR; }
+    return PROVER_OK;
+}
+int ug_groth16_prover_finish(void* prover_object, const void* partials_sum, char* proof_buffer, unsigned long long* proof_size,
+                             char* public_buffer, unsigned long long* public_size, char* error_msg,
+                             unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL) throw std::invalid_argument("Null prover object");
+    if (!partials_sum || !proof_buffer || !proof_size || !public_buffer || !public_size) throw std::invalid_argument("Null buffer");
+    Groth16Prover* prover = static_cast<Groth16Prover*>(static_cast<ProverBase*>(prover_object));
+    checkBufferSizes(prover->proofBufferMinSize(), proof_size, prover->publicBufferMinSize(), public_size, "Minimum");
+    std::string stringProof, stringPublic;
+    prover->finish(static_cast<const uint8_t*>(partials_sum), stringProof, stringPublic);
+    checkBufferSizes(stringProof.length(), proof_size, stringPublic.length(), public_size, "Required");
+    std::strncpy(proof_buffer, stringProof.c_str(), *proof_size);
+    std::strncpy(public_buffer, stringPublic.c_str(), *public_size);
+    API_CATCH
+}
+
+}  // extern "C"

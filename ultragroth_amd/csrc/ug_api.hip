@@ -1,0 +1,377 @@
+// ug_api.hip -- implementation of the inner C-ABI declared in include/ultragroth_hip.h.
+// Owns device memory, the stream and the reusable workspaces; translates between the reference's byte
+// formats and the device forms; catches every exception at the boundary.
+#include <cstring>
+#include <string>
+#include <vector>
+#include <exception>
+#include "dev_common.hpp"
+#include "internal.hpp"
+#include "../../include/ultragroth_hip.h"
+
+using namespace ug;
+
+namespace {
+thread_local std::string g_last_error;
+int fail(const std::string& msg) { g_last_error = msg; return UG_ERROR; }
+#define UG_TRY try {
+#define UG_CATCH                                                       \
+    } catch (const std::exception& e) { return fail(e.what()); }       \
+    catch (...) { return fail("unknown error"); }                      \
+    return UG_OK;
+}  // namespace
+
+struct ug_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    MsmWorkspace ws_g1, ws_g2;
+    MsmStats stats;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    double msm_ms = 0, fft_ms = 0;
+    NttPlan raw_ntt;                       // cache for ug_fr_ntt
+    void use() const { UG_HIP(hipSetDevice(device)); }
+};
+struct ug_bases {
+    ug_ctx* ctx; bool g2; u64 n; u64 global_first; u32* pts;
+};
+struct ug_dvec {
+    ug_ctx* ctx; u64 n; u32* data;
+};
+struct ug_schedule {
+    ug_ctx* ctx; MsmSchedule sched; u64 first = 0;
+};
+struct ug_hpoly {
+    ug_ctx* ctx; CoefMatrix mat; NttPlan ntt; u32 domain = 0, nvars = 0;
+    u32 *a = nullptr, *b = nullptr, *c = nullptr, *t = nullptr;     // domain elements each
+};
+
+namespace {
+struct ScopedTimer {       // accumulates stream time between construction and stop()
+    ug_ctx* c; double* acc;
+    ScopedTimer(ug_ctx* c_, double* acc_) : c(c_), acc(acc_) { UG_HIP(hipEventRecord(c->t0, c->stream)); }
+    void stop() {
+        UG_HIP(hipEventRecord(c->t1, c->stream));
+        UG_HIP(hipEventSynchronize(c->t1));
+        float ms = 0;
+        UG_HIP(hipEventElapsedTime(&ms, c->t0, c->t1));
+        *acc += ms;
+    }
+};
+template <class F> void store_mont256(uint8_t* out, const F& v);
+template <> void store_mont256<Fq>(uint8_t* out, const Fq& v) { u32 w[8]; to_mont256(w, v); memcpy(out, w, 32); }
+}  // namespace
+
+extern "C" {
+
+const char* ug_last_error(void) { return g_last_error.c_str(); }
+
+int ug_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+int ug_ctx_create(ug_ctx** out, int device) {
+    UG_TRY
+    if (!out) throw std::invalid_argument("null ctx pointer");
+    int n = 0;
+    UG_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) throw std::invalid_argument("no such HIP device: " + std::to_string(device));
+    ug_ctx* c = new ug_ctx();
+    c->device = device;
+    c->use();
+    UG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    UG_HIP(hipEventCreate(&c->t0)); UG_HIP(hipEventCreate(&c->t1));
+    UG_HIP(hipEventCreate(&c->stats.ev0)); UG_HIP(hipEventCreate(&c->stats.ev1));
+    *out = c;
+    UG_CATCH
+}
+void ug_ctx_destroy(ug_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    c->ws_g1.release(); c->ws_g2.release(); c->raw_ntt.release();
+    hipEventDestroy(c->t0); hipEventDestroy(c->t1); hipEventDestroy(c->stats.ev0); hipEventDestroy(c->stats.ev1);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+int ug_ctx_sync(ug_ctx* c) {
+    UG_TRY
+    c->use();
+    UG_HIP(hipStreamSynchronize(c->stream));
+    UG_CATCH
+}
+
+static int bases_create(ug_ctx* c, const void* host, u64 n, u64 global_first, bool g2, ug_bases** out) {
+    UG_TRY
+    if (!c || !out || (!host && n)) throw std::invalid_argument("null argument");
+    c->use();
+    ug_bases* b = new ug_bases{c, g2, n, global_first, nullptr};
+    size_t bytes = (size_t)n * (g2 ? 128 : 64);
+    UG_HIP(hipMalloc(&b->pts, bytes ? bytes : 4));
+    if (n) {
+        UG_HIP(hipMemcpyAsync(b->pts, host, bytes, hipMemcpyHostToDevice, c->stream));
+        if (g2) convert_points_g2(b->pts, n, c->stream); else convert_points_g1(b->pts, n, c->stream);
+        UG_HIP(hipStreamSynchronize(c->stream));
+    }
+    *out = b;
+    UG_CATCH
+}
+int ug_bases_create_g1(ug_ctx* c, const void* host, uint64_t n, uint64_t gf, ug_bases** out) { return bases_create(c, host, n, gf, false, out); }
+int ug_bases_create_g2(ug_ctx* c, const void* host, uint64_t n, uint64_t gf, ug_bases** out) { return bases_create(c, host, n, gf, true, out); }
+void ug_bases_destroy(ug_bases* b) {
+    if (!b) return;
+    hipSetDevice(b->ctx->device);
+    hipFree(b->pts);
+    delete b;
+}
+
+int ug_dvec_create(ug_ctx* c, uint64_t n, ug_dvec** out) {
+    UG_TRY
+    if (!c || !out) throw std::invalid_argument("null argument");
+    c->use();
+    ug_dvec* v = new ug_dvec{c, n, nullptr};
+    UG_HIP(hipMalloc(&v->data, n ? (size_t)n * 32 : 32));
+    *out = v;
+    UG_CATCH
+}
+int ug_dvec_upload(ug_dvec* v, const void* host, uint64_t n) {
+    UG_TRY
+    if (!v || (!host && n)) throw std::invalid_argument("null argument");
+    if (n > v->n) throw std::invalid_argument("upload larger than the vector");
+    v->ctx->use();
+    if (n) UG_HIP(hipMemcpyAsync(v->data, host, (size_t)n * 32, hipMemcpyHostToDevice, v->ctx->stream));
+    UG_HIP(hipStreamSynchronize(v->ctx->stream));
+    UG_CATCH
+}
+int ug_dvec_download(const ug_dvec* v, void* host, uint64_t first, uint64_t n) {
+    UG_TRY
+    if (!v || (!host && n)) throw std::invalid_argument("null argument");
+    if (first + n > v->n) throw std::invalid_argument("download outside the vector");
+    v->ctx->use();
+    if (n) UG_HIP(hipMemcpyAsync(host, v->data + first * 8, (size_t)n * 32, hipMemcpyDeviceToHost, v->ctx->stream));
+    UG_HIP(hipStreamSynchronize(v->ctx->stream));
+    UG_CATCH
+}
+int ug_dvec_gather(ug_dvec* out, const ug_dvec* src, const uint32_t* host_index, uint64_t n) {
+    UG_TRY
+    if (!out || !src || (!host_index && n)) throw std::invalid_argument("null argument");
+    if (n > out->n) throw std::invalid_argument("gather larger than the output vector");
+    ug_ctx* c = out->ctx;
+    c->use();
+    u32* idx = nullptr;
+    UG_HIP(hipMalloc(&idx, n ? (size_t)n * 4 : 4));
+    if (n) UG_HIP(hipMemcpyAsync(idx, host_index, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    gather_elements(out->data, src->data, idx, n, src->n, c->stream);
+    UG_HIP(hipStreamSynchronize(c->stream));
+    hipFree(idx);
+    UG_CATCH
+}
+uint64_t ug_dvec_size(const ug_dvec* v) { return v ? v->n : 0; }
+void ug_dvec_destroy(ug_dvec* v) {
+    if (!v) return;
+    hipSetDevice(v->ctx->device);
+    hipFree(v->data);
+    delete v;
+}
+
+int ug_schedule_create(ug_ctx* c, ug_schedule** out) {
+    UG_TRY
+    if (!c || !out) throw std::invalid_argument("null argument");
+    ug_schedule* s = new ug_schedule();
+    s->ctx = c;
+    *out = s;
+    UG_CATCH
+}
+int ug_schedule_build(ug_schedule* s, const ug_dvec* scalars, uint64_t first, uint64_t count) {
+    UG_TRY
+    if (!s || !scalars) throw std::invalid_argument("null argument");
+    if (first + count > scalars->n) throw std::invalid_argument("schedule range outside the scalar vector");
+    ug_ctx* c = s->ctx;
+    c->use();
+    ScopedTimer tm(c, &c->msm_ms);
+    s->first = first;
+    s->sched.build(scalars->data + first * 8, MsmGeometry::choose(count), c->stream);
+    tm.stop();
+    UG_CATCH
+}
+void ug_schedule_destroy(ug_schedule* s) {
+    if (!s) return;
+    hipSetDevice(s->ctx->device);
+    s->sched.release();
+    delete s;
+}
+
+static void affine_out_g1(uint8_t* out, const G1XYZZ& p) {
+    if (is_inf(p)) { memset(out, 0, 64); return; }
+    Fq x, y;
+    xyzz_to_affine(x, y, p);
+    u32 w[16];
+    to_mont256(w, x); to_mont256(w + 8, y);
+    memcpy(out, w, 64);
+}
+static void affine_out_g2(uint8_t* out, const G2XYZZ& p) {
+    if (is_inf(p)) { memset(out, 0, 128); return; }
+    Fq2 x, y;
+    xyzz_to_affine(x, y, p);
+    u32 w[32];
+    to_mont256(w, x.a); to_mont256(w + 8, x.b); to_mont256(w + 16, y.a); to_mont256(w + 24, y.b);
+    memcpy(out, w, 128);
+}
+
+int ug_msm_g1(ug_ctx* c, const ug_bases* b, const ug_schedule* s, int64_t index_shift, void* out) {
+    UG_TRY
+    if (!c || !b || !s || !out) throw std::invalid_argument("null argument");
+    if (b->g2) throw std::invalid_argument("ug_msm_g1 called with G2 bases");
+    c->use();
+    ScopedTimer tm(c, &c->msm_ms);
+    int64_t delta = (int64_t)s->first - index_shift - (int64_t)b->global_first;
+    G1XYZZ r = msm_g1(s->sched, c->ws_g1, b->pts, b->n, delta, c->stream, &c->stats);
+    tm.stop();
+    affine_out_g1((uint8_t*)out, r);
+    UG_CATCH
+}
+int ug_msm_g2(ug_ctx* c, const ug_bases* b, const ug_schedule* s, int64_t index_shift, void* out) {
+    UG_TRY
+    if (!c || !b || !s || !out) throw std::invalid_argument("null argument");
+    if (!b->g2) throw std::invalid_argument("ug_msm_g2 called with G1 bases");
+    c->use();
+    ScopedTimer tm(c, &c->msm_ms);
+    int64_t delta = (int64_t)s->first - index_shift - (int64_t)b->global_first;
+    G2XYZZ r = msm_g2(s->sched, c->ws_g2, b->pts, b->n, delta, c->stream, &c->stats);
+    tm.stop();
+    affine_out_g2((uint8_t*)out, r);
+    UG_CATCH
+}
+
+int ug_hpoly_create(ug_ctx* c, const void* host_coefs, uint64_t n_coefs, uint32_t domain, uint32_t n_vars, ug_hpoly** out) {
+    UG_TRY
+    if (!c || !out || (!host_coefs && n_coefs)) throw std::invalid_argument("null argument");
+    if (domain == 0 || (domain & (domain - 1))) throw std::invalid_argument("domain size is not a power of two");
+    if (domain > (1u << 27)) throw std::invalid_argument("domain size above 2^27 (Fr has 2-adicity 28)");
+    c->use();
+    ug_hpoly* hp = new ug_hpoly();
+    hp->ctx = c; hp->domain = domain; hp->nvars = n_vars;
+    uint8_t* raw = nullptr;
+    UG_HIP(hipMalloc(&raw, n_coefs ? (size_t)n_coefs * 44 : 4));
+    if (n_coefs) UG_HIP(hipMemcpyAsync(raw, host_coefs, (size_t)n_coefs * 44, hipMemcpyHostToDevice, c->stream));
+    bool ok = hp->mat.build(raw, n_coefs, domain, n_vars, c->stream);
+    hipFree(raw);
+    if (!ok) { delete hp; throw std::invalid_argument("coefficient record out of range (m, row or signal index)"); }
+    hp->ntt.init(hp->mat.logn, c->stream);
+    size_t bytes = (size_t)domain * 32;
+    UG_HIP(hipMalloc(&hp->a, bytes)); UG_HIP(hipMalloc(&hp->b, bytes));
+    UG_HIP(hipMalloc(&hp->c, bytes)); UG_HIP(hipMalloc(&hp->t, bytes));
+    *out = hp;
+    UG_CATCH
+}
+
+int ug_hpoly_run(ug_hpoly* hp, const ug_dvec* w, ug_dvec* h_out) {
+    UG_TRY
+    if (!hp || !w || !h_out) throw std::invalid_argument("null argument");
+    if (w->n < hp->nvars) throw std::invalid_argument("witness vector shorter than nVars");
+    if (h_out->n < hp->domain) throw std::invalid_argument("h vector shorter than the domain");
+    ug_ctx* c = hp->ctx;
+    c->use();
+    ScopedTimer tm(c, &c->fft_ms);
+    hipStream_t st = c->stream;
+    u64 n = hp->domain;
+    // S5-S6: a = A.w, b = B.w   (rows stored bit-reversed)            src/groth16.cpp:66-99
+    coef_matvec(hp->a, hp->b, hp->mat, w->data, st);
+    // S7: c = a o b                                                    :100-108
+    fr_mul_pointwise(hp->c, hp->a, hp->b, n, st);
+    // S8: ifft, twist by omega_2n^i (with 1/n folded in), fft          :110-140
+    u32* polys[3] = {hp->a, hp->b, hp->c};
+    for (int p = 0; p < 3; p++) {
+        hp->ntt.transform(hp->t, polys[p], /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st);
+        hp->ntt.transform(polys[p], hp->t, /*inverse*/ false, false, false, nullptr, nullptr, st);
+    }
+    // S9: h = a o b - c, to plain integers                             :142-148
+    fr_h_final(h_out->data, hp->a, hp->b, hp->c, n, st);
+    tm.stop();
+    UG_CATCH
+}
+
+int ug_hpoly_debug_abc(ug_hpoly* hp, void* ha, void* hb, void* hc) {
+    UG_TRY
+    if (!hp) throw std::invalid_argument("null argument");
+    ug_ctx* c = hp->ctx;
+    c->use();
+    void* host[3] = {ha, hb, hc};
+    u32* dev[3] = {hp->a, hp->b, hp->c};
+    for (int p = 0; p < 3; p++) {
+        if (!host[p]) continue;
+        fr_to_mont256(hp->t, dev[p], hp->domain, c->stream);
+        UG_HIP(hipMemcpyAsync(host[p], hp->t, (size_t)hp->domain * 32, hipMemcpyDeviceToHost, c->stream));
+        UG_HIP(hipStreamSynchronize(c->stream));
+    }
+    UG_CATCH
+}
+
+void ug_hpoly_destroy(ug_hpoly* hp) {
+    if (!hp) return;
+    hipSetDevice(hp->ctx->device);
+    hipFree(hp->a); hipFree(hp->b); hipFree(hp->c); hipFree(hp->t);
+    hp->mat.release(); hp->ntt.release();
+    delete hp;
+}
+
+int ug_fr_ntt(ug_ctx* c, void* host_data, int logn, int inverse) {
+    UG_TRY
+    if (!c || !host_data) throw std::invalid_argument("null argument");
+    if (logn < 0 || logn > 27) throw std::invalid_argument("logn out of range");
+    c->use();
+    if (c->raw_ntt.logn != logn) c->raw_ntt.init(logn, c->stream);
+    size_t bytes = ((size_t)1 << logn) * 32;
+    u32 *x = nullptr, *y = nullptr;
+    UG_HIP(hipMalloc(&x, bytes)); UG_HIP(hipMalloc(&y, bytes));
+    UG_HIP(hipMemcpyAsync(x, host_data, bytes, hipMemcpyHostToDevice, c->stream));
+    fr_from_mont256(x, x, (u64)1 << logn, c->stream);
+    if (logn == 0) UG_HIP(hipMemcpyAsync(y, x, bytes, hipMemcpyDeviceToDevice, c->stream));
+    else c->raw_ntt.transform(y, x, inverse != 0, /*gather_bitrev*/ true, false, nullptr, inverse ? c->raw_ntt.ninv : nullptr, c->stream);
+    fr_to_mont256(y, y, (u64)1 << logn, c->stream);
+    UG_HIP(hipMemcpyAsync(host_data, y, bytes, hipMemcpyDeviceToHost, c->stream));
+    UG_HIP(hipStreamSynchronize(c->stream));
+    hipFree(x); hipFree(y);
+    UG_CATCH
+}
+
+int ug_field_op(ug_ctx* c, int field, int op, void* out, const void* a, const void* b, uint64_t n) {
+    UG_TRY
+    if (!c || !out || !a || !b) throw std::invalid_argument("null argument");
+    if (field != UG_FIELD_FR && field != UG_FIELD_FQ) throw std::invalid_argument("unknown field");
+    if (op < 0 || op > 3) throw std::invalid_argument("unknown op");
+    c->use();
+    size_t bytes = (size_t)n * 32;
+    u32 *da = nullptr, *db = nullptr, *dout = nullptr;
+    UG_HIP(hipMalloc(&da, bytes ? bytes : 4)); UG_HIP(hipMalloc(&db, bytes ? bytes : 4)); UG_HIP(hipMalloc(&dout, bytes ? bytes : 4));
+    if (n) {
+        UG_HIP(hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, c->stream));
+        UG_HIP(hipMemcpyAsync(db, b, bytes, hipMemcpyHostToDevice, c->stream));
+        f_op_mont256(field, op, dout, da, db, n, c->stream);
+        UG_HIP(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, c->stream));
+    }
+    UG_HIP(hipStreamSynchronize(c->stream));
+    hipFree(da); hipFree(db); hipFree(dout);
+    UG_CATCH
+}
+
+int ug_ctx_timings(ug_ctx* c, double* msm_ms, double* fft_ms, int reset) {
+    UG_TRY
+    if (!c) throw std::invalid_argument("null argument");
+    if (msm_ms) *msm_ms = c->msm_ms;
+    if (fft_ms) *fft_ms = c->fft_ms;
+    if (reset) { c->msm_ms = 0; c->fft_ms = 0; }
+    UG_CATCH
+}
+int ug_ctx_kernel_stats(ug_ctx* c, double* avg_ms, uint64_t* launches, uint64_t* entries, int reset) {
+    UG_TRY
+    if (!c) throw std::invalid_argument("null argument");
+    if (avg_ms) *avg_ms = c->stats.launches ? c->stats.accumulate_ms / (double)c->stats.launches : 0.0;
+    if (launches) *launches = c->stats.launches;
+    if (entries) *entries = c->stats.entries;
+    if (reset) { c->stats.accumulate_ms = 0; c->stats.launches = 0; c->stats.entries = 0; }
+    UG_CATCH
+}
+
+}  // extern "C"
