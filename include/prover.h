@@ -113,9 +113,9 @@ void ug_test_set_blinding(const void *bytes, unsigned long long n);
 /* Device milliseconds of the last prove on this prover object: MSM part, H-polynomial ("FFT") part, and
  * host wall-clock milliseconds of the whole prove call. */
 int ug_prover_last_timings(void *prover_object, double *msm_ms, double *fft_ms, double *total_ms);
-/* average duration (ms), launch count and (point, window) entries of the bucket-accumulation kernel
- * since the prover was created or the counters were last reset */
-int ug_prover_kernel_stats(void *prover_object, double *accumulate_ms_avg, unsigned long long *launches,
+/* average duration (ms), launch count and (point, window) entries of the G1 (g2 = 0) or G2 (g2 = 1)
+ * bucket-accumulation kernel since the prover was created or the counters were last reset */
+int ug_prover_kernel_stats(void *prover_object, int g2, double *accumulate_ms_avg, unsigned long long *launches,
                            unsigned long long *entries, int reset);
 
 /* Sharded Groth16 proving, one process per GPU. Rank `shard_rank` of `shard_count` holds the base points

@@ -107,13 +107,18 @@ int  ug_fr_ntt(ug_ctx* ctx, void* host_data, int logn, int inverse);
 /* out[i] = a[i] (op) b[i] on n Montgomery elements of the chosen field (host buffers) */
 int  ug_field_op(ug_ctx* ctx, int field, int op, void* out, const void* a, const void* b, uint64_t n);
 
+/* Tooling for synthetic circuits (bench.py, tests): host_out[i] = (seed + i) * G as zkey-format affine
+ * records, G given as one such record (64 bytes for G1, 128 for G2). Not part of the reference interface. */
+int  ug_synth_points(ug_ctx* ctx, int g2, const void* generator_record, uint64_t seed, uint64_t n, void* host_out);
+
 /* milliseconds of device time spent in the MSM and H-polynomial parts since the last reset
  * (the MSM | FFT split the reference prints in src/ultra_groth.cpp:199-335) */
 int  ug_ctx_timings(ug_ctx* ctx, double* msm_ms, double* fft_ms, int reset);
 
-/* HIP events over one kernel of the hot path for roofline reporting: average duration in ms of the
- * bucket-accumulation launches since the last reset, their count, and the points they processed */
-int  ug_ctx_kernel_stats(ug_ctx* ctx, double* accumulate_ms_avg, uint64_t* launches, uint64_t* entries, int reset);
+/* HIP events (recorded on the launch stream) over the dominant kernel of the hot path, for roofline
+ * reporting: average duration in ms of the G1 (g2 = 0) or G2 (g2 = 1) bucket-accumulation launches since
+ * the last reset, their count, and the (point, window) entries they processed */
+int  ug_ctx_kernel_stats(ug_ctx* ctx, int g2, double* accumulate_ms_avg, uint64_t* launches, uint64_t* entries, int reset);
 
 #ifdef __cplusplus
 }

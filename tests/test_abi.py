@@ -1,0 +1,114 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/*.h declares, and its host-only entry points
+behave like the reference's (sizes, error codes, error strings). No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import ultragroth_amd as ug
+from ultragroth_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return ug.load()
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return set(re.findall(r"\b((?:ug|groth16|ultra_groth)_[a-z0-9_]+)\s*\(", txt))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    inner, outer = _declared("ultragroth_hip.h"), _declared("prover.h")
+    assert inner == set(_lib.INNER_SYMBOLS)
+    assert outer == set(_lib.OUTER_SYMBOLS)
+    for name in inner | outer:
+        assert hasattr(lib, name), name
+
+
+def test_reference_symbol_set_is_complete(lib):
+    """the 18 entry points of the reference's src/prover.h"""
+    ref = ["groth16_public_size_for_zkey_buf", "ultra_groth_public_size_for_zkey_buf", "groth16_public_size_for_zkey_file",
+           "ultra_groth_public_size_for_zkey_file", "groth16_proof_size", "ultra_groth_proof_size", "groth16_prover_create",
+           "ultra_groth_prover_create", "groth16_prover_create_zkey_file", "ultra_groth_prover_create_zkey_file",
+           "groth16_prover_prove", "ultra_groth_prover_prove", "groth16_prover_destroy", "ultra_groth_prover_destroy",
+           "groth16_prover", "ultra_groth_prover", "groth16_prover_zkey_file", "ultra_groth_prover_zkey_file"]
+    for name in ref:
+        assert hasattr(lib, name)
+
+
+def test_sizes(lib, zkey):
+    assert ug.groth16_proof_size() == 810                 # src/prover.cpp:55-59
+    assert ug.ultra_groth_proof_size() == 1400            # :61-65
+    assert ug.groth16_public_size_for_zkey_buf(zkey) == 1 * 82 + 4       # :67-71
+    v = C.c_ulonglong()
+    err = C.create_string_buffer(256)
+    path = os.path.join(ROOT, "tests", "golden", "circuit_final.zkey").encode()
+    assert lib.groth16_public_size_for_zkey_file(path, C.byref(v), err, 255) == 0 and v.value == 86
+
+
+def test_error_strings_match_the_reference(lib, zkey, wtns):
+    with pytest.raises(ug.ProverError) as e:
+        ug.groth16_public_size_for_zkey_buf(b"zkey")
+    assert e.value.code == ug.PROVER_ERROR and e.value.message == "File is too short."           # binfile_utils.cpp:37
+    with pytest.raises(ug.ProverError) as e:
+        ug.groth16_public_size_for_zkey_buf(wtns)
+    assert e.value.message == "Invalid file type. It should be zkey and it is wtns"                # :44
+    with pytest.raises(ug.ProverError) as e:
+        ug.ultra_groth_public_size_for_zkey_buf(zkey)
+    assert e.value.message == "zkey file is not ultragroth"                                        # zkey_utils.cpp:129-131
+    bad = bytearray(zkey)
+    bad[4] = 9
+    with pytest.raises(ug.ProverError) as e:
+        ug.groth16_public_size_for_zkey_buf(bytes(bad))
+    assert e.value.message == "Invalid version. It should be <=1 and it is 9"                      # :49
+    with pytest.raises(ug.ProverError) as e:
+        ug.groth16_public_size_for_zkey_buf(zkey[:5000])
+    assert e.value.message.startswith("Section #")                                                 # :71-75
+    # null-argument checks come before any device work (src/prover.cpp:382-388,514-536)
+    err = C.create_string_buffer(256)
+    assert lib.groth16_prover_create(None, zkey, len(zkey), err, 255) == ug.PROVER_ERROR
+    assert err.value == b"Null prover object"
+    h = C.c_void_p()
+    assert lib.groth16_prover_create(C.byref(h), None, 0, err, 255) == ug.PROVER_ERROR
+    assert err.value == b"Null zkey buffer"
+    assert lib.groth16_prover_prove(None, wtns, len(wtns), None, None, None, None, err, 255) == ug.PROVER_ERROR
+    assert err.value == b"Null prover object"
+    msg = C.create_string_buffer(b"\xff" * 8, 8)          # strncpy semantics: at most maxsize bytes, maybe unterminated
+    assert lib.groth16_prover_create(None, zkey, len(zkey), msg, 4) == ug.PROVER_ERROR
+    assert msg.raw[:4] == b"Null" and msg.raw[4:] == b"\xff" * 4
+
+
+def test_no_silent_cpu_fallback(lib, zkey):
+    """without a GPU the compute entry points fail loudly"""
+    if ug.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(ug.DeviceError):
+        ug.Device(0)
+    with pytest.raises(ug.ProverError) as e:
+        ug.Groth16Prover(zkey)
+    assert e.value.code == ug.PROVER_ERROR and "HIP" in e.value.message
+
+
+def test_partials_add_is_host_only_and_exact(lib, zkey):
+    """ug_groth16_partials_add (the N>1 exchange step) against the oracle's group law"""
+    import oracle as O
+    off, _ = O.section(zkey, "zkey", 5)
+    off2, _ = O.section(zkey, "zkey", 7)
+    g1 = [zkey[off + 64 * i: off + 64 * i + 64] for i in range(2, 12)]
+    g2 = [zkey[off2 + 128 * i: off2 + 128 * i + 128] for i in range(2, 4)]
+    a = g1[0] + g1[1] + g2[0] + g1[2] + g1[3]
+    b = g1[4] + bytes(64) + g2[1] + g1[2] + g1[5]                  # B1 partial at infinity; C partials equal (doubling)
+    s = ug.ShardedGroth16Prover.add_partials(a, b)
+    assert s[0:64] == O.g1_add(g1[0], g1[4])
+    assert s[64:128] == g1[1]
+    assert s[128:256] == O.g2_add(g2[0], g2[1])
+    assert s[256:320] == O.g1_mul(g1[2], 2)
+    assert s[320:384] == O.g1_add(g1[3], g1[5])

@@ -1,0 +1,66 @@
+"""N > 1 exchange path on CPU: two gloo ranks each compute the partial MSM sums of their contiguous base-point range
+(with the oracle standing in for the device), all-gather the 384-byte partial records and add them with the
+product's ug_groth16_partials_add -- the same code bench.py runs over RCCL. The sum must equal the unsharded sums."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle as O
+    import ultragroth_amd as ug
+    zkey = open(os.path.join(ROOT, "tests", "golden", "circuit_final.zkey"), "rb").read()
+    wtns = open(os.path.join(ROOT, "tests", "golden", "witness.wtns"), "rb").read()
+    info = O.zkey_info(zkey)
+    M, N, P = info["nVars"], info["domainSize"], info["nPublic"]
+    sec = lambda sid: zkey[O.section(zkey, "zkey", sid)[0]: sum(O.section(zkey, "zkey", sid))]
+    w = wtns[O.section(wtns, "wtns", 2)[0]: sum(O.section(wtns, "wtns", 2))]
+    h = O.hpoly(sec(4)[4:], info["nCoefs"], w, M, N)
+    lo, hi = M * rank // world, M * (rank + 1) // world            # same split as Groth16Prover (prover_api.cpp)
+    hlo, hhi = N * rank // world, N * (rank + 1) // world
+    shift = P + 1
+    nC = M - P - 1
+    clo, chi = min(max(lo - shift, 0), nC), min(max(hi - shift, 0), nC)
+    part = O.g1_msm(sec(5)[64 * lo:64 * hi], w[32 * lo:32 * hi], hi - lo)
+    part += O.g1_msm(sec(6)[64 * lo:64 * hi], w[32 * lo:32 * hi], hi - lo)
+    part += O.g2_msm(sec(7)[128 * lo:128 * hi], w[32 * lo:32 * hi], hi - lo)
+    part += O.g1_msm(sec(8)[64 * clo:64 * chi], w[32 * (clo + shift):32 * (chi + shift)], chi - clo)
+    part += O.g1_msm(sec(9)[64 * hlo:64 * hhi], h[32 * hlo:32 * hhi], hhi - hlo)
+    mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)
+    allp = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allp, mine)
+    total = bytes(allp[0].numpy())
+    for other in allp[1:]:
+        total = ug.ShardedGroth16Prover.add_partials(total, bytes(other.numpy()))
+    if rank == 0:
+        q.put(total)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_partials_sum_to_the_unsharded_result(world, zkey, wtns):
+    import oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + world + (os.getpid() % 200)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    total = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r, s = 5, 7
+    _, _, raw = O.groth16_prove(zkey, wtns, r, s, want_raw=True)
+    assert total == raw

@@ -121,10 +121,10 @@ class _ProverBase:
         load().ug_prover_last_timings(self._h, C.byref(a), C.byref(b), C.byref(c))
         return a.value, b.value, c.value
 
-    def kernel_stats(self, reset=False):
-        """(avg ms, launches, entries) of the bucket-accumulation kernel since creation / last reset."""
+    def kernel_stats(self, g2=False, reset=False):
+        """(avg ms, launches, entries) of the G1 / G2 bucket-accumulation kernel since creation / last reset."""
         a, l, e = C.c_double(), C.c_ulonglong(), C.c_ulonglong()
-        load().ug_prover_kernel_stats(self._h, C.byref(a), C.byref(l), C.byref(e), 1 if reset else 0)
+        load().ug_prover_kernel_stats(self._h, 1 if g2 else 0, C.byref(a), C.byref(l), C.byref(e), 1 if reset else 0)
         return a.value, l.value, e.value
 
     def close(self):
@@ -318,9 +318,9 @@ class Device:
         _check(self._L.ug_ctx_timings(self._h, C.byref(a), C.byref(b), 1 if reset else 0))
         return a.value, b.value
 
-    def kernel_stats(self, reset=False):
+    def kernel_stats(self, g2=False, reset=False):
         a, l, e = C.c_double(), C.c_uint64(), C.c_uint64()
-        _check(self._L.ug_ctx_kernel_stats(self._h, C.byref(a), C.byref(l), C.byref(e), 1 if reset else 0))
+        _check(self._L.ug_ctx_kernel_stats(self._h, 1 if g2 else 0, C.byref(a), C.byref(l), C.byref(e), 1 if reset else 0))
         return a.value, l.value, e.value
 
 

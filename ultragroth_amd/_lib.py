@@ -18,7 +18,7 @@ INNER_SYMBOLS = [
     "ug_schedule_create", "ug_schedule_build", "ug_schedule_destroy",
     "ug_msm_g1", "ug_msm_g2",
     "ug_hpoly_create", "ug_hpoly_run", "ug_hpoly_debug_abc", "ug_hpoly_destroy",
-    "ug_fr_ntt", "ug_field_op", "ug_ctx_timings", "ug_ctx_kernel_stats",
+    "ug_fr_ntt", "ug_field_op", "ug_synth_points", "ug_ctx_timings", "ug_ctx_kernel_stats",
 ]
 OUTER_SYMBOLS = [
     "groth16_public_size_for_zkey_buf", "ultra_groth_public_size_for_zkey_buf",
@@ -82,8 +82,9 @@ def load():
     L.ug_hpoly_destroy.argtypes = [vp]; L.ug_hpoly_destroy.restype = None
     L.ug_fr_ntt.argtypes = [vp, vp, C.c_int, C.c_int]
     L.ug_field_op.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, u64]
+    L.ug_synth_points.argtypes = [vp, C.c_int, vp, u64, u64, vp]
     L.ug_ctx_timings.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
-    L.ug_ctx_kernel_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64), C.c_int]
+    L.ug_ctx_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64), C.c_int]
     # outer API (include/prover.h)
     for n in ("groth16_public_size_for_zkey_buf", "ultra_groth_public_size_for_zkey_buf"):
         getattr(L, n).argtypes = [vp, ull, pull, vp, ull]
@@ -105,7 +106,7 @@ def load():
         getattr(L, n).argtypes = [C.c_char_p, vp, ull, vp, pull, vp, pull, vp, ull]
     L.ug_test_set_blinding.argtypes = [vp, ull]; L.ug_test_set_blinding.restype = None
     L.ug_prover_last_timings.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
-    L.ug_prover_kernel_stats.argtypes = [vp, C.POINTER(C.c_double), pull, pull, C.c_int]
+    L.ug_prover_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_double), pull, pull, C.c_int]
     L.ug_groth16_prover_create_sharded.argtypes = [pp, vp, ull, C.c_int, C.c_int, C.c_int, vp, ull]
     L.ug_groth16_prover_load_witness.argtypes = [vp, vp, ull, vp, ull]
     L.ug_groth16_prover_run.argtypes = [vp, vp, vp, ull]

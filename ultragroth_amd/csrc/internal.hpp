@@ -53,7 +53,8 @@ struct MsmSchedule {
     HeavyBucket* heavy_buckets_dev = nullptr;
     // workspace
     u32 *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
-    u32* heavy_list = nullptr;    // device: [count, (bucket, start, count) * MAX_HEAVY]
+    u32* heavy_list = nullptr;    // device: [count, (bucket, start, count) * heavy_cap]
+    u32 heavy_cap = 0;
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     u64 capacity_n = 0; u64 capacity_buckets = 0;
     void reserve(const MsmGeometry& g);
@@ -87,6 +88,9 @@ G2XYZZ msm_g2(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_ba
 // zkey affine records (reference Montgomery form, R = 2^256) -> device form, in place on the device
 void convert_points_g1(u32* pts, u64 n, hipStream_t stream);
 void convert_points_g2(u32* pts, u64 n, hipStream_t stream);
+
+// bench / test tooling: out[i] = (seed + i) * G as zkey-format records (device buffer); G given as a host record
+void synth_points(bool g2, u32* out_dev, const u32* gen_record_host, u64 seed, u64 n, hipStream_t stream);
 
 // ---- hpoly.hip ----------------------------------------------------------------------------------------
 struct CoefMatrix {

@@ -30,7 +30,6 @@ namespace {
 
 constexpr u32 HEAVY = 256;            // buckets above this many entries take the block-parallel path
 constexpr u32 TASK_ENTRIES = 8192;    // entries per heavy task (one workgroup)
-constexpr u32 MAX_HEAVY = 8192;       // capacity of the heavy-bucket list
 constexpr int CHUNK = 32;             // buckets per running-sum chunk
 
 // ---- curve configurations -------------------------------------------------------------------------
@@ -46,6 +45,12 @@ struct G1Cfg {
         if (o == 0) return false;
         x = unpack256<FqParams>(w); y = unpack256<FqParams>(w + 8);
         return true;
+    }
+    static __host__ __device__ __forceinline__ void store_affine_mont256(u32* o, const F& x, const F& y) {
+        to_mont256(o, x); to_mont256(o + 8, y);
+    }
+    static __host__ __device__ __forceinline__ void store_affine_packed(u32* o, const F& x, const F& y) {
+        pack256(o, cond_sub_q(mul(x, fp_one<FqParams>()))); pack256(o + 8, cond_sub_q(mul(y, fp_one<FqParams>())));
     }
     static __host__ __device__ __forceinline__ void to_words(u32* p, const XYZZ<F>& a, size_t stride) {
 #pragma unroll
@@ -77,6 +82,13 @@ struct G2Cfg {
         x.a = unpack256<FqParams>(w); x.b = unpack256<FqParams>(w + 8);
         y.a = unpack256<FqParams>(w + 16); y.b = unpack256<FqParams>(w + 24);
         return true;
+    }
+    static __host__ __device__ __forceinline__ void store_affine_mont256(u32* o, const F& x, const F& y) {
+        to_mont256(o, x.a); to_mont256(o + 8, x.b); to_mont256(o + 16, y.a); to_mont256(o + 24, y.b);
+    }
+    static __host__ __device__ __forceinline__ void store_affine_packed(u32* o, const F& x, const F& y) {
+        const Fq* f[4] = {&x.a, &x.b, &y.a, &y.b};
+        for (int k = 0; k < 4; k++) pack256(o + 8 * k, cond_sub_q(mul(*f[k], fp_one<FqParams>())));
     }
     static __host__ __device__ __forceinline__ void to_words(u32* p, const XYZZ<F>& a, size_t stride) {
         const Fq* f[8] = {&a.x.a, &a.x.b, &a.y.a, &a.y.b, &a.zz.a, &a.zz.b, &a.zzz.a, &a.zzz.b};
@@ -149,7 +161,7 @@ __global__ void bucket_bounds_kernel(const u32* keys, u64 total, u32 sentinel, u
     if (p == 0 || keys[p - 1] != k) start[k] = (u32)p;
     if (p + 1 == total || keys[p + 1] != k) count[k] = (u32)p + 1;      // end for now
 }
-__global__ void bucket_counts_kernel(u32* start, u32* count, u32 nb, u32* heavy_list) {
+__global__ void bucket_counts_kernel(u32* start, u32* count, u32 nb, u32* heavy_list, u32 heavy_cap) {
     u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     u32 e = count[b];
@@ -157,7 +169,7 @@ __global__ void bucket_counts_kernel(u32* start, u32* count, u32 nb, u32* heavy_
     count[b] = c;
     if (c > HEAVY) {
         u32 pos = atomicAdd(&heavy_list[0], 1u);
-        if (pos < MAX_HEAVY) { heavy_list[1 + 3 * pos] = b; heavy_list[2 + 3 * pos] = start[b]; heavy_list[3 + 3 * pos] = c; }
+        if (pos < heavy_cap) { heavy_list[1 + 3 * pos] = b; heavy_list[2 + 3 * pos] = start[b]; heavy_list[3 + 3 * pos] = c; }
     }
 }
 
@@ -275,6 +287,28 @@ __global__ void convert_coords_kernel(u32* pts, u64 n_coords_groups, int coords_
     }
 }
 
+// ---- synthetic base points (bench / test tooling): record i = (seed + i) * G ------------------------------
+// table: 64 affine records 2^j * G in device form; output: zkey-format records (Montgomery R = 2^256)
+template <class Cfg>
+__global__ __launch_bounds__(128) void synth_points_kernel(const u32* table, u64 seed, u64 n, u32* out) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    typedef typename Cfg::F F;
+    u64 k = seed + i;
+    XYZZ<F> acc = xyzz_inf<F>();
+    for (int j = 0; j < 64; j++) {
+        if (!((k >> j) & 1)) continue;
+        F x, y;
+        Cfg::load_affine(table + (size_t)j * Cfg::AFF_WORDS, x, y);
+        acc = xyzz_madd(acc, x, y);
+    }
+    u32* o = out + i * Cfg::AFF_WORDS;
+    if (is_inf(acc)) { for (int w = 0; w < Cfg::AFF_WORDS; w++) o[w] = 0; return; }
+    F ax, ay;
+    xyzz_to_affine(ax, ay, acc);
+    Cfg::store_affine_mont256(o, ax, ay);
+}
+
 template <class T> void dev_alloc(T*& p, size_t bytes) { if (p) hipFree(p); p = nullptr; UG_HIP(hipMalloc(&p, bytes ? bytes : 4)); }
 template <class T> void dev_free(T*& p) { if (p) hipFree(p); p = nullptr; }
 
@@ -312,7 +346,8 @@ void MsmSchedule::reserve(const MsmGeometry& g) {
         dev_alloc(bucket_count, g.total_buckets() * 4);
         capacity_buckets = g.total_buckets();
     }
-    if (!heavy_list) dev_alloc(heavy_list, (3 * MAX_HEAVY + 1) * 4);
+    u64 hcap = total / HEAVY + 2;                       // no more buckets than this can exceed HEAVY entries
+    if (hcap > heavy_cap) { dev_alloc(heavy_list, (3 * hcap + 1) * 4); heavy_cap = (u32)hcap; }
 }
 
 void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_t stream) {
@@ -340,13 +375,13 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
     hipLaunchKernelGGL(bucket_bounds_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                        sorted_keys, total, sentinel, bucket_start, bucket_count);
     UG_KERNEL_CHECK();
-    hipLaunchKernelGGL(bucket_counts_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, bucket_start, bucket_count, nb, heavy_list);
+    hipLaunchKernelGGL(bucket_counts_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, bucket_start, bucket_count, nb, heavy_list, heavy_cap);
     UG_KERNEL_CHECK();
     // heavy buckets -> tasks (host round trip; the list is tiny)
     u32 nh = 0;
     UG_HIP(hipMemcpyAsync(&nh, heavy_list, 4, hipMemcpyDeviceToHost, stream));
     UG_HIP(hipStreamSynchronize(stream));
-    if (nh > MAX_HEAVY) throw std::runtime_error("msm: too many heavy buckets");
+    if (nh > heavy_cap) throw std::runtime_error("msm: heavy-bucket list overflow");
     if (nh) {
         std::vector<u32> trip((size_t)nh * 3);
         UG_HIP(hipMemcpy(trip.data(), heavy_list + 1, trip.size() * 4, hipMemcpyDeviceToHost));
@@ -370,7 +405,7 @@ void MsmSchedule::release() {
     dev_free(keys_a); dev_free(keys_b); dev_free(vals_a); dev_free(vals_b); dev_free(sort_tmp);
     dev_free(bucket_start); dev_free(bucket_count); dev_free(heavy_list);
     dev_free(heavy_tasks_dev); dev_free(heavy_buckets_dev);
-    capacity_n = capacity_buckets = 0; sort_tmp_bytes = 0; vals = nullptr;
+    capacity_n = capacity_buckets = 0; sort_tmp_bytes = 0; vals = nullptr; heavy_cap = 0;
 }
 
 // ---- workspace ------------------------------------------------------------------------------------------------
@@ -450,6 +485,45 @@ G1XYZZ msm_g1(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_ba
 }
 G2XYZZ msm_g2(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta, hipStream_t stream, MsmStats* stats) {
     return msm_run<G2Cfg>(s, ws, bases, n_bases, delta, stream, stats);
+}
+
+namespace {
+template <class Cfg>
+void synth_points_run(u32* out_dev, const u32* gen_record_host, u64 seed, u64 n, hipStream_t stream) {
+    typedef typename Cfg::F F;
+    // 2^j * G for j < 64 on the host, packed device form
+    std::vector<u32> table((size_t)64 * Cfg::AFF_WORDS);
+    std::vector<u32> gen(gen_record_host, gen_record_host + Cfg::AFF_WORDS);
+    XYZZ<F> p;
+    {
+        F x, y;
+        const int nc = Cfg::AFF_WORDS / 8;
+        Fq c[4];
+        for (int k = 0; k < nc; k++) c[k] = from_mont256<FqParams>(gen.data() + 8 * k);
+        if (nc == 2) { memcpy(&x, &c[0], sizeof(Fq)); memcpy(&y, &c[1], sizeof(Fq)); }
+        else { memcpy(&x, &c[0], 2 * sizeof(Fq)); memcpy(&y, &c[2], 2 * sizeof(Fq)); }
+        p = xyzz_from_affine(x, y);
+    }
+    for (int j = 0; j < 64; j++) {
+        F ax, ay;
+        xyzz_to_affine(ax, ay, p);
+        Cfg::store_affine_packed(table.data() + (size_t)j * Cfg::AFF_WORDS, ax, ay);
+        p = xyzz_dbl(p);
+    }
+    u32* d_table = nullptr;
+    UG_HIP(hipMalloc(&d_table, table.size() * 4));
+    UG_HIP(hipMemcpyAsync(d_table, table.data(), table.size() * 4, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(synth_points_kernel<Cfg>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, d_table, seed, n, out_dev);
+    UG_KERNEL_CHECK();
+    UG_HIP(hipStreamSynchronize(stream));
+    hipFree(d_table);
+}
+}  // namespace
+
+void synth_points(bool g2, u32* out_dev, const u32* gen_record_host, u64 seed, u64 n, hipStream_t stream) {
+    if (!n) return;
+    if (g2) synth_points_run<G2Cfg>(out_dev, gen_record_host, seed, n, stream);
+    else synth_points_run<G1Cfg>(out_dev, gen_record_host, seed, n, stream);
 }
 
 void convert_points_g1(u32* pts, u64 n, hipStream_t stream) {

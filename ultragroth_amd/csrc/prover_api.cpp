@@ -662,11 +662,11 @@ int ug_prover_last_timings(void* prover_object, double* msm_ms, double* fft_ms, 
     static_cast<ProverBase*>(prover_object)->timings(msm_ms, fft_ms, total_ms);
     return PROVER_OK;
 }
-int ug_prover_kernel_stats(void* prover_object, double* accumulate_ms_avg, unsigned long long* launches,
+int ug_prover_kernel_stats(void* prover_object, int g2, double* accumulate_ms_avg, unsigned long long* launches,
                            unsigned long long* entries, int reset) {
     if (!prover_object) return PROVER_ERROR;
     uint64_t l = 0, e = 0;
-    int rc = ug_ctx_kernel_stats(static_cast<ProverBase*>(prover_object)->ctx(), accumulate_ms_avg, &l, &e, reset);
+    int rc = ug_ctx_kernel_stats(static_cast<ProverBase*>(prover_object)->ctx(), g2, accumulate_ms_avg, &l, &e, reset);
     if (launches) *launches = l;
     if (entries) *entries = e;
     return rc == UG_OK ? PROVER_OK : PROVER_ERROR;

@@ -25,7 +25,7 @@ struct ug_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     MsmWorkspace ws_g1, ws_g2;
-    MsmStats stats;
+    MsmStats stats[2];                     // [0] G1, [1] G2 bucket-accumulation launches
     hipEvent_t t0 = nullptr, t1 = nullptr;
     double msm_ms = 0, fft_ms = 0;
     NttPlan raw_ntt;                       // cache for ug_fr_ntt
@@ -82,7 +82,7 @@ int ug_ctx_create(ug_ctx** out, int device) {
     c->use();
     UG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     UG_HIP(hipEventCreate(&c->t0)); UG_HIP(hipEventCreate(&c->t1));
-    UG_HIP(hipEventCreate(&c->stats.ev0)); UG_HIP(hipEventCreate(&c->stats.ev1));
+    for (int k = 0; k < 2; k++) { UG_HIP(hipEventCreate(&c->stats[k].ev0)); UG_HIP(hipEventCreate(&c->stats[k].ev1)); }
     *out = c;
     UG_CATCH
 }
@@ -91,7 +91,8 @@ void ug_ctx_destroy(ug_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     c->ws_g1.release(); c->ws_g2.release(); c->raw_ntt.release();
-    hipEventDestroy(c->t0); hipEventDestroy(c->t1); hipEventDestroy(c->stats.ev0); hipEventDestroy(c->stats.ev1);
+    hipEventDestroy(c->t0); hipEventDestroy(c->t1);
+    for (int k = 0; k < 2; k++) { hipEventDestroy(c->stats[k].ev0); hipEventDestroy(c->stats[k].ev1); }
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -226,7 +227,7 @@ int ug_msm_g1(ug_ctx* c, const ug_bases* b, const ug_schedule* s, int64_t index_
     c->use();
     ScopedTimer tm(c, &c->msm_ms);
     int64_t delta = (int64_t)s->first - index_shift - (int64_t)b->global_first;
-    G1XYZZ r = msm_g1(s->sched, c->ws_g1, b->pts, b->n, delta, c->stream, &c->stats);
+    G1XYZZ r = msm_g1(s->sched, c->ws_g1, b->pts, b->n, delta, c->stream, &c->stats[0]);
     tm.stop();
     affine_out_g1((uint8_t*)out, r);
     UG_CATCH
@@ -238,7 +239,7 @@ int ug_msm_g2(ug_ctx* c, const ug_bases* b, const ug_schedule* s, int64_t index_
     c->use();
     ScopedTimer tm(c, &c->msm_ms);
     int64_t delta = (int64_t)s->first - index_shift - (int64_t)b->global_first;
-    G2XYZZ r = msm_g2(s->sched, c->ws_g2, b->pts, b->n, delta, c->stream, &c->stats);
+    G2XYZZ r = msm_g2(s->sched, c->ws_g2, b->pts, b->n, delta, c->stream, &c->stats[1]);
     tm.stop();
     affine_out_g2((uint8_t*)out, r);
     UG_CATCH
@@ -356,6 +357,25 @@ int ug_field_op(ug_ctx* c, int field, int op, void* out, const void* a, const vo
     UG_CATCH
 }
 
+int ug_synth_points(ug_ctx* c, int g2, const void* generator_record, uint64_t seed, uint64_t n, void* host_out) {
+    UG_TRY
+    if (!c || !generator_record || (!host_out && n)) throw std::invalid_argument("null argument");
+    c->use();
+    size_t rec = g2 ? 128 : 64;
+    u32 gen[32];
+    memcpy(gen, generator_record, rec);
+    const u64 CH = (u64)1 << 22;                       // stage through a bounded device buffer
+    u32* dev = nullptr;
+    UG_HIP(hipMalloc(&dev, (size_t)(n < CH ? (n ? n : 1) : CH) * rec));
+    for (u64 done = 0; done < n; done += CH) {
+        u64 m = n - done < CH ? n - done : CH;
+        synth_points(g2 != 0, dev, gen, seed + done, m, c->stream);
+        UG_HIP(hipMemcpy((uint8_t*)host_out + done * rec, dev, (size_t)m * rec, hipMemcpyDeviceToHost));
+    }
+    hipFree(dev);
+    UG_CATCH
+}
+
 int ug_ctx_timings(ug_ctx* c, double* msm_ms, double* fft_ms, int reset) {
     UG_TRY
     if (!c) throw std::invalid_argument("null argument");
@@ -364,13 +384,14 @@ int ug_ctx_timings(ug_ctx* c, double* msm_ms, double* fft_ms, int reset) {
     if (reset) { c->msm_ms = 0; c->fft_ms = 0; }
     UG_CATCH
 }
-int ug_ctx_kernel_stats(ug_ctx* c, double* avg_ms, uint64_t* launches, uint64_t* entries, int reset) {
+int ug_ctx_kernel_stats(ug_ctx* c, int g2, double* avg_ms, uint64_t* launches, uint64_t* entries, int reset) {
     UG_TRY
     if (!c) throw std::invalid_argument("null argument");
-    if (avg_ms) *avg_ms = c->stats.launches ? c->stats.accumulate_ms / (double)c->stats.launches : 0.0;
-    if (launches) *launches = c->stats.launches;
-    if (entries) *entries = c->stats.entries;
-    if (reset) { c->stats.accumulate_ms = 0; c->stats.launches = 0; c->stats.entries = 0; }
+    MsmStats& st = c->stats[g2 ? 1 : 0];
+    if (avg_ms) *avg_ms = st.launches ? st.accumulate_ms / (double)st.launches : 0.0;
+    if (launches) *launches = st.launches;
+    if (entries) *entries = st.entries;
+    if (reset) { st.accumulate_ms = 0; st.launches = 0; st.entries = 0; }
     UG_CATCH
 }
 

@@ -1,0 +1,131 @@
+"""Seeded synthetic Groth16 circuits in the reference's zkey / wtns formats (bench and test tooling).
+
+Shapes follow SURVEY.md section 8(d): domainSize N, nVars = N - 1, nPublic = 1, nCoefs = 4 N (two A and
+two B entries per row, signal ids from the PRNG). Base points are valid curve points
+P_i = (seed + i) * G produced on the GPU by ``ug_synth_points`` (the generator walk of the survey), so an
+MSM over them has a closed form in the exponent:  sum s_i P_i = (sum s_i (seed + i) mod r) * G, which the
+full-size tests check. Scalar mixes: "U" uniform in [0, r); "C" circom-like (40 % in {0,1}, 20 % below
+2^32, 40 % uniform).
+
+The proofs of such circuits are not valid Groth16 proofs (there is no trapdoor behind the points); every
+arithmetic step is nevertheless exactly the prover's, and results are compared bit for bit with the oracle.
+"""
+import struct
+
+import numpy as np
+
+R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+Q_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+
+G1_GEN = (1, 2)
+G2_GEN = ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
+           11559732032986387107991004021392285783925812861821192530917403151452391805634),
+          (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+           4082367875863433681332203403145435568316851327593401208105741076214120093531))
+
+
+def _mont(x):
+    return int(x * (1 << 256) % Q_MOD).to_bytes(32, "little")
+
+
+def g1_generator_record():
+    return _mont(G1_GEN[0]) + _mont(G1_GEN[1])
+
+
+def g2_generator_record():
+    return _mont(G2_GEN[0][0]) + _mont(G2_GEN[0][1]) + _mont(G2_GEN[1][0]) + _mont(G2_GEN[1][1])
+
+
+# section seeds: point i of a set is (seed + i) * G
+SEEDS = {"A": 0x1000_0001, "B1": 0x2000_0003, "B2": 0x3000_0005, "C": 0x4000_0007, "H": 0x5000_0009, "VK": 0x77}
+
+
+def synth_points(dev, n, seed, g2=False):
+    """n zkey-format records (seed + i) * G, computed on the GPU"""
+    import ctypes as C
+    out = (C.c_char * (n * (128 if g2 else 64)))()
+    gen = g2_generator_record() if g2 else g1_generator_record()
+    rc = dev._L.ug_synth_points(dev._h, 1 if g2 else 0, gen, seed, n, out)
+    if rc != 0:
+        raise RuntimeError(dev._L.ug_last_error().decode())
+    return out
+
+
+def scalars(n, mix, seed):
+    """n plain 32-byte scalars < r as a uint64 array [n, 4]; mix 'U' or 'C'"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    v = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    # top limb uniform below r's top limb: uniform over [0, r) up to a 2^-62 sliver, always canonical
+    v[:, 3] = rng.integers(0, R_MOD >> 192, size=n, dtype=np.uint64)
+    if mix == "C":
+        kind = rng.random(n)
+        small = kind < 0.4
+        v[small, 1:] = 0
+        v[small, 0] = rng.integers(0, 2, size=int(small.sum()), dtype=np.uint64)
+        mid = (kind >= 0.4) & (kind < 0.6)
+        v[mid, 1:] = 0
+        v[mid, 0] &= np.uint64(0xFFFFFFFF)
+    elif mix != "U":
+        raise ValueError("mix must be 'U' or 'C'")
+    return v
+
+
+def coefficients(domain, nvars, seed):
+    """4 * domain packed 44-byte records: rows c = 0..domain-1, two entries in A (m=0) and two in B (m=1)"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    k = 4 * domain
+    rec = np.zeros(k, dtype=np.dtype([("m", "<u4"), ("c", "<u4"), ("s", "<u4"), ("v", "<u8", (4,))], align=False))
+    assert rec.dtype.itemsize == 44
+    rows = np.repeat(np.arange(domain, dtype=np.uint32), 4)
+    rec["m"] = np.tile(np.array([0, 0, 1, 1], dtype=np.uint32), domain)
+    rec["c"] = rows
+    rec["s"] = rng.integers(0, nvars, size=k, dtype=np.uint32)
+    val = rng.integers(0, 1 << 63, size=(k, 4), dtype=np.uint64)
+    val[:, 3] &= np.uint64((1 << 60) - 1)
+    rec["v"] = val
+    perm = rng.permutation(k)                       # the reference assumes no order (it takes locks)
+    return rec[perm]
+
+
+def _section(sid, payload):
+    return struct.pack("<IQ", sid, len(payload)) + payload
+
+
+def build_circuit(dev, log_domain, mix="U", seed=0x5EED0000, n_public=1, g1_only=False):
+    """Returns (zkey_bytes, wtns_bytes, info). Sections are laid out as snarkjs does (1..10)."""
+    domain = 1 << log_domain
+    nvars = domain - 1
+    n_c = nvars - n_public - 1
+    r_le = R_MOD.to_bytes(32, "little")
+    q_le = Q_MOD.to_bytes(32, "little")
+    vk_g1 = bytes(synth_points(dev, 3, SEEDS["VK"]))                    # alpha1, beta1, delta1
+    vk_g2 = bytes(synth_points(dev, 3, SEEDS["VK"], g2=True))           # beta2, gamma2, delta2
+    header = struct.pack("<I", 32) + q_le + struct.pack("<I", 32) + r_le + struct.pack("<III", nvars, n_public, domain)
+    header += vk_g1[0:64] + vk_g1[64:128] + vk_g2[0:128] + vk_g2[128:256] + vk_g1[128:192] + vk_g2[256:384]
+    coefs = coefficients(domain, nvars, seed + 1)
+    parts = [b"zkey", struct.pack("<II", 1, 10), _section(1, struct.pack("<I", 1)), _section(2, header),
+             _section(3, bytes(64 * (n_public + 1)))]
+    parts.append(struct.pack("<IQ", 4, 4 + coefs.nbytes) + struct.pack("<I", len(coefs)))
+    parts.append(coefs.tobytes())
+    a = synth_points(dev, nvars, SEEDS["A"])
+    parts.append(struct.pack("<IQ", 5, len(a))); parts.append(a)
+    if g1_only:
+        # config 2 of BASELINE.json (G1 MSM + NTT only): B1, B2, C are all-infinity sets of the right size
+        b1 = bytes(64 * nvars); b2 = bytes(128 * nvars); c = bytes(64 * n_c)
+    else:
+        b1 = synth_points(dev, nvars, SEEDS["B1"])
+        b2 = synth_points(dev, nvars, SEEDS["B2"], g2=True)
+        c = synth_points(dev, n_c, SEEDS["C"])
+    parts.append(struct.pack("<IQ", 6, len(b1))); parts.append(b1)
+    parts.append(struct.pack("<IQ", 7, len(b2))); parts.append(b2)
+    parts.append(struct.pack("<IQ", 8, len(c))); parts.append(c)
+    h = synth_points(dev, domain, SEEDS["H"])
+    parts.append(struct.pack("<IQ", 9, len(h))); parts.append(h)
+    parts.append(_section(10, b""))
+    zkey = b"".join(bytes(p) if not isinstance(p, (bytes, bytearray)) else p for p in parts)
+    w = scalars(nvars, mix, seed + 2)
+    w[0] = (1, 0, 0, 0)
+    wtns = b"wtns" + struct.pack("<II", 2, 2) + _section(1, struct.pack("<I", 32) + r_le + struct.pack("<I", nvars))
+    wtns += struct.pack("<IQ", 2, w.nbytes) + w.tobytes()
+    info = dict(domainSize=domain, nVars=nvars, nPublic=n_public, nCoefs=len(coefs), mix=mix, seed=seed, g1_only=g1_only)
+    return zkey, wtns, info
