@@ -37,24 +37,30 @@ struct MsmGeometry {
     u64 total_buckets() const { return (u64)windows * buckets; }
 };
 
-struct HeavyTask { u32 bucket, start, len, slot; };          // a slice of a heavy bucket's entries
-struct HeavyBucket { u32 bucket, first_slot, nslots, pad; };  // the task partials that make up one bucket
+struct HeavyBucket { u32 bucket, first_seg, last_seg, pad; };  // a bucket cut into many segment pieces
 
 // Signed-digit decomposition of n scalars, grouped by (window, bucket): shared by every base set that
 // is multiplied by the same scalars (A, B1, B2 and C all use the witness, src/groth16.cpp:55-64).
 struct MsmSchedule {
     MsmGeometry geo;
+    const u32* keys = nullptr;    // sorted bucket ids (sentinel = total_buckets at the end)
     const u32* vals = nullptr;    // sorted entries: scalar index | sign << 31
+    const u32* tkeys = nullptr;   // lane-transposed copies of keys / vals (see msm.hip: transposed_index)
+    const u32* tvals = nullptr;
     u32* bucket_start = nullptr;  // per bucket: first entry
     u32* bucket_count = nullptr;  // per bucket: number of entries
-    // buckets with more than HEAVY entries, cut into workgroup-sized tasks
-    u32 n_tasks = 0, n_heavy = 0;
-    HeavyTask* heavy_tasks_dev = nullptr;
-    HeavyBucket* heavy_buckets_dev = nullptr;
+    u32 n_valid = 0;              // entries with a non-zero digit
+    int log_seg = 0;              // entries per lane of the segmented accumulation = 2^log_seg
+    u32 n_heavy = 0;              // buckets cut into more than FIX_MAX pieces
+    u32* heavy_list = nullptr;    // device: HeavyBucket[heavy_cap]
+    u32 heavy_cap = 0;
+    u32* medium_list = nullptr;   // device: HeavyBucket[heavy_cap] for buckets of FIX_MAX < pieces <= MEDIUM_MAX
+    u32 n_medium = 0;
+    u32* heavy_offsets = nullptr; // device: first task of each heavy bucket (n_heavy + 1 entries)
+    u32 n_heavy_tasks = 0;
+    u32* meta = nullptr;          // device: [n_heavy, n_valid, n_heavy_tasks, n_medium]
     // workspace
     u32 *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
-    u32* heavy_list = nullptr;    // device: [count, (bucket, start, count) * heavy_cap]
-    u32 heavy_cap = 0;
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     u64 capacity_n = 0; u64 capacity_buckets = 0;
     void reserve(const MsmGeometry& g);
@@ -67,9 +73,10 @@ struct MsmWorkspace {
     u32* bucket_pts = nullptr;   // total_buckets XYZZ records
     u32* chunk_pts = nullptr;    // reduction scratch
     u32* chunk_pts2 = nullptr;
-    u32* task_pts = nullptr;     // heavy-task partial sums
-    size_t bucket_bytes = 0, chunk_bytes = 0, task_bytes = 0;
-    void reserve(const MsmGeometry& g, bool g2, u32 n_tasks);
+    u32* slot_pts = nullptr;     // two partial sums per segment of the accumulation
+    u32* task_pts = nullptr;     // partial sums of the heavy-bucket tasks
+    size_t bucket_bytes = 0, chunk_bytes = 0, slot_bytes = 0, task_bytes = 0;
+    void reserve(const MsmGeometry& g, bool g2, u64 n_segments, u32 n_heavy_tasks);
     void release();
     ~MsmWorkspace() { release(); }
 };

@@ -28,8 +28,10 @@ namespace ug {
 
 namespace {
 
-constexpr u32 HEAVY = 256;            // buckets above this many entries take the block-parallel path
-constexpr u32 TASK_ENTRIES = 8192;    // entries per heavy task (one workgroup)
+constexpr int LOG_SEG = 5;            // entries per lane of the segmented accumulation: 2^5
+constexpr u32 FIX_MAX = 32;           // buckets cut into more pieces than this take the block-parallel path
+constexpr u32 MEDIUM_MAX = 4096;      // up to this many pieces: one wave per bucket; above: two-level heavy path
+constexpr u32 HEAVY_TASK = 1024;      // pieces summed by one workgroup of the heavy path
 constexpr int CHUNK = 32;             // buckets per running-sum chunk
 
 // ---- curve configurations -------------------------------------------------------------------------
@@ -46,6 +48,16 @@ struct G1Cfg {
         x = unpack256<FqParams>(w); y = unpack256<FqParams>(w + 8);
         return true;
     }
+    // raw record words already in registers -> coordinates; false for the all-zero record (infinity)
+    static __device__ __forceinline__ bool decode_affine(const u32* w, F& x, F& y) {
+        u32 o = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) o |= w[i];
+        if (o == 0) return false;
+        x = unpack256<FqParams>(w); y = unpack256<FqParams>(w + 8);
+        return true;
+    }
+    static __device__ __forceinline__ void load_raw(u32* w, const u32* p) { load8(w, p); load8(w + 8, p + 8); }
     static __host__ __device__ __forceinline__ void store_affine_mont256(u32* o, const F& x, const F& y) {
         to_mont256(o, x); to_mont256(o + 8, y);
     }
@@ -82,6 +94,18 @@ struct G2Cfg {
         x.a = unpack256<FqParams>(w); x.b = unpack256<FqParams>(w + 8);
         y.a = unpack256<FqParams>(w + 16); y.b = unpack256<FqParams>(w + 24);
         return true;
+    }
+    static __device__ __forceinline__ bool decode_affine(const u32* w, F& x, F& y) {
+        u32 o = 0;
+#pragma unroll
+        for (int i = 0; i < 32; i++) o |= w[i];
+        if (o == 0) return false;
+        x.a = unpack256<FqParams>(w); x.b = unpack256<FqParams>(w + 8);
+        y.a = unpack256<FqParams>(w + 16); y.b = unpack256<FqParams>(w + 24);
+        return true;
+    }
+    static __device__ __forceinline__ void load_raw(u32* w, const u32* p) {
+        load8(w, p); load8(w + 8, p + 8); load8(w + 16, p + 16); load8(w + 24, p + 24);
     }
     static __host__ __device__ __forceinline__ void store_affine_mont256(u32* o, const F& x, const F& y) {
         to_mont256(o, x.a); to_mont256(o + 8, x.b); to_mont256(o + 16, y.a); to_mont256(o + 24, y.b);
@@ -153,54 +177,134 @@ __global__ void msm_digits_kernel(const u32* scalars, u64 n, int c, int windows,
 }
 
 // ---- 3. bucket bounds -----------------------------------------------------------------------------------
-__global__ void bucket_bounds_kernel(const u32* keys, u64 total, u32 sentinel, u32* start, u32* count) {
+// meta[0] = number of heavy buckets, meta[1] = number of non-sentinel entries
+__global__ void bucket_bounds_kernel(const u32* keys, u64 total, u32 sentinel, u32* start, u32* count, u32* meta) {
     u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= total) return;
     u32 k = keys[p];
     if (k == sentinel) return;
     if (p == 0 || keys[p - 1] != k) start[k] = (u32)p;
     if (p + 1 == total || keys[p + 1] != k) count[k] = (u32)p + 1;      // end for now
+    if (p + 1 == total || keys[p + 1] == sentinel) meta[1] = (u32)p + 1;
 }
-__global__ void bucket_counts_kernel(u32* start, u32* count, u32 nb, u32* heavy_list, u32 heavy_cap) {
+// buckets whose entries span more than FIX_MAX lanes of the segmented accumulation are listed as heavy
+__global__ void bucket_counts_kernel(u32* start, u32* count, u32 nb, int log_seg, u32* meta, u32* heavy_list, u32* medium_list,
+                                     u32 heavy_cap) {
     u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     u32 e = count[b];
     u32 c = e ? e - start[b] : 0;
     count[b] = c;
-    if (c > HEAVY) {
-        u32 pos = atomicAdd(&heavy_list[0], 1u);
-        if (pos < heavy_cap) { heavy_list[1 + 3 * pos] = b; heavy_list[2 + 3 * pos] = start[b]; heavy_list[3 + 3 * pos] = c; }
+    if (!c) return;
+    u32 first = start[b] >> log_seg, last = (start[b] + c - 1) >> log_seg;
+    u32 pieces = last - first + 1;
+    if (pieces > MEDIUM_MAX) {
+        u32 pos = atomicAdd(&meta[0], 1u);
+        if (pos < heavy_cap) { heavy_list[4 * pos] = b; heavy_list[4 * pos + 1] = first; heavy_list[4 * pos + 2] = last; heavy_list[4 * pos + 3] = 0; }
+    } else if (pieces > FIX_MAX) {
+        u32 pos = atomicAdd(&meta[3], 1u);
+        if (pos < heavy_cap) { medium_list[4 * pos] = b; medium_list[4 * pos + 1] = first; medium_list[4 * pos + 2] = last; medium_list[4 * pos + 3] = 0; }
     }
 }
 
 // ---- 4. bucket accumulation -----------------------------------------------------------------------------
-template <class Cfg>
-__device__ __forceinline__ void accumulate_entry(XYZZ<typename Cfg::F>& acc, const u32* bases, u64 n_bases,
-                                                 int64_t delta, u32 v) {
-    typedef typename Cfg::F F;
-    int64_t sidx = (int64_t)(v & 0x7fffffffu) + delta;      // scalar index -> index into this base slice
-    if (sidx < 0 || (u64)sidx >= n_bases) return;
-    u64 idx = (u64)sidx;
-    F x, y;
-    if (!Cfg::load_affine(bases + idx * Cfg::AFF_WORDS, x, y)) return;
-    if (v >> 31) y = neg<1>(y);
-    acc = xyzz_madd(acc, x, y);
+// Balanced, segmented form: the sorted entry list is cut into equal segments of 2^log_seg entries, one
+// lane per segment, so every lane of a wave performs the same number of mixed additions whatever the
+// bucket sizes are. A lane walks its segment run by run (a run = consecutive entries of one bucket):
+//   - a run that begins and ends inside the segment is a whole bucket: written straight to bucket_pts;
+//   - a run cut by the segment's start goes to slot 2t, a run cut only by its end to slot 2t + 1.
+// bucket_fixup_kernel then adds the pieces of every bucket that straddles segments (normally two).
+// Entries are stored "lane-transposed": the 2^log_seg entries of the 64 segments handled by one wave are
+// interleaved so that step k of all 64 lanes reads 64 consecutive words (one fully coalesced 256-byte access).
+__host__ __device__ __forceinline__ u64 transposed_index(u64 seg, u32 k, int log_seg) {
+    return ((seg >> 6) << (log_seg + 6)) + ((u64)k << 6) + (seg & 63);
+}
+__global__ void transpose_entries_kernel(const u32* __restrict__ keys, const u32* __restrict__ vals, u64 n_padded, u32 n_valid,
+                                         u32 sentinel, int log_seg, u32* __restrict__ tkeys, u32* __restrict__ tvals) {
+    u64 o = (u64)blockIdx.x * blockDim.x + threadIdx.x;          // output position (coalesced stores)
+    if (o >= n_padded) return;
+    u64 tile = o >> (log_seg + 6);
+    u32 k = (u32)(o >> 6) & ((1u << log_seg) - 1), lane = (u32)o & 63;
+    u64 src = (((tile << 6) + lane) << log_seg) + k;
+    bool in = src < n_valid;
+    tkeys[o] = in ? keys[src] : sentinel;
+    tvals[o] = in ? vals[src] : 0u;
 }
 
 template <class Cfg>
-__global__ __launch_bounds__(256) void bucket_accumulate_kernel(const u32* bases, u64 n_bases, int64_t delta,
-                                                                const u32* vals, const u32* start, const u32* count,
-                                                                u32 nb, u32* out) {
+__global__ __launch_bounds__(256) void segment_accumulate_kernel(const u32* __restrict__ bases, u64 n_bases, int64_t delta,
+                                                                 const u32* __restrict__ keys, const u32* __restrict__ tkeys,
+                                                                 const u32* __restrict__ tvals, u32 n_valid, int log_seg,
+                                                                 u32* __restrict__ bucket_pts, u32* __restrict__ slot_pts) {
+    typedef typename Cfg::F F;
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u64 lo = (u64)t << log_seg;
+    if (lo >= n_valid) return;
+    u64 hi = lo + ((u64)1 << log_seg);
+    if (hi > n_valid) hi = n_valid;
+    const u32 cnt = (u32)(hi - lo);
+    const u64 tbase = transposed_index(t, 0, log_seg);
+    u32 cur = tkeys[tbase];
+    bool first_run = true;
+    const bool start_open = lo > 0 && keys[lo - 1] == cur;
+    XYZZ<F> acc = xyzz_inf<F>();
+    // software pipeline: the raw record of entry k + 1 is in flight while entry k is added
+    u32 raw[Cfg::AFF_WORDS];
+    u32 nkey = cur, nval = tvals[tbase];
+    int64_t nidx = (int64_t)(nval & 0x7fffffffu) + delta;
+    bool nin = nidx >= 0 && (u64)nidx < n_bases;
+    if (nin) Cfg::load_raw(raw, bases + (u64)nidx * Cfg::AFF_WORDS);
+    for (u32 k = 0; k < cnt; k++) {
+        F x, y;
+        bool valid = nin && Cfg::decode_affine(raw, x, y);
+        if (valid && (nval >> 31)) y = neg<1>(y);
+        u32 key = nkey;
+        if (k + 1 < cnt) {
+            nkey = tkeys[tbase + ((u64)(k + 1) << 6)];
+            nval = tvals[tbase + ((u64)(k + 1) << 6)];
+            nidx = (int64_t)(nval & 0x7fffffffu) + delta;
+            nin = nidx >= 0 && (u64)nidx < n_bases;
+            if (nin) Cfg::load_raw(raw, bases + (u64)nidx * Cfg::AFF_WORDS);
+        }
+        if (key != cur) {                          // the previous run ended inside the segment
+            u32* dst = (first_run && start_open) ? slot_pts + (size_t)(2 * t) * Cfg::PT_WORDS : bucket_pts + (size_t)cur * Cfg::PT_WORDS;
+            Cfg::to_words(dst, acc, 1);
+            acc = xyzz_inf<F>();
+            cur = key;
+            first_run = false;
+        }
+        if (valid) acc = xyzz_madd(acc, x, y);
+    }
+    const bool end_open = hi < n_valid && keys[hi] == cur;
+    u32* dst;
+    if (first_run && start_open) dst = slot_pts + (size_t)(2 * t) * Cfg::PT_WORDS;
+    else if (end_open) dst = slot_pts + (size_t)(2 * t + 1) * Cfg::PT_WORDS;
+    else dst = bucket_pts + (size_t)cur * Cfg::PT_WORDS;
+    Cfg::to_words(dst, acc, 1);
+}
+
+// piece k of a bucket whose entries start in segment `first`: k = 0 is the end-cut run of `first`,
+// k >= 1 the start-cut run of segment first + k
+template <class Cfg>
+__device__ __forceinline__ XYZZ<typename Cfg::F> load_piece(const u32* slot_pts, u32 first, u32 k) {
+    size_t slot = k ? (size_t)2 * (first + k) : (size_t)2 * first + 1;
+    return Cfg::from_words(slot_pts + slot * Cfg::PT_WORDS, 1);
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(128) void bucket_fixup_kernel(const u32* start, const u32* count, u32 nb, int log_seg,
+                                                           const u32* slot_pts, u32* bucket_pts) {
     u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     typedef typename Cfg::F F;
-    XYZZ<F> acc = xyzz_inf<F>();
-    u32 cnt = count[b];
-    if (cnt && cnt <= HEAVY) {
-        u32 s = start[b];
-        for (u32 k = 0; k < cnt; k++) accumulate_entry<Cfg>(acc, bases, n_bases, delta, vals[s + k]);
-    }
-    Cfg::to_words(out + (size_t)b * Cfg::PT_WORDS, acc, 1);
+    u32 c = count[b];
+    if (!c) { Cfg::to_words(bucket_pts + (size_t)b * Cfg::PT_WORDS, xyzz_inf<F>(), 1); return; }
+    u32 first = start[b] >> log_seg, last = (start[b] + c - 1) >> log_seg;
+    u32 pieces = last - first + 1;
+    if (pieces == 1 || pieces > FIX_MAX) return;       // whole bucket already written / medium or heavy path
+    XYZZ<F> acc = load_piece<Cfg>(slot_pts, first, 0);
+    for (u32 k = 1; k < pieces; k++) acc = xyzz_add(acc, load_piece<Cfg>(slot_pts, first, k));
+    Cfg::to_words(bucket_pts + (size_t)b * Cfg::PT_WORDS, acc, 1);
 }
 
 // workgroup tree reduction of one XYZZ per thread through LDS ([word][thread] planes); result in thread 0
@@ -216,28 +320,83 @@ __device__ __forceinline__ XYZZ<typename Cfg::F> block_reduce(XYZZ<typename Cfg:
     return acc;
 }
 
+// Medium buckets (FIX_MAX < pieces <= MEDIUM_MAX; the short top window of uniform scalars makes thousands of
+// them): one wave per bucket, lanes stride over the pieces, then a 6-step cross-lane butterfly of full additions.
 template <class Cfg>
-__global__ __launch_bounds__(Cfg::BLOCK) void heavy_partial_kernel(const u32* bases, u64 n_bases, int64_t delta,
-                                                                   const u32* vals, const HeavyTask* tasks, u32* partial) {
+__global__ __launch_bounds__(256) void medium_bucket_kernel(const HeavyBucket* mb, u32 n_medium, const u32* slot_pts, u32* bucket_pts) {
+    typedef typename Cfg::F F;
+    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= n_medium) return;
+    HeavyBucket h = mb[wave];
+    u32 pieces = h.last_seg - h.first_seg + 1;
+    XYZZ<F> acc = xyzz_inf<F>();
+    for (u32 k = lane; k < pieces; k += 64) acc = xyzz_add(acc, load_piece<Cfg>(slot_pts, h.first_seg, k));
+    u32 w[Cfg::PT_WORDS];
+    for (int off = 32; off > 0; off >>= 1) {
+        Cfg::to_words(w, acc, 1);
+#pragma unroll
+        for (int i = 0; i < Cfg::PT_WORDS; i++) w[i] = __shfl_xor(w[i], off, 64);
+        acc = xyzz_add(acc, Cfg::from_words(w, 1));
+    }
+    if (lane == 0) Cfg::to_words(bucket_pts + (size_t)h.bucket * Cfg::PT_WORDS, acc, 1);
+}
+
+// Heavy buckets (a 0/1-heavy witness, or the short top window of uniform scalars, puts up to millions of
+// entries in one bucket) are reduced in two levels so that the whole chip works on them:
+//   heavy_plan      one workgroup: tasks per heavy bucket = ceil(pieces / HEAVY_TASK), exclusive scan -> offsets
+//   heavy_partial   one workgroup per task: sums up to HEAVY_TASK pieces (lanes stride, then LDS tree)
+//   heavy_final     one workgroup per heavy bucket: sums its task partials, writes the bucket
+__global__ __launch_bounds__(1024) void heavy_plan_kernel(const HeavyBucket* hb, u32 n_heavy_cap, u32* meta, u32* offsets) {
+    __shared__ u32 part[1024];
+    const u32 n = meta[0] < n_heavy_cap ? meta[0] : n_heavy_cap;
+    const u32 per = (n + 1023) / 1024;
+    u32 lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    u32 sum = 0;
+    for (u32 i = lo; i < hi; i++) sum += (hb[i].last_seg - hb[i].first_seg + 1 + HEAVY_TASK - 1) / HEAVY_TASK;
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 run = 0;
+        for (int i = 0; i < 1024; i++) { u32 v = part[i]; part[i] = run; run += v; }
+        meta[2] = run;
+        offsets[n] = run;
+    }
+    __syncthreads();
+    u32 run = part[threadIdx.x];
+    for (u32 i = lo; i < hi; i++) {
+        offsets[i] = run;
+        run += (hb[i].last_seg - hb[i].first_seg + 1 + HEAVY_TASK - 1) / HEAVY_TASK;
+    }
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::BLOCK) void heavy_partial_kernel(const HeavyBucket* hb, const u32* offsets, u32 n_heavy,
+                                                                   const u32* slot_pts, u32* task_pts) {
     __shared__ u32 lds[Cfg::PT_WORDS * Cfg::BLOCK / 2];
     typedef typename Cfg::F F;
-    HeavyTask t = tasks[blockIdx.x];
+    const u32 task = blockIdx.x;
+    u32 lo = 0, hi = n_heavy;                          // last heavy bucket whose first task is <= task
+    while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (offsets[mid] <= task) lo = mid; else hi = mid; }
+    HeavyBucket h = hb[lo];
+    u32 pieces = h.last_seg - h.first_seg + 1;
+    u32 p0 = (task - offsets[lo]) * HEAVY_TASK, p1 = p0 + HEAVY_TASK < pieces ? p0 + HEAVY_TASK : pieces;
     XYZZ<F> acc = xyzz_inf<F>();
-    for (u32 k = threadIdx.x; k < t.len; k += Cfg::BLOCK) accumulate_entry<Cfg>(acc, bases, n_bases, delta, vals[t.start + k]);
+    for (u32 k = p0 + threadIdx.x; k < p1; k += Cfg::BLOCK) acc = xyzz_add(acc, load_piece<Cfg>(slot_pts, h.first_seg, k));
     acc = block_reduce<Cfg>(acc, lds);
-    if (threadIdx.x == 0) Cfg::to_words(partial + (size_t)t.slot * Cfg::PT_WORDS, acc, 1);
+    if (threadIdx.x == 0) Cfg::to_words(task_pts + (size_t)task * Cfg::PT_WORDS, acc, 1);
 }
-// one workgroup per heavy bucket: sum its task partials, write the bucket
+
 template <class Cfg>
-__global__ __launch_bounds__(Cfg::BLOCK) void heavy_final_kernel(const HeavyBucket* hb, const u32* partial, u32* buckets) {
+__global__ __launch_bounds__(Cfg::BLOCK) void heavy_final_kernel(const HeavyBucket* hb, const u32* offsets, const u32* task_pts,
+                                                                 u32* bucket_pts) {
     __shared__ u32 lds[Cfg::PT_WORDS * Cfg::BLOCK / 2];
     typedef typename Cfg::F F;
     HeavyBucket h = hb[blockIdx.x];
+    u32 t0 = offsets[blockIdx.x], t1 = offsets[blockIdx.x + 1];
     XYZZ<F> acc = xyzz_inf<F>();
-    for (u32 k = threadIdx.x; k < h.nslots; k += Cfg::BLOCK)
-        acc = xyzz_add(acc, Cfg::from_words(partial + (size_t)(h.first_slot + k) * Cfg::PT_WORDS, 1));
+    for (u32 k = t0 + threadIdx.x; k < t1; k += Cfg::BLOCK) acc = xyzz_add(acc, Cfg::from_words(task_pts + (size_t)k * Cfg::PT_WORDS, 1));
     acc = block_reduce<Cfg>(acc, lds);
-    if (threadIdx.x == 0) Cfg::to_words(buckets + (size_t)h.bucket * Cfg::PT_WORDS, acc, 1);
+    if (threadIdx.x == 0) Cfg::to_words(bucket_pts + (size_t)h.bucket * Cfg::PT_WORDS, acc, 1);
 }
 
 // ---- 5. bucket reduction --------------------------------------------------------------------------------
@@ -333,8 +492,9 @@ MsmGeometry MsmGeometry::choose(u64 n, int force_c) {
 void MsmSchedule::reserve(const MsmGeometry& g) {
     u64 total = g.n * g.windows;
     if (total > capacity_n) {
-        dev_alloc(keys_a, total * 4); dev_alloc(keys_b, total * 4);
-        dev_alloc(vals_a, total * 4); dev_alloc(vals_b, total * 4);
+        u64 padded = total + ((u64)64 << LOG_SEG);          // room for the lane-transposed copy's last tile
+        dev_alloc(keys_a, padded * 4); dev_alloc(keys_b, padded * 4);
+        dev_alloc(vals_a, padded * 4); dev_alloc(vals_b, padded * 4);
         size_t need = 0;
         hipcub::DoubleBuffer<u32> dk(keys_a, keys_b), dv(vals_a, vals_b);
         UG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, dk, dv, (int)total, 0, 32));
@@ -346,14 +506,18 @@ void MsmSchedule::reserve(const MsmGeometry& g) {
         dev_alloc(bucket_count, g.total_buckets() * 4);
         capacity_buckets = g.total_buckets();
     }
-    u64 hcap = total / HEAVY + 2;                       // no more buckets than this can exceed HEAVY entries
-    if (hcap > heavy_cap) { dev_alloc(heavy_list, (3 * hcap + 1) * 4); heavy_cap = (u32)hcap; }
+    u64 hcap = (total >> LOG_SEG) / (FIX_MAX - 1) + 2;   // a heavy bucket covers at least FIX_MAX - 1 whole segments
+    if (hcap > heavy_cap) {
+        dev_alloc(heavy_list, 4 * hcap * 4); dev_alloc(medium_list, 4 * hcap * 4); dev_alloc(heavy_offsets, (hcap + 1) * 4);
+        heavy_cap = (u32)hcap;
+    }
+    if (!meta) dev_alloc(meta, 16);
 }
 
 void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_t stream) {
     geo = g;
     reserve(g);
-    n_tasks = 0; n_heavy = 0;
+    n_heavy = 0; n_medium = 0; n_heavy_tasks = 0; n_valid = 0; log_seg = LOG_SEG;
     if (g.n == 0) return;
     u64 total = g.n * g.windows;
     if (total >= ((u64)1 << 31)) throw std::invalid_argument("msm: n * windows exceeds 2^31 entries");
@@ -367,61 +531,62 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
     hipcub::DoubleBuffer<u32> dk(keys_a, keys_b), dv(vals_a, vals_b);
     size_t tmp = sort_tmp_bytes;
     UG_HIP(hipcub::DeviceRadixSort::SortPairs(sort_tmp, tmp, dk, dv, (int)total, 0, end_bit, stream));
-    const u32* sorted_keys = dk.Current();
+    keys = dk.Current();
     vals = dv.Current();
     UG_HIP(hipMemsetAsync(bucket_start, 0, (size_t)nb * 4, stream));
     UG_HIP(hipMemsetAsync(bucket_count, 0, (size_t)nb * 4, stream));
-    UG_HIP(hipMemsetAsync(heavy_list, 0, 4, stream));
+    UG_HIP(hipMemsetAsync(meta, 0, 16, stream));
     hipLaunchKernelGGL(bucket_bounds_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                       sorted_keys, total, sentinel, bucket_start, bucket_count);
+                       keys, total, sentinel, bucket_start, bucket_count, meta);
     UG_KERNEL_CHECK();
-    hipLaunchKernelGGL(bucket_counts_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, bucket_start, bucket_count, nb, heavy_list, heavy_cap);
+    hipLaunchKernelGGL(bucket_counts_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, bucket_start, bucket_count, nb,
+                       log_seg, meta, heavy_list, medium_list, heavy_cap);
     UG_KERNEL_CHECK();
-    // heavy buckets -> tasks (host round trip; the list is tiny)
-    u32 nh = 0;
-    UG_HIP(hipMemcpyAsync(&nh, heavy_list, 4, hipMemcpyDeviceToHost, stream));
+    hipLaunchKernelGGL(heavy_plan_kernel, dim3(1), dim3(1024), 0, stream, (const HeavyBucket*)heavy_list, heavy_cap, meta, heavy_offsets);
+    UG_KERNEL_CHECK();
+    u32 m[4] = {0, 0, 0, 0};
+    UG_HIP(hipMemcpyAsync(m, meta, 16, hipMemcpyDeviceToHost, stream));
     UG_HIP(hipStreamSynchronize(stream));
-    if (nh > heavy_cap) throw std::runtime_error("msm: heavy-bucket list overflow");
-    if (nh) {
-        std::vector<u32> trip((size_t)nh * 3);
-        UG_HIP(hipMemcpy(trip.data(), heavy_list + 1, trip.size() * 4, hipMemcpyDeviceToHost));
-        std::vector<HeavyTask> tasks;
-        std::vector<HeavyBucket> hbs;
-        u32 slot = 0;
-        for (u32 i = 0; i < nh; i++) {
-            u32 id = trip[3 * i], st = trip[3 * i + 1], ct = trip[3 * i + 2], first = slot;
-            for (u32 off = 0; off < ct; off += TASK_ENTRIES) tasks.push_back({id, st + off, std::min(TASK_ENTRIES, ct - off), slot++});
-            hbs.push_back({id, first, slot - first, 0});
-        }
-        n_tasks = slot; n_heavy = nh;
-        dev_alloc(heavy_tasks_dev, (size_t)n_tasks * sizeof(HeavyTask));
-        dev_alloc(heavy_buckets_dev, (size_t)n_heavy * sizeof(HeavyBucket));
-        UG_HIP(hipMemcpy(heavy_tasks_dev, tasks.data(), (size_t)n_tasks * sizeof(HeavyTask), hipMemcpyHostToDevice));
-        UG_HIP(hipMemcpy(heavy_buckets_dev, hbs.data(), (size_t)n_heavy * sizeof(HeavyBucket), hipMemcpyHostToDevice));
+    if (m[0] > heavy_cap || m[3] > heavy_cap) throw std::runtime_error("msm: heavy-bucket list overflow");
+    n_medium = m[3];
+    n_heavy = m[0];
+    n_valid = m[1];
+    n_heavy_tasks = m[2];
+    // lane-transposed copy of the valid entries into the sort's spare buffers
+    u64 tile = (u64)64 << log_seg;
+    u64 n_padded = ((u64)n_valid + tile - 1) / tile * tile;
+    u32* tk = (keys == keys_a) ? keys_b : keys_a;
+    u32* tv = (vals == vals_a) ? vals_b : vals_a;
+    if (n_padded) {
+        hipLaunchKernelGGL(transpose_entries_kernel, dim3((unsigned)((n_padded + 255) / 256)), dim3(256), 0, stream,
+                           keys, vals, n_padded, n_valid, sentinel, log_seg, tk, tv);
+        UG_KERNEL_CHECK();
     }
+    tkeys = tk; tvals = tv;
 }
 
 void MsmSchedule::release() {
     dev_free(keys_a); dev_free(keys_b); dev_free(vals_a); dev_free(vals_b); dev_free(sort_tmp);
-    dev_free(bucket_start); dev_free(bucket_count); dev_free(heavy_list);
-    dev_free(heavy_tasks_dev); dev_free(heavy_buckets_dev);
-    capacity_n = capacity_buckets = 0; sort_tmp_bytes = 0; vals = nullptr; heavy_cap = 0;
+    dev_free(bucket_start); dev_free(bucket_count); dev_free(heavy_list); dev_free(medium_list); dev_free(heavy_offsets); dev_free(meta);
+    capacity_n = capacity_buckets = 0; sort_tmp_bytes = 0; vals = nullptr; keys = nullptr; heavy_cap = 0;
 }
 
 // ---- workspace ------------------------------------------------------------------------------------------------
-void MsmWorkspace::reserve(const MsmGeometry& g, bool g2, u32 n_tasks) {
+void MsmWorkspace::reserve(const MsmGeometry& g, bool g2, u64 n_segments, u32 n_heavy_tasks) {
     size_t ptw = g2 ? G2Cfg::PT_WORDS : G1Cfg::PT_WORDS;
     size_t need = (size_t)g.total_buckets() * ptw * 4;
     if (need > bucket_bytes) { dev_alloc(bucket_pts, need); bucket_bytes = need; }
     int chunk = g.buckets < (u32)CHUNK ? (int)g.buckets : CHUNK;
     size_t cneed = (size_t)g.windows * (g.buckets / chunk) * ptw * 4;
     if (cneed > chunk_bytes) { dev_alloc(chunk_pts, cneed); dev_alloc(chunk_pts2, cneed); chunk_bytes = cneed; }
-    size_t tneed = (size_t)n_tasks * ptw * 4;
+    size_t sneed = (size_t)n_segments * 2 * ptw * 4;
+    if (sneed > slot_bytes) { dev_alloc(slot_pts, sneed); slot_bytes = sneed; }
+    size_t tneed = (size_t)n_heavy_tasks * ptw * 4;
     if (tneed > task_bytes) { dev_alloc(task_pts, tneed); task_bytes = tneed; }
 }
 void MsmWorkspace::release() {
-    dev_free(bucket_pts); dev_free(chunk_pts); dev_free(chunk_pts2); dev_free(task_pts);
-    bucket_bytes = chunk_bytes = task_bytes = 0;
+    dev_free(bucket_pts); dev_free(chunk_pts); dev_free(chunk_pts2); dev_free(slot_pts); dev_free(task_pts);
+    bucket_bytes = chunk_bytes = slot_bytes = task_bytes = 0;
 }
 
 // ---- driver -------------------------------------------------------------------------------------------------------
@@ -432,19 +597,30 @@ XYZZ<typename Cfg::F> msm_run(const MsmSchedule& s, MsmWorkspace& ws, const u32*
     typedef typename Cfg::F F;
     const MsmGeometry& g = s.geo;
     if (g.n == 0 || n_bases == 0) return xyzz_inf<F>();
-    ws.reserve(g, Cfg::PT_WORDS == G2Cfg::PT_WORDS, s.n_tasks);
     u32 nb = (u32)g.total_buckets();
+    u64 nseg = ((u64)s.n_valid + ((u64)1 << s.log_seg) - 1) >> s.log_seg;
+    ws.reserve(g, Cfg::PT_WORDS == G2Cfg::PT_WORDS, nseg, s.n_heavy_tasks);
     if (stats) UG_HIP(hipEventRecord(stats->ev0, stream));
-    hipLaunchKernelGGL(bucket_accumulate_kernel<Cfg>, dim3((nb + 255) / 256), dim3(256), 0, stream,
-                       bases, n_bases, delta, s.vals, s.bucket_start, s.bucket_count, nb, ws.bucket_pts);
-    UG_KERNEL_CHECK();
+    if (nseg) {
+        hipLaunchKernelGGL(segment_accumulate_kernel<Cfg>, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, stream,
+                           bases, n_bases, delta, s.keys, s.tkeys, s.tvals, s.n_valid, s.log_seg, ws.bucket_pts, ws.slot_pts);
+        UG_KERNEL_CHECK();
+    }
     if (stats) UG_HIP(hipEventRecord(stats->ev1, stream));
-    if (s.n_tasks) {
-        hipLaunchKernelGGL(heavy_partial_kernel<Cfg>, dim3(s.n_tasks), dim3(Cfg::BLOCK), 0, stream,
-                           bases, n_bases, delta, s.vals, s.heavy_tasks_dev, ws.task_pts);
+    hipLaunchKernelGGL(bucket_fixup_kernel<Cfg>, dim3((nb + 127) / 128), dim3(128), 0, stream,
+                       s.bucket_start, s.bucket_count, nb, s.log_seg, ws.slot_pts, ws.bucket_pts);
+    UG_KERNEL_CHECK();
+    if (s.n_medium) {
+        hipLaunchKernelGGL(medium_bucket_kernel<Cfg>, dim3((s.n_medium + 3) / 4), dim3(256), 0, stream,
+                           (const HeavyBucket*)s.medium_list, s.n_medium, ws.slot_pts, ws.bucket_pts);
+        UG_KERNEL_CHECK();
+    }
+    if (s.n_heavy) {
+        hipLaunchKernelGGL(heavy_partial_kernel<Cfg>, dim3(s.n_heavy_tasks), dim3(Cfg::BLOCK), 0, stream,
+                           (const HeavyBucket*)s.heavy_list, s.heavy_offsets, s.n_heavy, ws.slot_pts, ws.task_pts);
         UG_KERNEL_CHECK();
         hipLaunchKernelGGL(heavy_final_kernel<Cfg>, dim3(s.n_heavy), dim3(Cfg::BLOCK), 0, stream,
-                           s.heavy_buckets_dev, ws.task_pts, ws.bucket_pts);
+                           (const HeavyBucket*)s.heavy_list, s.heavy_offsets, ws.task_pts, ws.bucket_pts);
         UG_KERNEL_CHECK();
     }
     int chunk = g.buckets < (u32)CHUNK ? (int)g.buckets : CHUNK;
