@@ -28,7 +28,7 @@ namespace ug {
 
 namespace {
 
-constexpr int LOG_SEG = 5;            // entries per lane of the segmented accumulation: 2^5
+constexpr int LOG_SEG = 7;            // at most 2^7 entries per lane of the segmented accumulation (see pick_log_seg)
 constexpr u32 FIX_MAX = 32;           // buckets cut into more pieces than this take the block-parallel path
 constexpr u32 MEDIUM_MAX = 4096;      // up to this many pieces: one wave per bucket; above: two-level heavy path
 constexpr u32 HEAVY_TASK = 1024;      // pieces summed by one workgroup of the heavy path
@@ -506,7 +506,7 @@ void MsmSchedule::reserve(const MsmGeometry& g) {
         dev_alloc(bucket_count, g.total_buckets() * 4);
         capacity_buckets = g.total_buckets();
     }
-    u64 hcap = (total >> LOG_SEG) / (FIX_MAX - 1) + 2;   // a heavy bucket covers at least FIX_MAX - 1 whole segments
+    u64 hcap = (total >> 5) / (FIX_MAX - 1) + 2;         // a listed bucket covers at least FIX_MAX - 1 whole segments (>= 2^5 entries each)
     if (hcap > heavy_cap) {
         dev_alloc(heavy_list, 4 * hcap * 4); dev_alloc(medium_list, 4 * hcap * 4); dev_alloc(heavy_offsets, (hcap + 1) * 4);
         heavy_cap = (u32)hcap;
@@ -517,7 +517,10 @@ void MsmSchedule::reserve(const MsmGeometry& g) {
 void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_t stream) {
     geo = g;
     reserve(g);
-    n_heavy = 0; n_medium = 0; n_heavy_tasks = 0; n_valid = 0; log_seg = LOG_SEG;
+    n_heavy = 0; n_medium = 0; n_heavy_tasks = 0; n_valid = 0;
+    // entries per lane: long segments cut fewer buckets into pieces, but keep about a million lanes in flight
+    log_seg = 5;
+    while (log_seg < LOG_SEG && ((g.n * g.windows) >> (log_seg + 1)) >= ((u64)1 << 20)) log_seg++;
     if (g.n == 0) return;
     u64 total = g.n * g.windows;
     if (total >= ((u64)1 << 31)) throw std::invalid_argument("msm: n * windows exceeds 2^31 entries");
