@@ -60,6 +60,7 @@ def _load():
     L.ugo_f_mul_vec.argtypes = [C.c_int, vp, vp, vp, C.c_size_t]
     L.ugo_keccak256.argtypes = [vp, vp, C.c_uint64]
     L.ugo_derive_challenge.argtypes = [vp, vp]
+    L.ugo_fr_dot_walk.argtypes = [vp, vp, C.c_uint64, C.c_uint64]
     return L
 
 
@@ -205,6 +206,14 @@ def g2_add(p, q):
     out = C.create_string_buffer(128)
     lib.ugo_g2_add(out, bytes(p), bytes(q))
     return out.raw
+
+
+def fr_dot_walk(scalars, n, seed):
+    """sum scalars[i] * (seed + i) mod r  (scalars: n x 32-byte plain integers, any buffer)"""
+    out = C.create_string_buffer(32)
+    buf = scalars if isinstance(scalars, (bytes, bytearray)) else (C.c_char * (n * 32)).from_buffer(scalars)
+    lib.ugo_fr_dot_walk(out, buf, n, seed)
+    return from_le(out.raw)
 
 
 def keccak256(data):

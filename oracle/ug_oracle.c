@@ -796,3 +796,24 @@ int ugo_num_threads(void) {
     return 1;
 #endif
 }
+
+/* sum_i scalars[i] * (seed + i) mod r, plain integers in and out: the discrete log of an MSM over the
+ * synthetic base points P_i = (seed + i) * G (ultragroth_amd/synth.py), for full-size checks in the exponent */
+void ugo_fr_dot_walk(uint64_t out[4], const uint8_t *scalars, uint64_t n, uint64_t seed) {
+    fe total; fe_zero(&total);
+#pragma omp parallel
+    {
+        fe acc; fe_zero(&acc);
+#pragma omp for schedule(static)
+        for (uint64_t i = 0; i < n; i++) {
+            fe s, k = {{seed + i, 0, 0, 0}}, t;
+            memcpy(&s, scalars + i * 32, 32);
+            fe_to_mont(&s, &s, &UGO_FR);          /* also reduces values >= r */
+            fe_mul(&t, &s, &k, &UGO_FR);          /* (s R)(k)/R = s k */
+            fe_add(&acc, &acc, &t, &UGO_FR);
+        }
+#pragma omp critical
+        fe_add(&total, &total, &acc, &UGO_FR);
+    }
+    memcpy(out, &total, 32);
+}

@@ -1,0 +1,208 @@
+"""GPU tests beyond the fixture: synthetic circuits against the oracle at sizes it finishes in seconds, the sharded
+(multi-GPU) path, UltraGroth, and size-independent properties at BASELINE.json's full sizes."""
+import ctypes as C
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import fixed_rs
+
+pytestmark = pytest.mark.gpu
+
+FULL_LOG = int(os.environ.get("UG_FULL_LOG", "24"))          # BASELINE.json configs[2]
+
+
+def _sec(buf, ftype, sid):
+    off, sz = O.section(buf, ftype, sid)
+    return buf[off:off + sz]
+
+
+@pytest.mark.parametrize("log_domain,mix", [(12, "U"), (14, "C"), (16, "U")])
+def test_synthetic_circuit_proof_bit_exact(device, log_domain, mix):
+    """whole prove through the reference's C API == oracle, on seeded synthetic circuits (unsorted coefficients,
+    circom-like and uniform witnesses)"""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, wtns, info = synth.build_circuit(device, log_domain, mix=mix)
+    r, s = fixed_rs()
+    ug.set_test_blinding(r + s)
+    try:
+        proof, pub = ug.groth16_prover(zkey, wtns)
+    finally:
+        ug.set_test_blinding(b"")
+    exp = O.groth16_prove(zkey, wtns, int.from_bytes(r, "little"), int.from_bytes(s, "little"))
+    assert (proof, pub) == (exp[0], exp[1])
+
+
+def test_synthetic_points_are_the_generator_walk(device):
+    from ultragroth_amd import synth
+    g1 = synth.g1_generator_record()
+    g2 = synth.g2_generator_record()
+    assert O.lib.ugo_g1_on_curve(g1) == 1 and O.lib.ugo_g2_on_curve(g2) == 1
+    pts = bytes(synth.synth_points(device, 40, 1000))
+    for i in (0, 1, 17, 39):
+        assert pts[64 * i:64 * i + 64] == O.g1_mul(g1, 1000 + i)
+    pts2 = bytes(synth.synth_points(device, 9, 5, g2=True))
+    for i in (0, 3, 8):
+        assert pts2[128 * i:128 * i + 128] == O.g2_mul(g2, 5 + i)
+
+
+def test_hpoly_2_18_matches_oracle(device):
+    from ultragroth_amd import synth
+    zkey, wtns, info = synth.build_circuit(device, 18, mix="C", g1_only=True)
+    coefs = _sec(zkey, "zkey", 4)[4:]
+    w = _sec(wtns, "wtns", 2)
+    hp = device.hpoly(coefs, info["nCoefs"], info["domainSize"], info["nVars"])
+    h = device.download(hp.run(device.dvec(info["nVars"], w)), 0, info["domainSize"])
+    assert h == O.hpoly(coefs, info["nCoefs"], w, info["nVars"], info["domainSize"])
+
+
+def test_long_coefficient_rows(device):
+    """rows with thousands of entries (range accumulation in the mat-vec) and empty rows"""
+    rng = random.Random(1)
+    logn, nvars = 10, 900
+    n = 1 << logn
+    recs = []
+    for i in range(5000):
+        recs.append((0, 3, rng.randrange(nvars)))
+    for i in range(3000):
+        recs.append((1, 3, rng.randrange(nvars)))
+    for c in range(0, n, 7):
+        recs.append((rng.randrange(2), c, rng.randrange(nvars)))
+    rng.shuffle(recs)
+    raw = b"".join(int(m).to_bytes(4, "little") + int(c).to_bytes(4, "little") + int(s).to_bytes(4, "little") +
+                   O.to_le(rng.randrange(O.R_MOD)) for m, c, s in recs)
+    w = b"".join(O.to_le(rng.randrange(O.R_MOD)) for _ in range(nvars))
+    hp = device.hpoly(raw, len(recs), n, nvars)
+    h = device.download(hp.run(device.dvec(nvars, w)), 0, n)
+    assert h == O.hpoly(raw, len(recs), w, nvars, n)
+
+
+def test_bad_coefficient_record_is_rejected(device):
+    import ultragroth_amd as ug
+    raw = (0).to_bytes(4, "little") + (99999).to_bytes(4, "little") + (0).to_bytes(4, "little") + bytes(32)
+    with pytest.raises(ug.DeviceError):
+        device.hpoly(raw, 1, 1024, 10)
+
+
+def test_sharded_prover_equals_unsharded(device, zkey, wtns):
+    """the N > 1 path on one GPU: 3 ranks' partial sums, added, give the unsharded proof byte for byte"""
+    import ultragroth_amd as ug
+    r, s = fixed_rs()
+    world = 3
+    ranks = [ug.ShardedGroth16Prover(zkey, 0, k, world) for k in range(world)]
+    total = None
+    for p in ranks:
+        p.load_witness(wtns)
+        part = p.run()
+        total = part if total is None else ug.ShardedGroth16Prover.add_partials(total, part)
+    ug.set_test_blinding(r + s)
+    try:
+        proof, pub = ranks[0].finish(total)
+    finally:
+        ug.set_test_blinding(b"")
+    exp = O.groth16_prove(zkey, wtns, int.from_bytes(r, "little"), int.from_bytes(s, "little"))
+    assert (proof, pub) == (exp[0], exp[1])
+    for p in ranks:
+        p.close()
+
+
+def test_api_errors_on_device(zkey, wtns):
+    import ultragroth_amd as ug
+    with ug.Groth16Prover(zkey) as p:
+        with pytest.raises(ug.ProverError) as e:
+            p.prove(wtns, proof_size=100)
+        assert e.value.code == ug.PROVER_ERROR_SHORT_BUFFER
+        assert e.value.message == "Proof buffer is too short. Minimum size: 810, actual size: 100"     # prover.cpp:127-133
+        with pytest.raises(ug.ProverError) as e:
+            p.prove(wtns, public_size=5)
+        assert e.value.message == "Public buffer is too short. Minimum size: 86, actual size: 5"
+        short = bytearray(wtns)
+        nv_off = O.section(wtns, "wtns", 1)[0] + 36
+        short[nv_off:nv_off + 4] = (1002).to_bytes(4, "little")
+        with pytest.raises(ug.ProverError) as e:
+            p.prove(bytes(short))
+        assert e.value.code == ug.PROVER_INVALID_WITNESS_LENGTH
+        assert e.value.message == "Invalid witness length. Circuit: 1003, witness: 1002"               # prover.cpp:190-195
+        with pytest.raises(ug.ProverError) as e:
+            p.prove(zkey)
+        assert e.value.message == "Invalid file type. It should be wtns and it is zkey"
+        proof, pub = p.prove(wtns)                          # still usable after errors
+        assert json.loads(proof)["protocol"] == "groth16"
+
+
+def test_ultragroth_matches_oracle(device):
+    """UltraGroth (parity unpinned upstream: no fixture exists): product == oracle on a synthetic protocol-1337 circuit"""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, uwtns, info = synth.build_ultra_circuit(device, 12)
+    rk, r, s = bytes(range(1, 32)), bytes(range(40, 71)), bytes(range(80, 111))
+    ug.set_test_blinding(rk + r + s)
+    try:
+        proof, pub = ug.ultra_groth_prover(zkey, uwtns)
+    finally:
+        ug.set_test_blinding(b"")
+    exp = O.ultra_groth_prove(zkey, uwtns, int.from_bytes(rk, "little"), int.from_bytes(r, "little"), int.from_bytes(s, "little"))
+    assert (proof, pub) == exp
+    j = json.loads(proof)
+    assert j["protocol"] == "ultragroth" and set(j) == {"pi_a", "pi_b", "pi_f", "pi_r", "protocol"}
+    assert len(json.loads(pub)) == info["nPublic"] - 1            # rand_indx is skipped (prover.cpp:89-105)
+    with pytest.raises(ug.ProverError) as e:
+        ug.groth16_prover(zkey, uwtns)
+    assert e.value.message == "zkey file is not groth16"
+
+
+# ---- size-independent properties at full size ------------------------------------------------------------------
+
+def test_full_size_g1_msm_in_the_exponent(device):
+    """sum s_i P_i with P_i = (seed + i) G equals (sum s_i (seed + i) mod r) G, at the full configs[2] size"""
+    from ultragroth_amd import synth
+    n = (1 << FULL_LOG) - 1
+    seed = synth.SEEDS["A"]
+    pts = synth.synth_points(device, n, seed)
+    sc = synth.scalars(n, "U", 99)
+    b = device.bases(pts, n)
+    del pts
+    v = device.dvec(n, sc.tobytes())
+    got = device.msm(b, device.schedule(v, 0, n))
+    k = O.fr_dot_walk(sc.tobytes(), n, seed)
+    assert got == O.g1_mul(synth.g1_generator_record(), k)
+    # linearity / sharding property: MSM over two halves adds up to the whole
+    half = n // 2
+    lo = device.msm(b, device.schedule(v, 0, half))
+    hi = device.msm(b, device.schedule(v, half, n - half))
+    assert O.g1_add(lo, hi) == got
+
+
+def test_full_size_g2_msm_in_the_exponent(device):
+    from ultragroth_amd import synth
+    n = (1 << max(FULL_LOG - 2, 10)) - 1
+    seed = synth.SEEDS["B2"]
+    pts = synth.synth_points(device, n, seed, g2=True)
+    sc = synth.scalars(n, "C", 98)
+    b = device.bases(pts, n, g2=True)
+    del pts
+    got = device.msm(b, device.schedule(device.dvec(n, sc.tobytes()), 0, n), g2=True)
+    assert got == O.g2_mul(synth.g2_generator_record(), O.fr_dot_walk(sc.tobytes(), n, seed))
+
+
+def test_full_size_ntt_round_trip_and_delta(device):
+    logn = FULL_LOG
+    n = 1 << logn
+    rng = np.random.Generator(np.random.PCG64(5))
+    x = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    x[:, 3] &= np.uint64((1 << 60) - 1)
+    data = x.tobytes()
+    fwd = device.ntt(data, logn)
+    assert device.ntt(fwd, logn, inverse=True) == data
+    # transform of the delta at index 1 is (omega^k)_k: spot-check against the oracle's root
+    R = 1 << 256
+    delta = bytes(32) + O.to_le(R % O.R_MOD) + bytes(32 * (n - 2))
+    out = device.ntt(delta, logn)
+    w = O.root_of_unity(logn) * pow(R, -1, O.R_MOD) % O.R_MOD
+    for k in (0, 1, 2, 12345, n // 2, n - 1):
+        assert O.mont_decode(out[32 * k:32 * k + 32], O.R_MOD) == pow(w, k, O.R_MOD)

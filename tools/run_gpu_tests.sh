@@ -1,3 +1,4 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -40
+export OMP_NUM_THREADS=16
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q --durations=8 2>&1 | tail -40

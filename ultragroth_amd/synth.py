@@ -129,3 +129,56 @@ def build_circuit(dev, log_domain, mix="U", seed=0x5EED0000, n_public=1, g1_only
     wtns += struct.pack("<IQ", 2, w.nbytes) + w.tobytes()
     info = dict(domainSize=domain, nVars=nvars, nPublic=n_public, nCoefs=len(coefs), mix=mix, seed=seed, g1_only=g1_only)
     return zkey, wtns, info
+
+
+def build_ultra_circuit(dev, log_domain, mix="C", seed=0x5EED0005, lookup_log=8):
+    """UltraGroth (protocol 1337) zkey + .uwtns of the same shapes: SURVEY.md section 8(d) config 5.
+
+    nPublic = 2 with rand_indx = 2; the private signals are split into a round set C1 (a quarter of them) and a
+    final set C2 (the rest); lookup table of 2^lookup_log rows, nVars/8 chunks. Section map as the reference reads
+    it (src/prover.cpp:242-259, src/zkey_utils.cpp:123-163; uwtns sections 3..6 src/prover.cpp:287-292)."""
+    domain = 1 << log_domain
+    nvars = domain - 1
+    n_public, rand_indx = 2, 2
+    rng = np.random.Generator(np.random.PCG64(seed))
+    priv = rng.permutation(np.arange(n_public + 1, nvars, dtype=np.uint32))
+    n1 = len(priv) // 4
+    idx1 = np.sort(priv[:n1]).astype("<u4")
+    idx2 = np.sort(priv[n1:]).astype("<u4")
+    r_le = R_MOD.to_bytes(32, "little")
+    q_le = Q_MOD.to_bytes(32, "little")
+    vk_g1 = bytes(synth_points(dev, 4, SEEDS["VK"]))                    # alpha1, beta1, round_delta1, final_delta1
+    vk_g2 = bytes(synth_points(dev, 4, SEEDS["VK"], g2=True))           # beta2, gamma2, round_delta2, final_delta2
+    header = struct.pack("<I", 32) + q_le + struct.pack("<I", 32) + r_le
+    header += struct.pack("<IIIIII", nvars, n_public, domain, len(idx1), len(idx2), rand_indx)
+    header += vk_g1[0:64] + vk_g1[64:128] + vk_g2[0:128] + vk_g2[128:256]
+    header += vk_g1[128:192] + vk_g2[256:384] + vk_g1[192:256] + vk_g2[384:512]
+    coefs = coefficients(domain, nvars, seed + 1)
+    secs = [
+        (1, struct.pack("<I", 1337)), (2, header), (3, bytes(64 * (n_public + 1))),
+        (4, struct.pack("<I", len(coefs)) + coefs.tobytes()),
+        (5, bytes(synth_points(dev, nvars, SEEDS["A"]))), (6, bytes(synth_points(dev, nvars, SEEDS["B1"]))),
+        (7, bytes(synth_points(dev, nvars, SEEDS["B2"], g2=True))),
+        (8, bytes(synth_points(dev, len(idx1), SEEDS["C"]))),                 # round points C1
+        (9, bytes(synth_points(dev, len(idx2), SEEDS["C"] + (1 << 28)))),     # final points C2
+        (10, idx1.tobytes()), (11, idx2.tobytes()),
+        (12, bytes(synth_points(dev, domain, SEEDS["H"]))), (13, b""),
+    ]
+    zkey = b"zkey" + struct.pack("<II", 1, len(secs)) + b"".join(_section(i, p) for i, p in secs)
+    w = scalars(nvars, mix, seed + 2)
+    w[0] = (1, 0, 0, 0)
+    lookup = 1 << lookup_log
+    n_chunks = max(nvars // 8, 1)
+    chunks = rng.integers(0, lookup, size=n_chunks, dtype=np.uint32).astype("<u4")
+    freq = rng.integers(0, 1 << 20, size=lookup, dtype=np.uint32).astype("<u4")
+    n_push = 2 * lookup + n_chunks + 1
+    # lookup signals live in the final set; the challenge itself lands on the public signal rand_indx
+    targets = rng.permutation(idx2)[:min(n_push - 1, len(idx2))]
+    w_idx = np.concatenate([np.array([rand_indx], dtype=np.uint32), targets]).astype("<u4")
+    p_idx = np.concatenate([np.array([0], dtype=np.uint32), 1 + rng.permutation(n_push - 1)[:len(targets)].astype(np.uint32)]).astype("<u4")
+    uw = [(1, struct.pack("<I", 32) + r_le + struct.pack("<I", nvars)), (2, w.tobytes()), (3, chunks.tobytes()),
+          (4, freq.tobytes()), (5, w_idx.tobytes()), (6, p_idx.tobytes())]
+    wtns = b"wtns" + struct.pack("<II", 2, len(uw)) + b"".join(_section(i, p) for i, p in uw)
+    info = dict(domainSize=domain, nVars=nvars, nPublic=n_public, randIndx=rand_indx, nC1=len(idx1), nC2=len(idx2),
+                lookup=lookup, chunks=n_chunks)
+    return zkey, wtns, info
