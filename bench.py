@@ -143,6 +143,16 @@ def main():
         # (64 B affine base + 32 B scalar, each read once)
         g1_bytes = 96.0 * n_local
         achieved = g1_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, corrected as the microarch guide
+        # says), measured separately on this workload and committed under profiles/; null when not measured
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            k = pmc.get(str(log_domain), {}).get("segment_accumulate_kernel<G1Cfg>")
+            if k and world == 1 and args.mix == "U":
+                traffic = k["fetch"] + k["write"]
+        except Exception:
+            traffic = None
         res = {
             "metric": "proofs/s", "value": args.steps / elapsed, "unit": "proofs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -153,8 +163,9 @@ def main():
                        "log_domain": log_domain, "mix": args.mix, "parallelism": "base-range shard x%d" % world},
             "msm_ms_per_proof": msm_ms / args.steps, "fft_ms_per_proof": fft_ms / args.steps,
             "create_s": create_s, "witness_upload_s": upload_s, "zkey_bytes": zkey_bytes,
-            "roofline": {"bound": "hbm", "kernel": "bucket_accumulate_kernel<G1Cfg>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "segment_accumulate_kernel<G1Cfg>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": g1_bytes,
                          "avg_launch_ms": acc_ms, "launches": launches,
                          "g2_kernel": {"avg_launch_ms": g2_ms, "launches": g2_launches,
                                        "achieved": (160.0 * n_local / (g2_ms * 1e-3) / 1e9) if g2_ms > 0 else 0.0},
