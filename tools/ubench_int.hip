@@ -127,6 +127,55 @@ __global__ void k_fma32(u64* out, u32 a, u32 b) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = (u64)s;
 }
 
+
+#define UB_KERNEL32(NAME, ASM)                                                              \
+__global__ void NAME(u64* out, u32 a, u32 b) {                                              \
+    u32 c[8]; u32 y = b ^ threadIdx.x;                                                      \
+    for (int j = 0; j < 8; j++) c[j] = j + threadIdx.x + a;                                 \
+    for (int i = 0; i < ITERS; i++) {                                                       \
+        _Pragma("unroll") for (int j = 0; j < 8; j++) asm volatile(ASM : "+v"(c[j]) : "v"(y)); \
+    }                                                                                       \
+    u64 s = 0; for (int j = 0; j < 8; j++) s += c[j];                                       \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                         \
+}
+#define UB_KERNEL64(NAME, ASM)                                                              \
+__global__ void NAME(u64* out, u32 a, u32 b) {                                              \
+    u64 c[8]; u32 y = (b ^ threadIdx.x) & 31;                                               \
+    for (int j = 0; j < 8; j++) c[j] = ((u64)(j + threadIdx.x + a) << 33) | 12345;          \
+    for (int i = 0; i < ITERS; i++) {                                                       \
+        _Pragma("unroll") for (int j = 0; j < 8; j++) asm volatile(ASM : "+v"(c[j]) : "v"(y)); \
+    }                                                                                       \
+    u64 s = 0; for (int j = 0; j < 8; j++) s += c[j];                                       \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                         \
+}
+UB_KERNEL32(k_and32, "v_and_b32 %0, %0, %1")
+UB_KERNEL32(k_alignbit, "v_alignbit_b32 %0, %0, %1, 29")
+UB_KERNEL32(k_add3, "v_add3_u32 %0, %0, %1, %1")
+UB_KERNEL32(k_lshladd32, "v_lshl_add_u32 %0, %0, 3, %1")
+UB_KERNEL32(k_lshr32, "v_lshrrev_b32 %0, 3, %0")
+UB_KERNEL32(k_or3, "v_or3_b32 %0, %0, %1, %1")
+UB_KERNEL32(k_addco, "v_add_co_u32 %0, vcc, %0, %1")
+UB_KERNEL32(k_sub32, "v_sub_u32 %0, %0, %1")
+UB_KERNEL64(k_lshr64, "v_lshrrev_b64 %0, 3, %0")
+UB_KERNEL64(k_ashr64, "v_ashrrev_i64 %0, 3, %0")
+UB_KERNEL64(k_lshl64, "v_lshlrev_b64 %0, 1, %0")
+// one mad followed by N independent adds: do the adds hide under the mad?
+template <int NADD>
+__global__ void k_mad_plus_adds(u64* out, u32 a, u32 b) {
+    u64 c[8]; u32 d[8]; u32 y = b ^ threadIdx.x;
+    for (int j = 0; j < 8; j++) { c[j] = j + threadIdx.x + a; d[j] = j * 7 + a; }
+    for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(c[j]) : "v"(y), "v"((u32)(j + 3)) : "vcc");
+#pragma unroll
+            for (int k = 0; k < NADD; k++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(d[(j + k) & 7]) : "v"(y));
+        }
+    }
+    u64 s = 0; for (int j = 0; j < 8; j++) s += c[j] + d[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <typename K>
 static int run(const char* name, K kern, double ops_per_thread, int blocks, int threads, u64* out) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -167,6 +216,22 @@ int main() {
         if (run("mad_u32_u24", k_mad24, ops, blocks, threads, out)) return 1;
         if (run("fma_f64", k_dfma, ops, blocks, threads, out)) return 1;
         if (run("fma_f32", k_fma32, ops, blocks, threads, out)) return 1;
+        if (run("and_b32", k_and32, ops, blocks, threads, out)) return 1;
+        if (run("alignbit_b32", k_alignbit, ops, blocks, threads, out)) return 1;
+        if (run("add3_u32", k_add3, ops, blocks, threads, out)) return 1;
+        if (run("lshl_add_u32", k_lshladd32, ops, blocks, threads, out)) return 1;
+        if (run("lshrrev_b32", k_lshr32, ops, blocks, threads, out)) return 1;
+        if (run("or3_b32", k_or3, ops, blocks, threads, out)) return 1;
+        if (run("add_co_u32", k_addco, ops, blocks, threads, out)) return 1;
+        if (run("sub_u32", k_sub32, ops, blocks, threads, out)) return 1;
+        if (run("lshrrev_b64", k_lshr64, ops, blocks, threads, out)) return 1;
+        if (run("ashrrev_i64", k_ashr64, ops, blocks, threads, out)) return 1;
+        if (run("lshlrev_b64", k_lshl64, ops, blocks, threads, out)) return 1;
+        printf("--- one v_mad_u64_u32 followed by N independent v_add_u32 (rate counted per mad)\n");
+        if (run("mad+0add", k_mad_plus_adds<0>, ops, blocks, threads, out)) return 1;
+        if (run("mad+1add", k_mad_plus_adds<1>, ops, blocks, threads, out)) return 1;
+        if (run("mad+2add", k_mad_plus_adds<2>, ops, blocks, threads, out)) return 1;
+        if (run("mad+4add", k_mad_plus_adds<4>, ops, blocks, threads, out)) return 1;
         break;  // occupancy is set by the hardware (8 waves/SIMD at these register counts)
     }
     CK(hipFree(out));

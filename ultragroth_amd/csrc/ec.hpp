@@ -51,7 +51,7 @@ template <class F> UG_HD XYZZ<F> xyzz_dbl_affine(const F& x, const F& y) {
     F m = triple(sqrk<1>(x));                       // < 3.1
     r.x = add(sqrk<4>(m), neg<3>(dbl(s)));          // < 1.2 + 3 = 4.2
     F t = sub<5>(s, r.x);                           // < 6.1
-    r.y = sub<2>(mulk<7>(m, t), mulk<8>(w, y));     // < 1.4 + 2 = 3.4
+    r.y = mul_subk<7, 1>(m, t, w, y);               // M t - W y: < 1.3
     r.zz = v;
     r.zzz = w;
     return r;
@@ -68,7 +68,7 @@ template <class F> UG_HD XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
     F m = triple(sqrk<7>(p.x));                     // < 3 * 1.58 = 4.74
     r.x = add(sqrk<5>(m), neg<3>(dbl(s)));          // < 1.3 + 3 = 4.3
     F t = sub<5>(s, r.x);                           // < 6.41
-    r.y = sub<2>(mulk<7>(m, t), mulk<8>(w, p.y));   // < 1.4 + 2 = 3.4
+    r.y = mul_subk<7, 4>(m, t, w, p.y);             // M t - W Y: < (31 + 34 + 6 + 6)/170 + 1 = 1.5
     r.zz = mulk<8>(v, p.zz);
     r.zzz = mulk<8>(w, p.zzz);
     return r;
@@ -90,9 +90,9 @@ template <class F> UG_HD XYZZ<F> xyzz_madd(const XYZZ<F>& p, const F& x2, const 
     XYZZ<F> r;
     F ppp = mulk<8>(pp_, pp);                       // < 1.52
     F q = mulk<8>(p.x, pp);                         // < 1.41
-    r.x = add(r2, add(neg<2>(ppp), neg<3>(dbl(q))));    // < 1.5 + 2 + 3 = 6.5
+    r.x = sub_b_2c_5q(r2, ppp, q);                  // R^2 - PPP - 2Q + 5q  < 1.5 + 5 = 6.5   (PPP + 2Q < 4.4)
     F t = sub<7>(q, r.x);                           // < 8.41
-    r.y = sub<2>(mulk<9>(rr_, t), mulk<8>(p.y, ppp));   // < 1.6 + 2 = 3.6
+    r.y = mul_subk<9, 2>(rr_, t, p.y, ppp);         // R t - Y PPP, one reduction: < (43 + 46 + 8 + 6)/170 + 1 = 1.6
     r.zz = mulk<8>(p.zz, pp);
     r.zzz = mulk<8>(p.zzz, ppp);
     return r;
@@ -117,9 +117,9 @@ template <class F> UG_HD XYZZ<F> xyzz_add(const XYZZ<F>& p1, const XYZZ<F>& p2) 
     XYZZ<F> r;
     F ppp = mulk<8>(pp_, pp);                       // < 1.2
     F q = mulk<8>(u1, pp);                          // < 1.1
-    r.x = add(r2, add(neg<2>(ppp), neg<3>(dbl(q))));    // < 6.15
+    r.x = sub_b_2c_5q(r2, ppp, q);                  // < 1.15 + 5 = 6.15   (PPP + 2Q < 3.4)
     F t = sub<7>(q, r.x);                           // < 8.1
-    r.y = sub<2>(mulk<9>(rr_, t), mulk<8>(s1, ppp));    // < 3.4
+    r.y = mul_subk<9, 2>(rr_, t, s1, ppp);          // R t - S1 PPP: < (27 + 30 + 3 + 2)/170 + 1 = 1.4
     r.zz = mulk<8>(mulk<8>(p1.zz, p2.zz), pp);
     r.zzz = mulk<8>(mulk<8>(p1.zzz, p2.zzz), ppp);
     return r;

@@ -227,6 +227,26 @@ template <int K, class P> UG_HD Fp<P> neg(const Fp<P>& a) {
     return norm_weak<P>(x);
 }
 
+// a - b - 2c + 5q in one pass (X3 = R^2 - PPP - 2Q of the addition formulas). Requires b + 2c < 5q.
+// Uses the table padded by 4*2^29 per limb, so limbs stay non-negative for weak b, c.
+template <class P> UG_HD Fp<P> sub_b_2c_5q(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c) {
+    UG_BOUND(add(b, dbl(c)), 5, "sub_b_2c_5q");
+    u32 x[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) x[i] = a.l[i] + P::kqw5[i] - b.l[i] - (c.l[i] << 1);
+    return norm_weak<P>(x);
+}
+// a*b + c*(K q - d) with one reduction  (= a*b - c*d mod q). Requires d < K q.
+// Result < (A B + C K)/170 q + q for operands below A q, B q, C q.
+template <int K, class P> UG_HD Fp<P> mul_sub(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c_, const Fp<P>& d) {
+    u64 c[2 * NL];
+    Fp<P> nd = neg<K>(d);
+    cols_zero(c);
+    cols_mul(c, a, b);
+    cols_mul(c, c_, nd);
+    return redc<P>(c);
+}
+
 // ---- exact forms ---------------------------------------------------------------------------------
 template <class P> UG_HD bool limbs_all_zero(const Fp<P>& a) {
     u32 o = 0;
@@ -368,6 +388,23 @@ template <int KB, class P> UG_HD Fp2<P> sqrk(const Fp2<P>& x) {
     cols_zero(c); cols_sqr(c, x.a); cols_mul(c, x.b, nb); r.a = redc<P>(c);
     cols_zero(c); cols_mul(c, x.a, dbl(x.b)); r.b = redc<P>(c);
     return r;
+}
+// a*b - c*d with one reduction per component: real = a0 b0 + a1 (KB q - b1) + c0 (K q - d0) + c1 d1,
+// imag = a0 b1 + a1 b0 + c0 (K q - d1) + c1 (K q - d0). Requires b.b < KB q and d < K q (both components).
+// Four column products share a reduction: 4 * 9 * 2^58 + 9 * 2^58 < 2^64.
+template <int KB, int K, class P> UG_HD Fp2<P> mul_subk(const Fp2<P>& a, const Fp2<P>& b, const Fp2<P>& c_, const Fp2<P>& d) {
+    Fp2<P> r;
+    u64 c[2 * NL];
+    Fp<P> nb1 = neg<KB>(b.b), nd0 = neg<K>(d.a), nd1 = neg<K>(d.b);
+    cols_zero(c); cols_mul(c, a.a, b.a); cols_mul(c, a.b, nb1); cols_mul(c, c_.a, nd0); cols_mul(c, c_.b, d.b); r.a = redc<P>(c);
+    cols_zero(c); cols_mul(c, a.a, b.b); cols_mul(c, a.b, b.a); cols_mul(c, c_.a, nd1); cols_mul(c, c_.b, nd0); r.b = redc<P>(c);
+    return r;
+}
+template <int KB, int K, class P> UG_HD Fp<P> mul_subk(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c_, const Fp<P>& d) {
+    return mul_sub<K>(a, b, c_, d);
+}
+template <class P> UG_HD Fp2<P> sub_b_2c_5q(const Fp2<P>& a, const Fp2<P>& b, const Fp2<P>& c) {
+    Fp2<P> r; r.a = sub_b_2c_5q(a.a, b.a, c.a); r.b = sub_b_2c_5q(a.b, b.b, c.b); return r;
 }
 // same spelling for the base field, where no negation multiple is needed
 template <int KB, class P> UG_HD Fp<P> mulk(const Fp<P>& a, const Fp<P>& b) { return mul(a, b); }

@@ -28,7 +28,7 @@ constexpr int NTT_MAX_LOG_TILE = 11;      // 2^11 elements * 36 B = 72 KiB of LD
 struct PassArgs {
     const u32* in;
     u32* out;
-    const u32* tw;        // packed twiddles w^i, i < n/2 (direction-specific table)
+    const u32* tw;        // packed twiddles, stage-major: entry (2^s - 1 + j) = omega_{2^(s+1)}^j, j < 2^s
     const u32* post;      // optional: out[i] *= post[i]   (natural index), nullptr if none
     const u32* post_const;// optional: out[i] *= *post_const
     int logn;
@@ -74,13 +74,13 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(PassArgs a) {
                 u32 elow = p & ((1u << d) - 1);
                 u32 e0 = ((p >> d) << (d + 1)) | elow;
                 pos0 = (t << k) | e0; pos1 = pos0 + (1u << d);
-                twi = elow << (a.logn - d - 1);
+                twi = ((1u << d) - 1) + elow;
             } else {
                 u32 t = bf & tmask, p = bf >> j;
                 u32 elow = p & ((1u << d) - 1);
                 u32 e0 = ((p >> d) << (d + 1)) | elow;
                 pos0 = (e0 << j) | t; pos1 = pos0 + (1u << (d + j));
-                twi = ((elow << s0) | (lo0 + t)) << (a.logn - (s0 + d) - 1);
+                twi = ((1u << (s0 + d)) - 1) + ((elow << s0) | (lo0 + t));
             }
             Fr x0, x1;
 #pragma unroll
@@ -160,29 +160,40 @@ void NttPlan::init(int logn_, hipStream_t stream) {
     release();
     logn = logn_;
     u64 n = (u64)1 << logn;
-    u64 half = n > 1 ? n / 2 : 1;
-    UG_HIP(hipMalloc(&tw_fwd, half * 32));
-    UG_HIP(hipMalloc(&tw_inv, half * 32));
+    // Stage-major twiddle tables: stage s (butterfly span 2^s) reads omega_{2^(s+1)}^j at consecutive j, so the
+    // lanes of a wave touch consecutive 32-byte entries at every stage (a single table of omega_n^i indexed with a
+    // stage-dependent stride makes the late stages hit one L2 channel with 64 KiB strides).
+    u64 entries = n > 1 ? n - 1 : 1;
+    UG_HIP(hipMalloc(&tw_fwd, entries * 32));
+    UG_HIP(hipMalloc(&tw_inv, entries * 32));
     UG_HIP(hipMalloc(&twist, n * 32));
     UG_HIP(hipMalloc(&ninv, 32));
-    Fr w = fr_root_of_unity(logn), winv = cond_sub_q(inv(w)), w2n = fr_root_of_unity(logn + 1);
+    Fr w2n = fr_root_of_unity(logn + 1);
     Fr n_inverse = cond_sub_q(inv(host_fr_from_u64(n)));
     Fr one = cond_sub_q(fp_one<FrParams>());
-    u32 consts[5][8];
-    pack256(consts[0], w); pack256(consts[1], winv); pack256(consts[2], w2n); pack256(consts[3], n_inverse); pack256(consts[4], one);
+    std::vector<u32> consts((size_t)(3 + 2 * (logn + 1)) * 8);
+    pack256(consts.data(), w2n); pack256(consts.data() + 8, n_inverse); pack256(consts.data() + 16, one);
+    for (int st = 0; st < logn; st++) {
+        Fr w = fr_root_of_unity(st + 1);
+        pack256(consts.data() + (size_t)(3 + 2 * st) * 8, w);
+        pack256(consts.data() + (size_t)(4 + 2 * st) * 8, cond_sub_q(inv(w)));
+    }
     u32* d_consts;
-    UG_HIP(hipMalloc(&d_consts, sizeof consts));
-    UG_HIP(hipMemcpyAsync(d_consts, consts, sizeof consts, hipMemcpyHostToDevice, stream));
+    UG_HIP(hipMalloc(&d_consts, consts.size() * 4));
+    UG_HIP(hipMemcpyAsync(d_consts, consts.data(), consts.size() * 4, hipMemcpyHostToDevice, stream));
     auto launch = [&](u32* table, int base_i, int scale_i, u64 count) {
         u64 threads = (count + POW_RUN - 1) / POW_RUN;
         unsigned blocks = (unsigned)((threads + 255) / 256);
         hipLaunchKernelGGL(power_table_kernel, dim3(blocks), dim3(256), 0, stream, table, d_consts + 8 * base_i, d_consts + 8 * scale_i, count);
         UG_KERNEL_CHECK();
     };
-    launch(tw_fwd, 0, 4, half);
-    launch(tw_inv, 1, 4, half);
-    launch(twist, 2, 3, n);                    // n^-1 * omega_{2n}^i
-    UG_HIP(hipMemcpyAsync(ninv, d_consts + 8 * 3, 32, hipMemcpyDeviceToDevice, stream));
+    for (int st = 0; st < logn; st++) {
+        u64 off = ((u64)1 << st) - 1;
+        launch(tw_fwd + off * 8, 3 + 2 * st, 2, (u64)1 << st);
+        launch(tw_inv + off * 8, 4 + 2 * st, 2, (u64)1 << st);
+    }
+    launch(twist, 0, 1, n);                    // n^-1 * omega_{2n}^i
+    UG_HIP(hipMemcpyAsync(ninv, d_consts + 8, 32, hipMemcpyDeviceToDevice, stream));
     UG_HIP(hipStreamSynchronize(stream));
     UG_HIP(hipFree(d_consts));
 }
