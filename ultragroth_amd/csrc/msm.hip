@@ -20,6 +20,7 @@
 // (G1: 8 mul + 2 sqr in Fq, G2: the same in Fq2). Algorithmic HBM bytes: 96 n (G1) / 160 n (G2).
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include "dev_common.hpp"
 #include "internal.hpp"
@@ -219,16 +220,29 @@ __global__ void bucket_counts_kernel(u32* start, u32* count, u32 nb, int log_seg
 __host__ __device__ __forceinline__ u64 transposed_index(u64 seg, u32 k, int log_seg) {
     return ((seg >> 6) << (log_seg + 6)) + ((u64)k << 6) + (seg & 63);
 }
-__global__ void transpose_entries_kernel(const u32* __restrict__ keys, const u32* __restrict__ vals, u64 n_padded, u32 n_valid,
-                                         u32 sentinel, int log_seg, u32* __restrict__ tkeys, u32* __restrict__ tvals) {
-    u64 o = (u64)blockIdx.x * blockDim.x + threadIdx.x;          // output position (coalesced stores)
-    if (o >= n_padded) return;
-    u64 tile = o >> (log_seg + 6);
-    u32 k = (u32)(o >> 6) & ((1u << log_seg) - 1), lane = (u32)o & 63;
-    u64 src = (((tile << 6) + lane) << log_seg) + k;
-    bool in = src < n_valid;
-    tkeys[o] = in ? keys[src] : sentinel;
-    tvals[o] = in ? vals[src] : 0u;
+// one workgroup per tile of 64 segments: coalesced reads of the tile's 64 * 2^log_seg consecutive entries,
+// transposition through LDS (row stride padded by one word), coalesced writes
+__global__ __launch_bounds__(256) void transpose_entries_kernel(const u32* __restrict__ keys, const u32* __restrict__ vals,
+                                                                u32 n_valid, u32 sentinel, int log_seg,
+                                                                u32* __restrict__ tkeys, u32* __restrict__ tvals) {
+    extern __shared__ u32 tile[];                                   // 2 arrays of 64 * (S + 1) words
+    const u32 S = 1u << log_seg, row = S + 1;
+    u32* tk = tile;
+    u32* tv = tile + 64 * row;
+    const u64 base = (u64)blockIdx.x << (log_seg + 6);
+    for (u32 i = threadIdx.x; i < (64u << log_seg); i += blockDim.x) {
+        u64 src = base + i;
+        bool in = src < n_valid;
+        u32 seg = i >> log_seg, k = i & (S - 1);
+        tk[seg * row + k] = in ? keys[src] : sentinel;
+        tv[seg * row + k] = in ? vals[src] : 0u;
+    }
+    __syncthreads();
+    for (u32 o = threadIdx.x; o < (64u << log_seg); o += blockDim.x) {
+        u32 k = o >> 6, lane = o & 63;
+        tkeys[base + o] = tk[lane * row + k];
+        tvals[base + o] = tv[lane * row + k];
+    }
 }
 
 template <class Cfg>
@@ -291,17 +305,26 @@ __device__ __forceinline__ XYZZ<typename Cfg::F> load_piece(const u32* slot_pts,
     return Cfg::from_words(slot_pts + slot * Cfg::PT_WORDS, 1);
 }
 
+// One lane per segment boundary: the bucket that crosses the boundary after segment t is summed by the lane of
+// the segment in which it starts, so the active lanes are dense (a lane-per-bucket sweep leaves 3/4 of a wave idle
+// when most buckets lie inside one segment). Buckets with more than FIX_MAX pieces go to the wave / workgroup paths.
 template <class Cfg>
-__global__ __launch_bounds__(128) void bucket_fixup_kernel(const u32* start, const u32* count, u32 nb, int log_seg,
-                                                           const u32* slot_pts, u32* bucket_pts) {
-    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
+__global__ __launch_bounds__(128) void bucket_fixup_kernel(const u32* __restrict__ keys, const u32* __restrict__ start,
+                                                           const u32* __restrict__ count, u32 n_valid, u32 nseg, int log_seg,
+                                                           const u32* __restrict__ slot_pts, u32* __restrict__ bucket_pts) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t + 1 >= nseg) return;
     typedef typename Cfg::F F;
-    u32 c = count[b];
-    if (!c) { Cfg::to_words(bucket_pts + (size_t)b * Cfg::PT_WORDS, xyzz_inf<F>(), 1); return; }
-    u32 first = start[b] >> log_seg, last = (start[b] + c - 1) >> log_seg;
+    u64 idx = ((u64)t + 1) << log_seg;             // first entry of segment t + 1
+    if (idx >= n_valid) return;
+    u32 b = keys[idx];
+    if (keys[idx - 1] != b) return;                // no bucket crosses this boundary
+    u32 st = start[b];
+    u32 first = st >> log_seg;
+    if (first != t) return;                        // the bucket started in an earlier segment: that lane sums it
+    u32 last = (st + count[b] - 1) >> log_seg;
     u32 pieces = last - first + 1;
-    if (pieces == 1 || pieces > FIX_MAX) return;       // whole bucket already written / medium or heavy path
+    if (pieces > FIX_MAX) return;
     XYZZ<F> acc = load_piece<Cfg>(slot_pts, first, 0);
     for (u32 k = 1; k < pieces; k++) acc = xyzz_add(acc, load_piece<Cfg>(slot_pts, first, k));
     Cfg::to_words(bucket_pts + (size_t)b * Cfg::PT_WORDS, acc, 1);
@@ -402,17 +425,18 @@ __global__ __launch_bounds__(Cfg::BLOCK) void heavy_final_kernel(const HeavyBuck
 // ---- 5. bucket reduction --------------------------------------------------------------------------------
 // thread = (window, chunk of `chunk` buckets): P = sum_k (k_global + 1) * bucket_k over the chunk
 template <class Cfg>
-__global__ __launch_bounds__(128) void bucket_chunk_reduce_kernel(const u32* buckets, u32 per_window, int chunk,
+__global__ __launch_bounds__(128) void bucket_chunk_reduce_kernel(const u32* buckets, const u32* count, u32 per_window, int chunk,
                                                                   u32 nchunks_total, int scalar_bits, u32* out) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nchunks_total) return;
     typedef typename Cfg::F F;
     u32 chunks_per_window = per_window / chunk;
     u32 w = t / chunks_per_window, j = t % chunks_per_window;
-    const u32* base = buckets + ((size_t)w * per_window + (size_t)j * chunk) * Cfg::PT_WORDS;
+    const size_t b0 = (size_t)w * per_window + (size_t)j * chunk;
+    const u32* base = buckets + b0 * Cfg::PT_WORDS;
     XYZZ<F> run = xyzz_inf<F>(), acc = xyzz_inf<F>();
     for (int k = chunk - 1; k >= 0; k--) {
-        run = xyzz_add(run, Cfg::from_words(base + (size_t)k * Cfg::PT_WORDS, 1));
+        if (count[b0 + k]) run = xyzz_add(run, Cfg::from_words(base + (size_t)k * Cfg::PT_WORDS, 1));   // empty bucket = infinity
         acc = xyzz_add(acc, run);
     }
     u32 off = j * (u32)chunk;                  // weight offset of the chunk
@@ -477,10 +501,21 @@ template <class T> void dev_free(T*& p) { if (p) hipFree(p); p = nullptr; }
 MsmGeometry MsmGeometry::choose(u64 n, int force_c) {
     MsmGeometry g;
     g.n = n;
-    int lg = 0;
-    while (((u64)1 << lg) < n) lg++;
-    int c = force_c ? force_c : lg - 4;
-    if (c < 6) c = 6;
+    // Window size: minimise windows * (entries + 4 * buckets) -- one mixed addition per (point, window) entry against
+    // about four addition-equivalents per bucket in the reduction (measured ratio at 2^20..2^24 on MI355X).
+    int c = force_c;
+    if (!c) {
+        static const int env_c = getenv("UG_MSM_C") ? atoi(getenv("UG_MSM_C")) : 0;      // tuning knob
+        c = env_c;
+    }
+    if (!c) {
+        double best = 0;
+        for (int k = 6; k <= 22; k++) {
+            double cost = (double)((255 + k - 1) / k) * ((double)n + 4.0 * (double)((u64)1 << (k - 1)));
+            if (!c || cost < best) { best = cost; c = k; }
+        }
+    }
+    if (c < 2) c = 2;
     if (c > 22) c = 22;
     g.c = c;
     g.windows = (255 + c - 1) / c;
@@ -561,8 +596,9 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
     u32* tk = (keys == keys_a) ? keys_b : keys_a;
     u32* tv = (vals == vals_a) ? vals_b : vals_a;
     if (n_padded) {
-        hipLaunchKernelGGL(transpose_entries_kernel, dim3((unsigned)((n_padded + 255) / 256)), dim3(256), 0, stream,
-                           keys, vals, n_padded, n_valid, sentinel, log_seg, tk, tv);
+        size_t lds = (size_t)2 * 64 * (((size_t)1 << log_seg) + 1) * 4;
+        hipLaunchKernelGGL(transpose_entries_kernel, dim3((unsigned)(n_padded / tile)), dim3(256), lds, stream,
+                           keys, vals, n_valid, sentinel, log_seg, tk, tv);
         UG_KERNEL_CHECK();
     }
     tkeys = tk; tvals = tv;
@@ -610,9 +646,11 @@ XYZZ<typename Cfg::F> msm_run(const MsmSchedule& s, MsmWorkspace& ws, const u32*
         UG_KERNEL_CHECK();
     }
     if (stats) UG_HIP(hipEventRecord(stats->ev1, stream));
-    hipLaunchKernelGGL(bucket_fixup_kernel<Cfg>, dim3((nb + 127) / 128), dim3(128), 0, stream,
-                       s.bucket_start, s.bucket_count, nb, s.log_seg, ws.slot_pts, ws.bucket_pts);
-    UG_KERNEL_CHECK();
+    if (nseg > 1) {
+        hipLaunchKernelGGL(bucket_fixup_kernel<Cfg>, dim3((unsigned)((nseg + 127) / 128)), dim3(128), 0, stream,
+                           s.keys, s.bucket_start, s.bucket_count, s.n_valid, (u32)nseg, s.log_seg, ws.slot_pts, ws.bucket_pts);
+        UG_KERNEL_CHECK();
+    }
     if (s.n_medium) {
         hipLaunchKernelGGL(medium_bucket_kernel<Cfg>, dim3((s.n_medium + 3) / 4), dim3(256), 0, stream,
                            (const HeavyBucket*)s.medium_list, s.n_medium, ws.slot_pts, ws.bucket_pts);
@@ -630,7 +668,7 @@ XYZZ<typename Cfg::F> msm_run(const MsmSchedule& s, MsmWorkspace& ws, const u32*
     u32 cpw = g.buckets / chunk;                       // chunks per window
     u32 nchunks = cpw * g.windows;
     hipLaunchKernelGGL(bucket_chunk_reduce_kernel<Cfg>, dim3((nchunks + 127) / 128), dim3(128), 0, stream,
-                       ws.bucket_pts, g.buckets, chunk, nchunks, g.c, ws.chunk_pts);
+                       ws.bucket_pts, s.bucket_count, g.buckets, chunk, nchunks, g.c, ws.chunk_pts);
     UG_KERNEL_CHECK();
     u32* cur = ws.chunk_pts; u32* nxt = ws.chunk_pts2;
     while (cpw > 1) {
