@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--cpu-sample-log", type=int, default=None, help="log2 domain of the CPU-baseline sample circuit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also compare the proof with the oracle (small sizes)")
+    ap.add_argument("--g1-only", action="store_true", help="BASELINE.json configs[1]: G1 MSM + NTT only (B1/B2/C sets at infinity)")
+    ap.add_argument("--ultra", action="store_true", help="BASELINE.json configs[4]: UltraGroth two-round prove (single GPU)")
     return ap.parse_args()
 
 
@@ -63,6 +65,34 @@ def cpu_baseline(dev, args, log_domain):
     }
 
 
+def bench_ultra(args, dev, ug, synth):
+    """UltraGroth: the whole ultra_groth_prover_prove call (witness upload, round-1 commitment MSM, Keccak
+    challenge, host lookup completion, final-round MSMs + H polynomial, blinding, JSON)."""
+    zkey, uwtns, info = synth.build_ultra_circuit(dev, args.log_domain, mix="C")
+    t0 = time.perf_counter()
+    prover = ug.UltraGrothProver(zkey)
+    create_s = time.perf_counter() - t0
+    for _ in range(args.warmup):
+        prover.prove(uwtns)
+    msm_ms = fft_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        prover.prove(uwtns)
+        m, f, _ = prover.last_timings()
+        msm_ms += m
+        fft_ms += f
+    elapsed = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "proofs/s", "value": args.steps / elapsed, "unit": "proofs/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 254-bit modular integers)", "data": "synthetic",
+        "config": {"workload": "ultragroth-bn254 2^%d constraints, two rounds, lookup 2^8, circom-like witness "
+                               "(BASELINE.json configs[4] shape, 1 GPU; witness from host memory)" % args.log_domain,
+                   "log_domain": args.log_domain, "protocol": "ultragroth"},
+        "msm_ms_per_proof": msm_ms / args.steps, "fft_ms_per_proof": fft_ms / args.steps, "create_s": create_s,
+    }))
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -78,15 +108,25 @@ def main():
     import ultragroth_amd as ug
     from ultragroth_amd import synth
 
+    # UG_BENCH_BACKEND=gloo + UG_BENCH_ONE_DEVICE=1 rehearse the N > 1 control flow on a one-GPU box
+    # (RCCL refuses two ranks on one device); the driver's multi-GPU runs use the defaults: nccl, one GPU per rank.
+    backend = os.environ.get("UG_BENCH_BACKEND", "nccl")
+    if os.environ.get("UG_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     dev = ug.Device(local_rank)
     log_domain = args.log_domain
-    zkey, wtns, info = synth.build_circuit(dev, log_domain, mix=args.mix)
+    if args.ultra:
+        return bench_ultra(args, dev, ug, synth)
+    zkey, wtns, info = synth.build_circuit(dev, log_domain, mix=args.mix, g1_only=args.g1_only)
     t0 = time.perf_counter()
     prover = ug.ShardedGroth16Prover(zkey, local_rank, rank, world)
     create_s = time.perf_counter() - t0
@@ -105,7 +145,9 @@ def main():
     def step():
         part = prover.run()
         if dist is not None:
-            mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).cuda()
+            mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)
+            if backend == "nccl":
+                mine = mine.cuda()
             allp = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(allp, mine)
             total = bytes(allp[0].cpu().numpy())
@@ -131,7 +173,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -159,7 +201,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 254-bit modular integers)",
             "data": "synthetic",
             "config": {"workload": "groth16-bn254 2^%d constraints, nVars 2^%d-1, nCoefs 4N, full G1+G2 MSM + H-poly FFT, "
-                                   "scalar mix %s (BASELINE.json configs[2] shape)" % (log_domain, log_domain, args.mix),
+                                   "scalar mix %s (BASELINE.json configs[%d] shape)" % (log_domain, log_domain, args.mix, 1 if args.g1_only else 2),
                        "log_domain": log_domain, "mix": args.mix, "parallelism": "base-range shard x%d" % world},
             "msm_ms_per_proof": msm_ms / args.steps, "fft_ms_per_proof": fft_ms / args.steps,
             "create_s": create_s, "witness_upload_s": upload_s, "zkey_bytes": zkey_bytes,

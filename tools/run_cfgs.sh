@@ -1,0 +1,15 @@
+set -o pipefail
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export OMP_NUM_THREADS=16
+show() { python - "$1" <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))
+print(sys.argv[1], "%.1f ms/proof (%.2f proofs/s)  msm %.1f  fft %.1f  create %.2fs" % (d["ms_per_step"], d["value"], d["msm_ms_per_proof"], d["fft_ms_per_proof"], d["create_s"]), d["config"]["workload"][:60])
+PY
+}
+timeout -k 10 600 python bench.py --log-domain 20 --g1-only --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/cfg1.json 2> gpurun_out/cfg1.err && show gpurun_out/cfg1.json || tail -3 gpurun_out/cfg1.err
+timeout -k 10 600 python bench.py --log-domain 24 --mix C --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/cfg2c.json 2> gpurun_out/cfg2c.err && show gpurun_out/cfg2c.json || tail -3 gpurun_out/cfg2c.err
+timeout -k 10 600 python bench.py --log-domain 22 --ultra --steps 3 --warmup 1 > gpurun_out/cfg4.json 2> gpurun_out/cfg4.err && show gpurun_out/cfg4.json || tail -3 gpurun_out/cfg4.err
+( time timeout -k 10 900 python bench.py --log-domain 26 --steps 2 --warmup 1 --no-cpu-baseline ) > gpurun_out/cfg3.json 2> gpurun_out/cfg3.err && show gpurun_out/cfg3.json || tail -5 gpurun_out/cfg3.err
+tail -4 gpurun_out/cfg3.err
