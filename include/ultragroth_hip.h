@@ -76,6 +76,9 @@ int  ug_dvec_upload(ug_dvec* v, const void* host, uint64_t n);           /* host
 int  ug_dvec_download(const ug_dvec* v, void* host, uint64_t first, uint64_t n);
 /* out[i] = src[index[i]] for i < n (UltraGroth round / final witness gathers, src/ultra_groth.cpp:415-445) */
 int  ug_dvec_gather(ug_dvec* out, const ug_dvec* src, const uint32_t* host_index, uint64_t n);
+/* dst[index[i]] = values[i] for i < n; indices must be distinct (UltraGroth lookup signals written back into the
+ * witness, src/ultra_groth.cpp:99-105) */
+int  ug_dvec_scatter(ug_dvec* dst, const uint32_t* host_index, const void* host_values, uint64_t n);
 uint64_t ug_dvec_size(const ug_dvec* v);
 void ug_dvec_destroy(ug_dvec* v);
 

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_CSRC, "libultragroth_hip.so")
 INNER_SYMBOLS = [
     "ug_last_error", "ug_device_count", "ug_ctx_create", "ug_ctx_destroy", "ug_ctx_sync",
     "ug_bases_create_g1", "ug_bases_create_g2", "ug_bases_destroy",
-    "ug_dvec_create", "ug_dvec_upload", "ug_dvec_download", "ug_dvec_gather", "ug_dvec_size", "ug_dvec_destroy",
+    "ug_dvec_create", "ug_dvec_upload", "ug_dvec_download", "ug_dvec_gather", "ug_dvec_scatter", "ug_dvec_size", "ug_dvec_destroy",
     "ug_schedule_create", "ug_schedule_build", "ug_schedule_destroy",
     "ug_msm_g1", "ug_msm_g2",
     "ug_hpoly_create", "ug_hpoly_run", "ug_hpoly_debug_abc", "ug_hpoly_destroy",
@@ -69,6 +69,7 @@ def load():
     L.ug_dvec_upload.argtypes = [vp, vp, u64]
     L.ug_dvec_download.argtypes = [vp, vp, u64, u64]
     L.ug_dvec_gather.argtypes = [vp, vp, vp, u64]
+    L.ug_dvec_scatter.argtypes = [vp, vp, vp, u64]
     L.ug_dvec_size.argtypes = [vp]; L.ug_dvec_size.restype = u64
     L.ug_dvec_destroy.argtypes = [vp]; L.ug_dvec_destroy.restype = None
     L.ug_schedule_create.argtypes = [vp, pp]

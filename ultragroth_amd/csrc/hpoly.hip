@@ -122,6 +122,16 @@ __global__ void gather_kernel(u32* out, const u32* src, const u32* index, u64 n,
     store8(out + i * 8, w);
 }
 
+__global__ void scatter_kernel(u32* dst, const u32* index, const u32* values, u64 n, u64 dst_n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 j = index[i];
+    if (j >= dst_n) return;
+    u32 w[8];
+    load8(w, values + i * 8);
+    store8(dst + j * 8, w);
+}
+
 template <class T> void dev_alloc(T*& p, size_t bytes) { if (p) hipFree(p); p = nullptr; UG_HIP(hipMalloc(&p, bytes ? bytes : 4)); }
 inline unsigned grid_for(u64 n, int block) { return (unsigned)((n + block - 1) / block); }
 
@@ -199,6 +209,11 @@ void fr_to_mont256(u32* out, const u32* in, u64 n, hipStream_t stream) {
 void gather_elements(u32* out, const u32* src, const u32* index_dev, u64 n, u64 src_n, hipStream_t stream) {
     if (!n) return;
     hipLaunchKernelGGL(gather_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, out, src, index_dev, n, src_n);
+    UG_KERNEL_CHECK();
+}
+void scatter_elements(u32* dst, const u32* index_dev, const u32* values_dev, u64 n, u64 dst_n, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, dst, index_dev, values_dev, n, dst_n);
     UG_KERNEL_CHECK();
 }
 void f_op_mont256(int which, int op, u32* out, const u32* a, const u32* b, u64 n, hipStream_t stream) {

@@ -124,5 +124,6 @@ void fr_from_mont256(u32* out, const u32* in, u64 n, hipStream_t stream);
 void fr_to_mont256(u32* out, const u32* in, u64 n, hipStream_t stream);
 void f_op_mont256(int which, int op, u32* out, const u32* a, const u32* b, u64 n, hipStream_t stream);
 void gather_elements(u32* out, const u32* src, const u32* index_dev, u64 n, u64 src_n, hipStream_t stream);
+void scatter_elements(u32* dst, const u32* index_dev, const u32* values_dev, u64 n, u64 dst_n, hipStream_t stream);
 
 }  // namespace ug

@@ -222,7 +222,7 @@ __host__ __device__ __forceinline__ u64 transposed_index(u64 seg, u32 k, int log
 }
 // one workgroup per tile of 64 segments: coalesced reads of the tile's 64 * 2^log_seg consecutive entries,
 // transposition through LDS (row stride padded by one word), coalesced writes
-__global__ __launch_bounds__(256) void transpose_entries_kernel(const u32* __restrict__ keys, const u32* __restrict__ vals,
+__global__ __launch_bounds__(1024) void transpose_entries_kernel(const u32* __restrict__ keys, const u32* __restrict__ vals,
                                                                 u32 n_valid, u32 sentinel, int log_seg,
                                                                 u32* __restrict__ tkeys, u32* __restrict__ tvals) {
     extern __shared__ u32 tile[];                                   // 2 arrays of 64 * (S + 1) words
@@ -597,7 +597,7 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
     u32* tv = (vals == vals_a) ? vals_b : vals_a;
     if (n_padded) {
         size_t lds = (size_t)2 * 64 * (((size_t)1 << log_seg) + 1) * 4;
-        hipLaunchKernelGGL(transpose_entries_kernel, dim3((unsigned)(n_padded / tile)), dim3(256), lds, stream,
+        hipLaunchKernelGGL(transpose_entries_kernel, dim3((unsigned)(n_padded / tile)), dim3(1024), lds, stream,
                            keys, vals, n_valid, sentinel, log_seg, tk, tv);
         UG_KERNEL_CHECK();
     }

@@ -9,6 +9,7 @@
 //   Proof::toJson, BuildPublicString              src/groth16.cpp:217-250, src/ultra_groth.cpp:476-513,
 //                                                 src/prover.cpp:89-117
 //   extern "C" entry points and error mapping     src/prover.cpp:311-891
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -370,7 +371,8 @@ public:
                                                 ", witness: " + std::to_string(wh.nVars));
         if (!wh.primeIsBn254) throw std::invalid_argument("different wtns curve");
         const uint64_t M = hdr_.nVars;
-        std::vector<uint8_t> signals(checkedSection(f, 2, M * 32), checkedSection(f, 2, M * 32) + M * 32);   // prover.cpp:283-285
+        const uint8_t* signals0 = checkedSection(f, 2, M * 32);       // the reference copies these (prover.cpp:283-285);
+                                                                      // here the copy lives in HBM and is patched there
         auto u32Section = [&](uint32_t id) {
             std::vector<uint32_t> v(f.sectionSize(id) >> 2);
             memcpy(v.data(), f.sectionData(id), v.size() * 4);
@@ -381,7 +383,7 @@ public:
 
         ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1));
         // ---- round 1: commitment to the round witnesses (ultra_groth.cpp:415-419, execute_round :161-184)
-        ugCheck(ug_dvec_upload(d_.w, signals.data(), M));
+        ugCheck(ug_dvec_upload(d_.w, signals0, M));
         ugCheck(ug_dvec_gather(d_.aux, d_.w, roundIdx_.data(), roundIdx_.size()));
         ugCheck(ug_schedule_build(d_.saux, d_.aux, 0, roundIdx_.size()));
         uint8_t commitRec[64];
@@ -407,11 +409,17 @@ public:
         for (int i = 0; i < 32; i++) chw[7 - (i >> 2)] |= (u32)ch[i] << (24 - 8 * (i & 3));
         Fr rand = from_normal<FrParams>(chw);              // reduces values >= r, like fromMpz + toMontgomery
 
-        // ---- lookup signals (compute_lookup :62-106): batched inversion instead of one GMP call each
-        computeLookup(signals, chunks, freq, wIdx, pIdx, rand);
+        // ---- lookup signals (compute_lookup :62-106): batched inversion instead of one GMP call each; the new
+        // values are scattered into the device copy of the witness (last write wins, as in the reference's loop)
+        std::vector<uint32_t> patchIdx;
+        std::vector<uint8_t> patchVal;
+        computeLookup(patchIdx, patchVal, chunks, freq, wIdx, pIdx, rand);
+        ugCheck(ug_dvec_scatter(d_.w, patchIdx.data(), patchVal.data(), patchIdx.size()));
+        std::vector<uint8_t> publicPart(signals0, signals0 + ((size_t)hdr_.nPublic + 1) * 32);
+        for (size_t i = 0; i < patchIdx.size(); i++)
+            if (patchIdx[i] <= hdr_.nPublic) memcpy(publicPart.data() + (size_t)patchIdx[i] * 32, patchVal.data() + i * 32, 32);
 
         // ---- final round (execute_final_round :187-399)
-        ugCheck(ug_dvec_upload(d_.w, signals.data(), M));
         ugCheck(ug_schedule_build(d_.sw, d_.w, 0, M));
         uint8_t sums[UG_GROTH16_PARTIALS_SIZE];
         ugCheck(ug_msm_g1(d_.ctx, d_.A, d_.sw, 0, sums));                                   // MSM1 :201
@@ -433,7 +441,7 @@ public:
         // keys pi_a, pi_b, pi_f, pi_r, protocol (src/ultra_groth.cpp:476-513)
         proof = "{\"pi_a\":" + g1Json(A) + ",\"pi_b\":" + g2Json(B) + ",\"pi_f\":" + g1Json(C) + ",\"pi_r\":" + g1Json(commitRec) +
                 ",\"protocol\":\"ultragroth\"}";
-        pub = publicJson(signals.data(), hdr_.nPublic, hdr_.randIndx);                      // prover.cpp:89-105
+        pub = publicJson(publicPart.data(), hdr_.nPublic, hdr_.randIndx);                   // prover.cpp:89-105
         totalMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 
@@ -448,8 +456,10 @@ public:
 
 private:
     static void putPlain(uint8_t* dst, const Fr& v) { u32 w[8]; to_normal(w, v); memcpy(dst, w, 32); }
-    void computeLookup(std::vector<uint8_t>& signals, const std::vector<uint32_t>& chunks, const std::vector<uint32_t>& freq,
-                       const std::vector<uint32_t>& wIdx, const std::vector<uint32_t>& pIdx, const Fr& rand) {
+    // produces the (witness index, value) patches of compute_lookup; duplicate targets keep the LAST write
+    void computeLookup(std::vector<uint32_t>& patchIdx, std::vector<uint8_t>& patchVal, const std::vector<uint32_t>& chunks,
+                       const std::vector<uint32_t>& freq, const std::vector<uint32_t>& wIdx, const std::vector<uint32_t>& pIdx,
+                       const Fr& rand) {
         const size_t L = freq.size(), Cn = chunks.size();
         // push_vector = [rand | inv1 (chunks) | inv2 (lookup) | prod (lookup)], plain integers
         std::vector<uint8_t> push((2 * L + Cn + 1) * 32);
@@ -480,15 +490,29 @@ private:
             memcpy(inv1 + j * 32, inv2 + (size_t)chunks[j] * 32, 32);
         }
         const size_t total = 2 * L + Cn + 1;
+        // keep, for every target index, only its last assignment (the reference applies them in order)
+        if (lastPos_.size() != hdr_.nVars) lastPos_.assign(hdr_.nVars, UINT32_MAX);
         for (size_t i = 0; i < wIdx.size(); i++) {
-            if (wIdx[i] >= hdr_.nVars || pIdx[i] >= total) throw std::range_error("uwtns: lookup index out of range");
-            memcpy(signals.data() + (size_t)wIdx[i] * 32, push.data() + (size_t)pIdx[i] * 32, 32);
+            if (wIdx[i] >= hdr_.nVars || pIdx[i] >= total) {
+                for (size_t k = 0; k < i; k++) lastPos_[wIdx[k]] = UINT32_MAX;
+                throw std::range_error("uwtns: lookup index out of range");
+            }
+            lastPos_[wIdx[i]] = (uint32_t)i;
         }
+        patchIdx.clear(); patchVal.clear();
+        patchIdx.reserve(wIdx.size()); patchVal.reserve(wIdx.size() * 32);
+        for (size_t i = 0; i < wIdx.size(); i++) {
+            if (lastPos_[wIdx[i]] != (uint32_t)i) continue;
+            patchIdx.push_back(wIdx[i]);
+            const uint8_t* src = push.data() + (size_t)pIdx[i] * 32;
+            patchVal.insert(patchVal.end(), src, src + 32);
+        }
+        for (size_t i = 0; i < wIdx.size(); i++) lastPos_[wIdx[i]] = UINT32_MAX;     // leave the scratch clean
     }
 
     ZkeyHeader hdr_;
     std::vector<uint8_t> vk_;
-    std::vector<uint32_t> roundIdx_, finalIdx_;
+    std::vector<uint32_t> roundIdx_, finalIdx_, lastPos_;
     DeviceProver d_;
     double msmMs_ = 0, fftMs_ = 0, totalMs_ = 0;
 };

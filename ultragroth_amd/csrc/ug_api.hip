@@ -168,6 +168,23 @@ int ug_dvec_gather(ug_dvec* out, const ug_dvec* src, const uint32_t* host_index,
     hipFree(idx);
     UG_CATCH
 }
+int ug_dvec_scatter(ug_dvec* dst, const uint32_t* host_index, const void* host_values, uint64_t n) {
+    UG_TRY
+    if (!dst || ((!host_index || !host_values) && n)) throw std::invalid_argument("null argument");
+    ug_ctx* c = dst->ctx;
+    c->use();
+    u32 *idx = nullptr, *val = nullptr;
+    UG_HIP(hipMalloc(&idx, n ? (size_t)n * 4 : 4));
+    UG_HIP(hipMalloc(&val, n ? (size_t)n * 32 : 32));
+    if (n) {
+        UG_HIP(hipMemcpyAsync(idx, host_index, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        UG_HIP(hipMemcpyAsync(val, host_values, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    }
+    scatter_elements(dst->data, idx, val, n, dst->n, c->stream);
+    UG_HIP(hipStreamSynchronize(c->stream));
+    hipFree(idx); hipFree(val);
+    UG_CATCH
+}
 uint64_t ug_dvec_size(const ug_dvec* v) { return v ? v->n : 0; }
 void ug_dvec_destroy(ug_dvec* v) {
     if (!v) return;
