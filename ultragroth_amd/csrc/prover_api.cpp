@@ -265,14 +265,30 @@ public:
     void run(uint8_t* partials) {
         if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
         ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1));
-        ugCheck(ug_schedule_build(d_.sw, d_.w, wr_.lo, wr_.hi - wr_.lo));
-        ugCheck(ug_msm_g1(d_.ctx, d_.A, d_.sw, 0, partials));                                  // S1  :55
-        ugCheck(ug_msm_g1(d_.ctx, d_.B1, d_.sw, 0, partials + 64));                            // S2  :58
-        ugCheck(ug_msm_g2(d_.ctx, d_.B2, d_.sw, 0, partials + 128));                           // S3  :61
-        ugCheck(ug_msm_g1(d_.ctx, d_.C, d_.sw, (int64_t)hdr_.nPublic + 1, partials + 256));    // S4  :64
+        // A schedule holds at most 2^31 (scalar, window) entries; ranges above MAX_RANGE scalars (only the
+        // reference's largest legal domain, 2^27, needs it) are proved in pieces whose partial sums are added.
+        memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
+        uint8_t part[UG_GROTH16_PARTIALS_SIZE];
+        for (uint64_t lo = wr_.lo; lo < wr_.hi; lo += MAX_RANGE) {
+            uint64_t n = std::min<uint64_t>(MAX_RANGE, wr_.hi - lo);
+            uint8_t* out = (lo == wr_.lo) ? partials : part;
+            memset(part, 0, sizeof part);
+            ugCheck(ug_schedule_build(d_.sw, d_.w, lo, n));
+            ugCheck(ug_msm_g1(d_.ctx, d_.A, d_.sw, 0, out));                                   // S1  :55
+            ugCheck(ug_msm_g1(d_.ctx, d_.B1, d_.sw, 0, out + 64));                             // S2  :58
+            ugCheck(ug_msm_g2(d_.ctx, d_.B2, d_.sw, 0, out + 128));                            // S3  :61
+            ugCheck(ug_msm_g1(d_.ctx, d_.C, d_.sw, (int64_t)hdr_.nPublic + 1, out + 256));     // S4  :64
+            if (out == part && ug_groth16_partials_add(partials, part) != PROVER_OK) throw std::runtime_error("partial sum failed");
+        }
         ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                              // S5-S9 :66-148
-        ugCheck(ug_schedule_build(d_.sh, d_.h, hr_.lo, hr_.hi - hr_.lo));
-        ugCheck(ug_msm_g1(d_.ctx, d_.H, d_.sh, 0, partials + 320));                            // S10 :154
+        for (uint64_t lo = hr_.lo; lo < hr_.hi; lo += MAX_RANGE) {
+            uint64_t n = std::min<uint64_t>(MAX_RANGE, hr_.hi - lo);
+            uint8_t* out = (lo == hr_.lo) ? partials : part;
+            memset(part, 0, sizeof part);
+            ugCheck(ug_schedule_build(d_.sh, d_.h, lo, n));
+            ugCheck(ug_msm_g1(d_.ctx, d_.H, d_.sh, 0, out + 320));                             // S10 :154
+            if (out == part && ug_groth16_partials_add(partials, part) != PROVER_OK) throw std::runtime_error("partial sum failed");
+        }
         ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
     }
 
@@ -305,6 +321,7 @@ public:
     ug_ctx* ctx() override { return d_.ctx; }
 
 private:
+    static constexpr uint64_t MAX_RANGE = (uint64_t)1 << 26;       // 2^26 scalars * <= 16 windows < 2^31 entries
     int rank_, count_;
     ZkeyHeader hdr_;
     std::vector<uint8_t> vk_, publicPart_;
