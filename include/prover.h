@@ -132,6 +132,20 @@ int ug_groth16_prover_load_witness(void *prover_object, const void *wtns_buffer,
 /* device part of the prove on the resident witness: the five MSMs over this rank's slice + H polynomial */
 int ug_groth16_prover_run(void *prover_object, void *partials_out,
                           char *error_msg, unsigned long long error_msg_maxsize);
+/* The same device part in phases, so that ranks can split the H-polynomial block (three independent
+ * iFFT/twist/FFT chains) instead of replicating it:
+ *   run_witness_msm   A, B1, B2, C partial sums over this rank's slice (H record left at infinity)
+ *   hpoly_chain       coset evaluations of polynomial `which` (0,1,2) into a device buffer of domainSize * 32 bytes
+ *   h_range           [first, first + count): the slice of h this rank multiplies
+ *   hpoly_combine     device buffers holding this rank's slice of the three evaluation vectors -> h slice
+ *   run_h_msm         H partial sum over this rank's slice (other records at infinity)
+ * Device pointers are raw HIP device addresses (e.g. torch.Tensor.data_ptr()) on the prover's device. */
+int ug_groth16_prover_run_witness_msm(void *prover_object, void *partials_out, char *error_msg, unsigned long long error_msg_maxsize);
+int ug_groth16_prover_hpoly_chain(void *prover_object, int which, void *device_out, char *error_msg, unsigned long long error_msg_maxsize);
+int ug_groth16_prover_h_range(void *prover_object, unsigned long long *first, unsigned long long *count, unsigned long long *domain_size);
+int ug_groth16_prover_hpoly_combine(void *prover_object, void *device_a, void *device_b, void *device_c,
+                                    char *error_msg, unsigned long long error_msg_maxsize);
+int ug_groth16_prover_run_h_msm(void *prover_object, void *partials_out, char *error_msg, unsigned long long error_msg_maxsize);
 int ug_groth16_partials_add(void *partials_acc, const void *partials_other);
 /* blinding + JSON from summed partials (host only) */
 int ug_groth16_prover_finish(void *prover_object, const void *partials_sum,

@@ -79,6 +79,8 @@ int  ug_dvec_gather(ug_dvec* out, const ug_dvec* src, const uint32_t* host_index
 /* dst[index[i]] = values[i] for i < n; indices must be distinct (UltraGroth lookup signals written back into the
  * witness, src/ultra_groth.cpp:99-105) */
 int  ug_dvec_scatter(ug_dvec* dst, const uint32_t* host_index, const void* host_values, uint64_t n);
+/* non-owning view of n 32-byte elements already in device memory (e.g. a torch / RCCL buffer) */
+int  ug_dvec_wrap(ug_ctx* ctx, void* device_ptr, uint64_t n, ug_dvec** out);
 uint64_t ug_dvec_size(const ug_dvec* v);
 void ug_dvec_destroy(ug_dvec* v);
 
@@ -100,6 +102,13 @@ int  ug_hpoly_create(ug_ctx* ctx, const void* host_coefs, uint64_t n_coefs, uint
                      uint32_t n_vars, ug_hpoly** out);
 /* h (domain_size plain integers) from the witness (n_vars plain integers), all on the device */
 int  ug_hpoly_run(ug_hpoly* hp, const ug_dvec* witness, ug_dvec* h_out);
+/* The same block in two steps, for a prover sharded over GPUs: ug_hpoly_chain computes the coset evaluations of
+ * ONE of the three polynomials (which = 0: A.w, 1: B.w, 2: (A.w) o (B.w)) -- ranks take different polynomials and
+ * exchange slices -- and ug_hpoly_combine turns matching slices of the three vectors into h[first, first+count).
+ * The evaluation vectors are in the library's device form and only meaningful to this library. */
+int  ug_hpoly_chain(ug_hpoly* hp, const ug_dvec* witness, int which, ug_dvec* out_evals);
+int  ug_hpoly_combine(ug_hpoly* hp, const ug_dvec* a, const ug_dvec* b, const ug_dvec* c, uint64_t first, uint64_t count,
+                      ug_dvec* h_out);
 /* optional: also return the three coset evaluation vectors (reference Montgomery form), for tests */
 int  ug_hpoly_debug_abc(ug_hpoly* hp, void* host_a, void* host_b, void* host_c);
 void ug_hpoly_destroy(ug_hpoly* hp);

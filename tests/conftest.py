@@ -40,6 +40,14 @@ def fixed_rs():
 
 @pytest.fixture(scope="session")
 def device():
+    # torch bundles its own HIP runtime: when a test uses both, torch must initialise first (as bench.py does),
+    # otherwise torch finds the runtime already loaded by libultragroth_hip.so and reports no GPUs
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
     import ultragroth_amd as ug
     d = ug.Device(0)
     yield d

@@ -111,6 +111,43 @@ def test_sharded_prover_equals_unsharded(device, zkey, wtns):
         p.close()
 
 
+def test_sharded_prover_with_split_hpoly(device):
+    """the N > 1 path with the H-polynomial chains split over ranks (as bench.py does over RCCL), on one GPU:
+    rank k mod 2 computes chain k into a device buffer, each rank combines its slices, proofs match the oracle"""
+    import torch
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, wtns, info = synth.build_circuit(device, 13, mix="C")
+    world, n_dom = 2, info["domainSize"]
+    sl = n_dom // world
+    ranks = [ug.ShardedGroth16Prover(zkey, 0, k, world) for k in range(world)]
+    for p in ranks:
+        p.load_witness(wtns)
+    parts = [p.run_witness_msm() for p in ranks]
+    full = torch.empty((3, n_dom, 32), dtype=torch.uint8, device="cuda")
+    for k in range(3):
+        ranks[k % world].hpoly_chain(k, full[k].data_ptr())
+    torch.cuda.synchronize()
+    total = None
+    for r, p in enumerate(ranks):
+        assert p.h_range() == (r * sl, sl, n_dom)
+        sl_bufs = [full[k, r * sl:(r + 1) * sl].contiguous() for k in range(3)]
+        torch.cuda.synchronize()
+        p.hpoly_combine(*(b.data_ptr() for b in sl_bufs))
+        part = parts[r][:320] + p.run_h_msm()[320:384]
+        total = part if total is None else ug.ShardedGroth16Prover.add_partials(total, part)
+    r_, s_ = fixed_rs()
+    ug.set_test_blinding(r_ + s_)
+    try:
+        proof, pub = ranks[0].finish(total)
+    finally:
+        ug.set_test_blinding(b"")
+    exp = O.groth16_prove(zkey, wtns, int.from_bytes(r_, "little"), int.from_bytes(s_, "little"))
+    assert (proof, pub) == (exp[0], exp[1])
+    for p in ranks:
+        p.close()
+
+
 def test_api_errors_on_device(zkey, wtns):
     import ultragroth_amd as ug
     with ug.Groth16Prover(zkey) as p:

@@ -197,6 +197,35 @@ class ShardedGroth16Prover:
             raise ProverError(rc, err.value.decode(errors="replace"))
         return out.raw
 
+    def _phase(self, name, *args):
+        out = C.create_string_buffer(GROTH16_PARTIALS_SIZE)
+        err = C.create_string_buffer(1024)
+        rc = getattr(load(), name)(self._h, *args, *([out] if name.endswith("_msm") else []), err, len(err) - 1)
+        if rc != PROVER_OK:
+            raise ProverError(rc, err.value.decode(errors="replace"))
+        return out.raw
+
+    def run_witness_msm(self):
+        """A, B1, B2, C partial sums of this rank (H record at infinity)"""
+        return self._phase("ug_groth16_prover_run_witness_msm")
+
+    def run_h_msm(self):
+        """H partial sum of this rank from the h slice on the device (other records at infinity)"""
+        return self._phase("ug_groth16_prover_run_h_msm")
+
+    def hpoly_chain(self, which, device_ptr):
+        """coset evaluations of polynomial `which` (0: A.w, 1: B.w, 2: their product) into device memory"""
+        self._phase("ug_groth16_prover_hpoly_chain", which, C.c_void_p(device_ptr))
+
+    def hpoly_combine(self, ptr_a, ptr_b, ptr_c):
+        """this rank's slices of the three evaluation vectors (device pointers) -> its slice of h"""
+        self._phase("ug_groth16_prover_hpoly_combine", C.c_void_p(ptr_a), C.c_void_p(ptr_b), C.c_void_p(ptr_c))
+
+    def h_range(self):
+        a, b, c = C.c_ulonglong(), C.c_ulonglong(), C.c_ulonglong()
+        load().ug_groth16_prover_h_range(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
     @staticmethod
     def add_partials(acc, other):
         a = C.create_string_buffer(bytes(acc), GROTH16_PARTIALS_SIZE)

@@ -14,10 +14,10 @@ LIB_PATH = os.path.join(_CSRC, "libultragroth_hip.so")
 INNER_SYMBOLS = [
     "ug_last_error", "ug_device_count", "ug_ctx_create", "ug_ctx_destroy", "ug_ctx_sync",
     "ug_bases_create_g1", "ug_bases_create_g2", "ug_bases_destroy",
-    "ug_dvec_create", "ug_dvec_upload", "ug_dvec_download", "ug_dvec_gather", "ug_dvec_scatter", "ug_dvec_size", "ug_dvec_destroy",
+    "ug_dvec_create", "ug_dvec_upload", "ug_dvec_download", "ug_dvec_gather", "ug_dvec_scatter", "ug_dvec_wrap", "ug_dvec_size", "ug_dvec_destroy",
     "ug_schedule_create", "ug_schedule_build", "ug_schedule_destroy",
     "ug_msm_g1", "ug_msm_g2",
-    "ug_hpoly_create", "ug_hpoly_run", "ug_hpoly_debug_abc", "ug_hpoly_destroy",
+    "ug_hpoly_create", "ug_hpoly_run", "ug_hpoly_chain", "ug_hpoly_combine", "ug_hpoly_debug_abc", "ug_hpoly_destroy",
     "ug_fr_ntt", "ug_field_op", "ug_synth_points", "ug_ctx_timings", "ug_ctx_kernel_stats",
 ]
 OUTER_SYMBOLS = [
@@ -33,6 +33,8 @@ OUTER_SYMBOLS = [
     "ug_test_set_blinding", "ug_prover_last_timings", "ug_prover_kernel_stats",
     "ug_groth16_prover_create_sharded", "ug_groth16_prover_load_witness", "ug_groth16_prover_run",
     "ug_groth16_partials_add", "ug_groth16_prover_finish",
+    "ug_groth16_prover_run_witness_msm", "ug_groth16_prover_run_h_msm", "ug_groth16_prover_hpoly_chain",
+    "ug_groth16_prover_hpoly_combine", "ug_groth16_prover_h_range",
 ]
 
 
@@ -70,6 +72,7 @@ def load():
     L.ug_dvec_download.argtypes = [vp, vp, u64, u64]
     L.ug_dvec_gather.argtypes = [vp, vp, vp, u64]
     L.ug_dvec_scatter.argtypes = [vp, vp, vp, u64]
+    L.ug_dvec_wrap.argtypes = [vp, vp, u64, pp]
     L.ug_dvec_size.argtypes = [vp]; L.ug_dvec_size.restype = u64
     L.ug_dvec_destroy.argtypes = [vp]; L.ug_dvec_destroy.restype = None
     L.ug_schedule_create.argtypes = [vp, pp]
@@ -79,6 +82,8 @@ def load():
     L.ug_msm_g2.argtypes = [vp, vp, vp, i64, vp]
     L.ug_hpoly_create.argtypes = [vp, vp, u64, u32, u32, pp]
     L.ug_hpoly_run.argtypes = [vp, vp, vp]
+    L.ug_hpoly_chain.argtypes = [vp, vp, C.c_int, vp]
+    L.ug_hpoly_combine.argtypes = [vp, vp, vp, vp, u64, u64, vp]
     L.ug_hpoly_debug_abc.argtypes = [vp, vp, vp, vp]
     L.ug_hpoly_destroy.argtypes = [vp]; L.ug_hpoly_destroy.restype = None
     L.ug_fr_ntt.argtypes = [vp, vp, C.c_int, C.c_int]
@@ -112,6 +117,11 @@ def load():
     L.ug_groth16_prover_load_witness.argtypes = [vp, vp, ull, vp, ull]
     L.ug_groth16_prover_run.argtypes = [vp, vp, vp, ull]
     L.ug_groth16_partials_add.argtypes = [vp, vp]
+    L.ug_groth16_prover_run_witness_msm.argtypes = [vp, vp, vp, ull]
+    L.ug_groth16_prover_run_h_msm.argtypes = [vp, vp, vp, ull]
+    L.ug_groth16_prover_hpoly_chain.argtypes = [vp, C.c_int, vp, vp, ull]
+    L.ug_groth16_prover_hpoly_combine.argtypes = [vp, vp, vp, vp, vp, ull]
+    L.ug_groth16_prover_h_range.argtypes = [vp, pull, pull, pull]
     L.ug_groth16_prover_finish.argtypes = [vp, vp, vp, pull, vp, pull, vp, ull]
     _lib = L
     return L

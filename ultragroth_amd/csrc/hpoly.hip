@@ -50,9 +50,10 @@ __global__ void row_ptr_kernel(const u32* keys, u64 ncoefs, u32 nrows, u32* row_
 }
 
 __global__ __launch_bounds__(256) void matvec_kernel(u32* a_br, u32* b_br, const u32* row_ptr, const u32* sig,
-                                                     const u32* val, const u32* wtns, u32 domain, int logn) {
+                                                     const u32* val, const u32* wtns, u32 domain, int logn, int mask) {
     u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= 2 * domain) return;
+    if (!((mask >> (r >= domain ? 1 : 0)) & 1)) return;        // bit 0: rows of A, bit 1: rows of B
     u32 s = row_ptr[r], e = row_ptr[r + 1];
     Fr acc = fp_zero<FrParams>();
     u32 since = 0;
@@ -185,9 +186,9 @@ void CoefMatrix::release() {
     row_ptr = sig = val = nullptr;
 }
 
-void coef_matvec(u32* a_br, u32* b_br, const CoefMatrix& m, const u32* wtns_dev, hipStream_t stream) {
+void coef_matvec(u32* a_br, u32* b_br, const CoefMatrix& m, const u32* wtns_dev, int mask, hipStream_t stream) {
     hipLaunchKernelGGL(matvec_kernel, dim3(grid_for((u64)2 * m.domain, 256)), dim3(256), 0, stream,
-                       a_br, b_br, m.row_ptr, m.sig, m.val, wtns_dev, m.domain, m.logn);
+                       a_br, b_br, m.row_ptr, m.sig, m.val, wtns_dev, m.domain, m.logn, mask);
     UG_KERNEL_CHECK();
 }
 void fr_mul_pointwise(u32* out, const u32* x, const u32* y, u64 n, hipStream_t stream) {

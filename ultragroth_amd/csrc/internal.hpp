@@ -114,7 +114,7 @@ struct CoefMatrix {
 };
 
 // a_br[bitrev(c)] = sum coef * w  over m = 0 rows, b_br likewise for m = 1 (device form, packed)
-void coef_matvec(u32* a_br, u32* b_br, const CoefMatrix& m, const u32* wtns_dev, hipStream_t stream);
+void coef_matvec(u32* a_br, u32* b_br, const CoefMatrix& m, const u32* wtns_dev, int mask, hipStream_t stream);   // mask bit 0: A rows, bit 1: B rows
 // out[i] = x[i] * y[i]
 void fr_mul_pointwise(u32* out, const u32* x, const u32* y, u64 n, hipStream_t stream);
 // h[i] = plain integer of (a[i] * b[i] - c[i])      (src/groth16.cpp:142-148)

@@ -261,10 +261,10 @@ public:
         witnessLoaded_ = true;
     }
 
-    // S1-S10 on this rank's slices; partials = A | B1 | B2 | C | H affine records
-    void run(uint8_t* partials) {
+    // S1-S4 on this rank's slice; partials = A | B1 | B2 | C | H affine records (H left at infinity)
+    void runWitnessMsm(uint8_t* partials, bool resetTimers = true) {
         if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
-        ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1));
+        if (resetTimers) ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1));
         // A schedule holds at most 2^31 (scalar, window) entries; ranges above MAX_RANGE scalars (only the
         // reference's largest legal domain, 2^27, needs it) are proved in pieces whose partial sums are added.
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
@@ -280,7 +280,12 @@ public:
             ugCheck(ug_msm_g1(d_.ctx, d_.C, d_.sw, (int64_t)hdr_.nPublic + 1, out + 256));     // S4  :64
             if (out == part && ug_groth16_partials_add(partials, part) != PROVER_OK) throw std::runtime_error("partial sum failed");
         }
-        ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                              // S5-S9 :66-148
+        ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
+    }
+    // S10 on this rank's slice of h (which must be in d_.h); only the H record of partials is written
+    void runHMsm(uint8_t* partials) {
+        memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
+        uint8_t part[UG_GROTH16_PARTIALS_SIZE];
         for (uint64_t lo = hr_.lo; lo < hr_.hi; lo += MAX_RANGE) {
             uint64_t n = std::min<uint64_t>(MAX_RANGE, hr_.hi - lo);
             uint8_t* out = (lo == hr_.lo) ? partials : part;
@@ -290,6 +295,40 @@ public:
             if (out == part && ug_groth16_partials_add(partials, part) != PROVER_OK) throw std::runtime_error("partial sum failed");
         }
         ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
+    }
+    void hpolyChain(int which, void* deviceOut) {
+        if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
+        ug_dvec* v = nullptr;
+        ugCheck(ug_dvec_wrap(d_.ctx, deviceOut, hdr_.domainSize, &v));
+        int rc = ug_hpoly_chain(d_.hp, d_.w, which, v);
+        ug_dvec_destroy(v);
+        ugCheck(rc);
+        ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
+    }
+    void hpolyCombine(void* da, void* db, void* dc) {
+        uint64_t cnt = hr_.hi - hr_.lo;
+        ug_dvec *a = nullptr, *b = nullptr, *c = nullptr;
+        ugCheck(ug_dvec_wrap(d_.ctx, da, cnt, &a));
+        ugCheck(ug_dvec_wrap(d_.ctx, db, cnt, &b));
+        ugCheck(ug_dvec_wrap(d_.ctx, dc, cnt, &c));
+        int rc = ug_hpoly_combine(d_.hp, a, b, c, hr_.lo, cnt, d_.h);
+        ug_dvec_destroy(a); ug_dvec_destroy(b); ug_dvec_destroy(c);
+        ugCheck(rc);
+        ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
+    }
+    void hRange(unsigned long long* first, unsigned long long* count, unsigned long long* domain) const {
+        if (first) *first = hr_.lo;
+        if (count) *count = hr_.hi - hr_.lo;
+        if (domain) *domain = hdr_.domainSize;
+    }
+
+    // S1-S10 on this rank's slices with the H-polynomial block computed locally (replicated when sharded)
+    void run(uint8_t* partials) {
+        runWitnessMsm(partials);
+        ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                              // S5-S9 :66-148
+        uint8_t hpart[UG_GROTH16_PARTIALS_SIZE];
+        runHMsm(hpart);
+        memcpy(partials + 320, hpart + 320, 64);
     }
 
     void finish(const uint8_t* sums, std::string& proof, std::string& pub) {
@@ -735,6 +774,36 @@ int ug_groth16_prover_run(void* prover_object, void* partials_out, char* error_m
     if (partials_out == NULL) throw std::invalid_argument("Null partials buffer");
     static_cast<Groth16Prover*>(static_cast<ProverBase*>(prover_object))->run(static_cast<uint8_t*>(partials_out));
     API_CATCH
+}
+int ug_groth16_prover_run_witness_msm(void* prover_object, void* partials_out, char* error_msg, unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL || partials_out == NULL) throw std::invalid_argument("Null argument");
+    static_cast<Groth16Prover*>(static_cast<ProverBase*>(prover_object))->runWitnessMsm(static_cast<uint8_t*>(partials_out));
+    API_CATCH
+}
+int ug_groth16_prover_run_h_msm(void* prover_object, void* partials_out, char* error_msg, unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL || partials_out == NULL) throw std::invalid_argument("Null argument");
+    static_cast<Groth16Prover*>(static_cast<ProverBase*>(prover_object))->runHMsm(static_cast<uint8_t*>(partials_out));
+    API_CATCH
+}
+int ug_groth16_prover_hpoly_chain(void* prover_object, int which, void* device_out, char* error_msg, unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL || device_out == NULL) throw std::invalid_argument("Null argument");
+    static_cast<Groth16Prover*>(static_cast<ProverBase*>(prover_object))->hpolyChain(which, device_out);
+    API_CATCH
+}
+int ug_groth16_prover_hpoly_combine(void* prover_object, void* device_a, void* device_b, void* device_c, char* error_msg,
+                                    unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL || !device_a || !device_b || !device_c) throw std::invalid_argument("Null argument");
+    static_cast<Groth16Prover*>(static_cast<ProverBase*>(prover_object))->hpolyCombine(device_a, device_b, device_c);
+    API_CATCH
+}
+int ug_groth16_prover_h_range(void* prover_object, unsigned long long* first, unsigned long long* count, unsigned long long* domain_size) {
+    if (prover_object == NULL) return PROVER_ERROR;
+    static_cast<Groth16Prover*>(static_cast<ProverBase*>(prover_object))->hRange(first, count, domain_size);
+    return PROVER_OK;
 }
 int ug_groth16_partials_add(void* partials_acc, const void* partials_other) {
     try {

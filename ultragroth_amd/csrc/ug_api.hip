@@ -35,7 +35,7 @@ struct ug_bases {
     ug_ctx* ctx; bool g2; u64 n; u64 global_first; u32* pts;
 };
 struct ug_dvec {
-    ug_ctx* ctx; u64 n; u32* data;
+    ug_ctx* ctx; u64 n; u32* data; bool owns;
 };
 struct ug_schedule {
     ug_ctx* ctx; MsmSchedule sched; u64 first = 0;
@@ -131,7 +131,7 @@ int ug_dvec_create(ug_ctx* c, uint64_t n, ug_dvec** out) {
     UG_TRY
     if (!c || !out) throw std::invalid_argument("null argument");
     c->use();
-    ug_dvec* v = new ug_dvec{c, n, nullptr};
+    ug_dvec* v = new ug_dvec{c, n, nullptr, true};
     UG_HIP(hipMalloc(&v->data, n ? (size_t)n * 32 : 32));
     *out = v;
     UG_CATCH
@@ -186,10 +186,16 @@ int ug_dvec_scatter(ug_dvec* dst, const uint32_t* host_index, const void* host_v
     UG_CATCH
 }
 uint64_t ug_dvec_size(const ug_dvec* v) { return v ? v->n : 0; }
+int ug_dvec_wrap(ug_ctx* c, void* device_ptr, uint64_t n, ug_dvec** out) {
+    UG_TRY
+    if (!c || !out || (!device_ptr && n)) throw std::invalid_argument("null argument");
+    if ((uintptr_t)device_ptr & 15) throw std::invalid_argument("device pointer must be 16-byte aligned");
+    *out = new ug_dvec{c, n, static_cast<u32*>(device_ptr), false};
+    UG_CATCH
+}
 void ug_dvec_destroy(ug_dvec* v) {
     if (!v) return;
-    hipSetDevice(v->ctx->device);
-    hipFree(v->data);
+    if (v->owns) { hipSetDevice(v->ctx->device); hipFree(v->data); }
     delete v;
 }
 
@@ -295,7 +301,7 @@ int ug_hpoly_run(ug_hpoly* hp, const ug_dvec* w, ug_dvec* h_out) {
     hipStream_t st = c->stream;
     u64 n = hp->domain;
     // S5-S6: a = A.w, b = B.w   (rows stored bit-reversed)            src/groth16.cpp:66-99
-    coef_matvec(hp->a, hp->b, hp->mat, w->data, st);
+    coef_matvec(hp->a, hp->b, hp->mat, w->data, 3, st);
     // S7: c = a o b                                                    :100-108
     fr_mul_pointwise(hp->c, hp->a, hp->b, n, st);
     // S8: ifft, twist by omega_2n^i (with 1/n folded in), fft          :110-140
@@ -306,6 +312,48 @@ int ug_hpoly_run(ug_hpoly* hp, const ug_dvec* w, ug_dvec* h_out) {
     }
     // S9: h = a o b - c, to plain integers                             :142-148
     fr_h_final(h_out->data, hp->a, hp->b, hp->c, n, st);
+    tm.stop();
+    UG_CATCH
+}
+
+// coset evaluations of one of the three polynomials (0 = A.w, 1 = B.w, 2 = (A.w) o (B.w)) into `out`
+// (domain elements, device form): the unit of work a rank of a sharded prover takes
+int ug_hpoly_chain(ug_hpoly* hp, const ug_dvec* w, int which, ug_dvec* out) {
+    UG_TRY
+    if (!hp || !w || !out) throw std::invalid_argument("null argument");
+    if (which < 0 || which > 2) throw std::invalid_argument("polynomial index out of range");
+    if (w->n < hp->nvars) throw std::invalid_argument("witness vector shorter than nVars");
+    if (out->n < hp->domain) throw std::invalid_argument("output vector shorter than the domain");
+    ug_ctx* c = hp->ctx;
+    c->use();
+    ScopedTimer tm(c, &c->fft_ms);
+    hipStream_t st = c->stream;
+    u64 n = hp->domain;
+    u32* src;
+    if (which == 2) {
+        coef_matvec(hp->a, hp->b, hp->mat, w->data, 3, st);
+        fr_mul_pointwise(hp->c, hp->a, hp->b, n, st);
+        src = hp->c;
+    } else {
+        coef_matvec(hp->a, hp->b, hp->mat, w->data, 1 << which, st);
+        src = which ? hp->b : hp->a;
+    }
+    hp->ntt.transform(hp->t, src, /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st);
+    hp->ntt.transform(out->data, hp->t, /*inverse*/ false, false, false, nullptr, nullptr, st);
+    tm.stop();
+    UG_CATCH
+}
+// h[first .. first + count) = plain(a o b - c) from the matching slices of the three coset evaluation vectors
+int ug_hpoly_combine(ug_hpoly* hp, const ug_dvec* a, const ug_dvec* b, const ug_dvec* cc, uint64_t first, uint64_t count,
+                     ug_dvec* h_out) {
+    UG_TRY
+    if (!hp || !a || !b || !cc || !h_out) throw std::invalid_argument("null argument");
+    if (a->n < count || b->n < count || cc->n < count) throw std::invalid_argument("slice vectors shorter than count");
+    if (first + count > h_out->n) throw std::invalid_argument("h slice outside the h vector");
+    ug_ctx* c = hp->ctx;
+    c->use();
+    ScopedTimer tm(c, &c->fft_ms);
+    fr_h_final(h_out->data + first * 8, a->data, b->data, cc->data, count, c->stream);
     tm.stop();
     UG_CATCH
 }
