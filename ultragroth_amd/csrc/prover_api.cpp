@@ -14,7 +14,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <exception>
 #include <string>
+#include <thread>
 #include <vector>
 #include "ec.hpp"
 #include "host_util.hpp"
@@ -172,6 +174,7 @@ Range shardRange(uint64_t n, int rank, int count) {
 // ---- common device-side state of a prover -------------------------------------------------------------------
 struct DeviceProver {
     ug_ctx* ctx = nullptr;
+    ug_ctx* ctx2 = nullptr;      // second stream (Groth16): the H-polynomial branch runs beside the witness MSMs
     ug_bases *A = nullptr, *B1 = nullptr, *B2 = nullptr, *C = nullptr, *H = nullptr, *roundC = nullptr;
     ug_hpoly* hp = nullptr;
     ug_dvec *w = nullptr, *h = nullptr, *aux = nullptr;
@@ -183,6 +186,7 @@ struct DeviceProver {
         ug_bases_destroy(A); ug_bases_destroy(B1); ug_bases_destroy(B2); ug_bases_destroy(C); ug_bases_destroy(H);
         ug_bases_destroy(roundC);
         ug_ctx_destroy(ctx);
+        ug_ctx_destroy(ctx2);
     }
 };
 
@@ -193,6 +197,13 @@ struct ProverBase {        // what the extern "C" layer stores behind the opaque
     virtual unsigned long long publicBufferMinSize() const = 0;
     virtual void timings(double* msm, double* fft, double* total) const = 0;
     virtual ug_ctx* ctx() = 0;
+    virtual int kernelStats(int g2, double* avgMs, unsigned long long* launches, unsigned long long* entries, int reset) {
+        uint64_t l = 0, e = 0;
+        int rc = ug_ctx_kernel_stats(ctx(), g2, avgMs, &l, &e, reset);
+        if (launches) *launches = l;
+        if (entries) *entries = e;
+        return rc;
+    }
 };
 
 const uint8_t* checkedSection(const BinFile& f, uint32_t id, uint64_t needBytes) {
@@ -238,12 +249,15 @@ public:
         ugCheck(ug_bases_create_g1(d_.ctx, pB1 + wr_.lo * 64, wr_.hi - wr_.lo, wr_.lo, &d_.B1));
         ugCheck(ug_bases_create_g2(d_.ctx, pB2 + wr_.lo * 128, wr_.hi - wr_.lo, wr_.lo, &d_.B2));
         ugCheck(ug_bases_create_g1(d_.ctx, pC + cLo * 64, cHi - cLo, cLo, &d_.C));
-        ugCheck(ug_bases_create_g1(d_.ctx, pH + hr_.lo * 64, hr_.hi - hr_.lo, hr_.lo, &d_.H));
-        ugCheck(ug_hpoly_create(d_.ctx, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
+        // the H branch (coefficient mat-vec, NTT chains, h schedule, H MSM) gets its own stream so that its
+        // memory-bound kernels (sort, transpose, gathers) overlap the integer-bound witness accumulations
+        ugCheck(ug_ctx_create(&d_.ctx2, device));
+        ugCheck(ug_bases_create_g1(d_.ctx2, pH + hr_.lo * 64, hr_.hi - hr_.lo, hr_.lo, &d_.H));
+        ugCheck(ug_hpoly_create(d_.ctx2, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
         ugCheck(ug_dvec_create(d_.ctx, M, &d_.w));
-        ugCheck(ug_dvec_create(d_.ctx, N, &d_.h));
+        ugCheck(ug_dvec_create(d_.ctx2, N, &d_.h));
         ugCheck(ug_schedule_create(d_.ctx, &d_.sw));
-        ugCheck(ug_schedule_create(d_.ctx, &d_.sh));
+        ugCheck(ug_schedule_create(d_.ctx2, &d_.sh));
     }
 
     const ZkeyHeader& header() const { return hdr_; }
@@ -264,7 +278,7 @@ public:
     // S1-S4 on this rank's slice; partials = A | B1 | B2 | C | H affine records (H left at infinity)
     void runWitnessMsm(uint8_t* partials, bool resetTimers = true) {
         if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
-        if (resetTimers) ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1));
+        if (resetTimers) { ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1)); ugCheck(ug_ctx_timings(d_.ctx2, nullptr, nullptr, 1)); }
         // A schedule holds at most 2^31 (scalar, window) entries; ranges above MAX_RANGE scalars (only the
         // reference's largest legal domain, 2^27, needs it) are proved in pieces whose partial sums are added.
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
@@ -280,7 +294,7 @@ public:
             ugCheck(ug_msm_g1(d_.ctx, d_.C, d_.sw, (int64_t)hdr_.nPublic + 1, out + 256));     // S4  :64
             if (out == part && ug_groth16_partials_add(partials, part) != PROVER_OK) throw std::runtime_error("partial sum failed");
         }
-        ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
+        collectTimings();
     }
     // S10 on this rank's slice of h (which must be in d_.h); only the H record of partials is written
     void runHMsm(uint8_t* partials) {
@@ -291,30 +305,36 @@ public:
             uint8_t* out = (lo == hr_.lo) ? partials : part;
             memset(part, 0, sizeof part);
             ugCheck(ug_schedule_build(d_.sh, d_.h, lo, n));
-            ugCheck(ug_msm_g1(d_.ctx, d_.H, d_.sh, 0, out + 320));                             // S10 :154
+            ugCheck(ug_msm_g1(d_.ctx2, d_.H, d_.sh, 0, out + 320));                            // S10 :154
             if (out == part && ug_groth16_partials_add(partials, part) != PROVER_OK) throw std::runtime_error("partial sum failed");
         }
-        ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
+        collectTimings();
+    }
+    void collectTimings() {
+        double m1 = 0, f1 = 0, m2 = 0, f2 = 0;
+        ugCheck(ug_ctx_timings(d_.ctx, &m1, &f1, 0));
+        ugCheck(ug_ctx_timings(d_.ctx2, &m2, &f2, 0));
+        msmMs_ = m1 + m2; fftMs_ = f1 + f2;      // device time per branch; the branches overlap in wall time
     }
     void hpolyChain(int which, void* deviceOut) {
         if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
         ug_dvec* v = nullptr;
-        ugCheck(ug_dvec_wrap(d_.ctx, deviceOut, hdr_.domainSize, &v));
+        ugCheck(ug_dvec_wrap(d_.ctx2, deviceOut, hdr_.domainSize, &v));
         int rc = ug_hpoly_chain(d_.hp, d_.w, which, v);
         ug_dvec_destroy(v);
         ugCheck(rc);
-        ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
+        collectTimings();
     }
     void hpolyCombine(void* da, void* db, void* dc) {
         uint64_t cnt = hr_.hi - hr_.lo;
         ug_dvec *a = nullptr, *b = nullptr, *c = nullptr;
-        ugCheck(ug_dvec_wrap(d_.ctx, da, cnt, &a));
-        ugCheck(ug_dvec_wrap(d_.ctx, db, cnt, &b));
-        ugCheck(ug_dvec_wrap(d_.ctx, dc, cnt, &c));
+        ugCheck(ug_dvec_wrap(d_.ctx2, da, cnt, &a));
+        ugCheck(ug_dvec_wrap(d_.ctx2, db, cnt, &b));
+        ugCheck(ug_dvec_wrap(d_.ctx2, dc, cnt, &c));
         int rc = ug_hpoly_combine(d_.hp, a, b, c, hr_.lo, cnt, d_.h);
         ug_dvec_destroy(a); ug_dvec_destroy(b); ug_dvec_destroy(c);
         ugCheck(rc);
-        ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
+        collectTimings();
     }
     void hRange(unsigned long long* first, unsigned long long* count, unsigned long long* domain) const {
         if (first) *first = hr_.lo;
@@ -322,13 +342,49 @@ public:
         if (domain) *domain = hdr_.domainSize;
     }
 
-    // S1-S10 on this rank's slices with the H-polynomial block computed locally (replicated when sharded)
+    // S1-S10 on this rank's slices with the H-polynomial block computed locally (replicated when sharded).
+    // With ULTRAGROTH_OVERLAP=1 two host threads drive two streams: S1-S4 on one, S5-S10 (H polynomial, its schedule,
+    // the H MSM) on the other, so the memory-bound kernels of one branch overlap the integer-bound kernels of the other
+    // (measured: 168 -> 162 ms per 2^24 proof). Off by default: overlapped kernels stretch each other, which blurs the
+    // per-kernel durations and the MSM | FFT split that bench.py and rocprof report.
     void run(uint8_t* partials) {
-        runWitnessMsm(partials);
-        ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                              // S5-S9 :66-148
+        if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
+        ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1));
+        ugCheck(ug_ctx_timings(d_.ctx2, nullptr, nullptr, 1));
         uint8_t hpart[UG_GROTH16_PARTIALS_SIZE];
-        runHMsm(hpart);
+        static const bool overlap = getenv("ULTRAGROTH_OVERLAP") && atoi(getenv("ULTRAGROTH_OVERLAP")) != 0;
+        if (!overlap) {
+            runWitnessMsm(partials, /*resetTimers*/ false);
+            ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                          // S5-S9 :66-148
+            runHMsm(hpart);                                                                    // S10   :154
+            memcpy(partials + 320, hpart + 320, 64);
+            collectTimings();
+            return;
+        }
+        std::exception_ptr hErr;
+        std::thread hBranch([&] {
+            try {
+                ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                      // S5-S9 :66-148
+                runHMsm(hpart);                                                                // S10   :154
+            } catch (...) { hErr = std::current_exception(); }
+        });
+        std::exception_ptr wErr;
+        try { runWitnessMsm(partials, /*resetTimers*/ false); } catch (...) { wErr = std::current_exception(); }
+        hBranch.join();
+        if (wErr) std::rethrow_exception(wErr);
+        if (hErr) std::rethrow_exception(hErr);
         memcpy(partials + 320, hpart + 320, 64);
+        collectTimings();
+    }
+    int kernelStats(int g2, double* avgMs, unsigned long long* launches, unsigned long long* entries, int reset) override {
+        double a1 = 0, a2 = 0;
+        uint64_t l1 = 0, l2 = 0, e1 = 0, e2 = 0;
+        if (ug_ctx_kernel_stats(d_.ctx, g2, &a1, &l1, &e1, reset) != UG_OK) return UG_ERROR;
+        if (ug_ctx_kernel_stats(d_.ctx2, g2, &a2, &l2, &e2, reset) != UG_OK) return UG_ERROR;
+        if (avgMs) *avgMs = (l1 + l2) ? (a1 * (double)l1 + a2 * (double)l2) / (double)(l1 + l2) : 0.0;
+        if (launches) *launches = l1 + l2;
+        if (entries) *entries = e1 + e2;
+        return UG_OK;
     }
 
     void finish(const uint8_t* sums, std::string& proof, std::string& pub) {
@@ -745,10 +801,7 @@ int ug_prover_last_timings(void* prover_object, double* msm_ms, double* fft_ms, 
 int ug_prover_kernel_stats(void* prover_object, int g2, double* accumulate_ms_avg, unsigned long long* launches,
                            unsigned long long* entries, int reset) {
     if (!prover_object) return PROVER_ERROR;
-    uint64_t l = 0, e = 0;
-    int rc = ug_ctx_kernel_stats(static_cast<ProverBase*>(prover_object)->ctx(), g2, accumulate_ms_avg, &l, &e, reset);
-    if (launches) *launches = l;
-    if (entries) *entries = e;
+    int rc = static_cast<ProverBase*>(prover_object)->kernelStats(g2, accumulate_ms_avg, launches, entries, reset);
     return rc == UG_OK ? PROVER_OK : PROVER_ERROR;
 }
 
