@@ -243,3 +243,50 @@ def test_full_size_ntt_round_trip_and_delta(device):
     w = O.root_of_unity(logn) * pow(R, -1, O.R_MOD) % O.R_MOD
     for k in (0, 1, 2, 12345, n // 2, n - 1):
         assert O.mont_decode(out[32 * k:32 * k + 32], O.R_MOD) == pow(w, k, O.R_MOD)
+
+
+def test_cli_prover_end_to_end(tmp_path, zkey, wtns, vkey):
+    """`prover <zkey> <wtns> <proof.json> <public.json>` (the reference's CLI contract, src/main_prover.cpp) with OS
+    entropy for the blinding: the files it writes pass the reference's acceptance test (pairing check)"""
+    import subprocess
+    from oracle import pairing
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "ultragroth_amd", "csrc", "prover")
+    golden = os.path.join(root, "tests", "golden")
+    proof_path, public_path = str(tmp_path / "proof.json"), str(tmp_path / "public.json")
+    r = subprocess.run([exe, os.path.join(golden, "circuit_final.zkey"), os.path.join(golden, "witness.wtns"), proof_path, public_path],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    proof, pub = open(proof_path).read(), open(public_path).read()
+    assert "\0" not in proof and pub == '["7713112592372404476342535432037683616424591277138491596200192981572885523208"]'
+    assert pairing.groth16_verify(vkey, pub, proof)
+    # wrong argument count and unreadable file: exit code 1 and the reference's messages
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage: prover <circuit.zkey> <witness.wtns> <proof.json> <public.json>" in r.stderr
+    r = subprocess.run([exe, "/nonexistent.zkey", "x", "y", "z"], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stderr.startswith("Error: ")
+    # the UltraGroth CLI rejects a Groth16 key with the reference's message
+    r = subprocess.run([exe + "_ultra_groth", os.path.join(golden, "circuit_final.zkey"), os.path.join(golden, "witness.wtns"),
+                        proof_path, public_path], capture_output=True, text=True)
+    assert r.returncode == 1 and "zkey file is not ultragroth" in r.stderr
+
+
+@pytest.mark.parametrize("log_domain,n_public", [(2, 1), (3, 0), (5, 3), (7, 1), (10, 0)])
+def test_tiny_circuits_and_public_counts(device, log_domain, n_public):
+    """smallest domains (single NTT pass, one segment, windows wider than the scalar count) and 0 / several public
+    signals: proof and public.json ("null" when empty, as nlohmann dumps an empty json) equal the oracle's"""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, wtns, info = synth.build_circuit(device, log_domain, mix="C", n_public=n_public, seed=0x5EED0100 + log_domain)
+    r, s = fixed_rs()
+    ug.set_test_blinding(r + s)
+    try:
+        proof, pub = ug.groth16_prover(zkey, wtns)
+    finally:
+        ug.set_test_blinding(b"")
+    exp = O.groth16_prove(zkey, wtns, int.from_bytes(r, "little"), int.from_bytes(s, "little"))
+    assert (proof, pub) == (exp[0], exp[1])
+    if n_public == 0:
+        assert pub == "null"
+    else:
+        assert len(json.loads(pub)) == n_public
