@@ -797,6 +797,15 @@ int ugo_num_threads(void) {
 #endif
 }
 
+/* cap the OpenMP team (bench.py: the box's CPU share may be smaller than the cores OpenMP sees) */
+void ugo_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* sum_i scalars[i] * (seed + i) mod r, plain integers in and out: the discrete log of an MSM over the
  * synthetic base points P_i = (seed + i) * G (ultragroth_amd/synth.py), for full-size checks in the exponent */
 void ugo_fr_dot_walk(uint64_t out[4], const uint8_t *scalars, uint64_t n, uint64_t seed) {

@@ -40,10 +40,18 @@ def g2_generator_record():
 SEEDS = {"A": 0x1000_0001, "B1": 0x2000_0003, "B2": 0x3000_0005, "C": 0x4000_0007, "H": 0x5000_0009, "VK": 0x77}
 
 
-def synth_points(dev, n, seed, g2=False):
-    """n zkey-format records (seed + i) * G, computed on the GPU"""
+def synth_points(dev, n, seed, g2=False, out=None):
+    """n zkey-format records (seed + i) * G, computed on the GPU; written into ``out`` (a writable buffer of exactly
+    n records) when given"""
     import ctypes as C
-    out = (C.c_char * (n * (128 if g2 else 64)))()
+    size = n * (128 if g2 else 64)
+    if n == 0:
+        return (C.c_char * 0)()
+    if out is None:
+        out = (C.c_char * size)()
+    else:
+        assert len(out) == size
+        out = (C.c_char * size).from_buffer(out)
     gen = g2_generator_record() if g2 else g1_generator_record()
     rc = dev._L.ug_synth_points(dev._h, 1 if g2 else 0, gen, seed, n, out)
     if rc != 0:
@@ -92,7 +100,10 @@ def _section(sid, payload):
 
 
 def build_circuit(dev, log_domain, mix="U", seed=0x5EED0000, n_public=1, g1_only=False):
-    """Returns (zkey_bytes, wtns_bytes, info). Sections are laid out as snarkjs does (1..10)."""
+    """Returns (zkey, wtns_bytes, info). Sections are laid out as snarkjs does (1..10). The zkey comes back as a
+    ctypes char array (buffer protocol, ``len``, accepted wherever the bindings take ``bytes``): every section is
+    generated in place, so the peak host footprint is one zkey (9.4 GB at 2^24), not two."""
+    import ctypes as C
     domain = 1 << log_domain
     nvars = domain - 1
     n_c = nvars - n_public - 1
@@ -102,32 +113,38 @@ def build_circuit(dev, log_domain, mix="U", seed=0x5EED0000, n_public=1, g1_only
     vk_g2 = bytes(synth_points(dev, 3, SEEDS["VK"], g2=True))           # beta2, gamma2, delta2
     header = struct.pack("<I", 32) + q_le + struct.pack("<I", 32) + r_le + struct.pack("<III", nvars, n_public, domain)
     header += vk_g1[0:64] + vk_g1[64:128] + vk_g2[0:128] + vk_g2[128:256] + vk_g1[128:192] + vk_g2[256:384]
+    n_coefs = 4 * domain
+    sizes = [(1, 4), (2, len(header)), (3, 64 * (n_public + 1)), (4, 4 + 44 * n_coefs), (5, 64 * nvars), (6, 64 * nvars),
+             (7, 128 * nvars), (8, 64 * n_c), (9, 64 * domain), (10, 0)]
+    total = 12 + sum(12 + sz for _, sz in sizes)
+    zkey = (C.c_char * total)()                                         # zero-filled
+    view = memoryview(zkey).cast("B")
+    view[0:12] = b"zkey" + struct.pack("<II", 1, len(sizes))
+    off, at = 12, {}
+    for sid, sz in sizes:
+        view[off:off + 12] = struct.pack("<IQ", sid, sz)
+        at[sid] = (off + 12, off + 12 + sz)
+        off += 12 + sz
+    view[at[1][0]:at[1][1]] = struct.pack("<I", 1)
+    view[at[2][0]:at[2][1]] = header
+    lo, hi = at[4]
+    view[lo:lo + 4] = struct.pack("<I", n_coefs)
     coefs = coefficients(domain, nvars, seed + 1)
-    parts = [b"zkey", struct.pack("<II", 1, 10), _section(1, struct.pack("<I", 1)), _section(2, header),
-             _section(3, bytes(64 * (n_public + 1)))]
-    parts.append(struct.pack("<IQ", 4, 4 + coefs.nbytes) + struct.pack("<I", len(coefs)))
-    parts.append(coefs.tobytes())
-    a = synth_points(dev, nvars, SEEDS["A"])
-    parts.append(struct.pack("<IQ", 5, len(a))); parts.append(a)
-    if g1_only:
-        # config 2 of BASELINE.json (G1 MSM + NTT only): B1, B2, C are all-infinity sets of the right size
-        b1 = bytes(64 * nvars); b2 = bytes(128 * nvars); c = bytes(64 * n_c)
-    else:
-        b1 = synth_points(dev, nvars, SEEDS["B1"])
-        b2 = synth_points(dev, nvars, SEEDS["B2"], g2=True)
-        c = synth_points(dev, n_c, SEEDS["C"])
-    parts.append(struct.pack("<IQ", 6, len(b1))); parts.append(b1)
-    parts.append(struct.pack("<IQ", 7, len(b2))); parts.append(b2)
-    parts.append(struct.pack("<IQ", 8, len(c))); parts.append(c)
-    h = synth_points(dev, domain, SEEDS["H"])
-    parts.append(struct.pack("<IQ", 9, len(h))); parts.append(h)
-    parts.append(_section(10, b""))
-    zkey = b"".join(bytes(p) if not isinstance(p, (bytes, bytearray)) else p for p in parts)
+    np.frombuffer(view[lo + 4:hi], dtype=coefs.dtype)[:] = coefs
+    del coefs
+    synth_points(dev, nvars, SEEDS["A"], out=view[at[5][0]:at[5][1]])
+    if not g1_only:
+        # (g1_only = config 2 of BASELINE.json, G1 MSM + NTT only: B1, B2, C stay all-infinity sets of the right size)
+        synth_points(dev, nvars, SEEDS["B1"], out=view[at[6][0]:at[6][1]])
+        synth_points(dev, nvars, SEEDS["B2"], g2=True, out=view[at[7][0]:at[7][1]])
+        synth_points(dev, n_c, SEEDS["C"], out=view[at[8][0]:at[8][1]])
+    synth_points(dev, domain, SEEDS["H"], out=view[at[9][0]:at[9][1]])
+    del view
     w = scalars(nvars, mix, seed + 2)
     w[0] = (1, 0, 0, 0)
     wtns = b"wtns" + struct.pack("<II", 2, 2) + _section(1, struct.pack("<I", 32) + r_le + struct.pack("<I", nvars))
     wtns += struct.pack("<IQ", 2, w.nbytes) + w.tobytes()
-    info = dict(domainSize=domain, nVars=nvars, nPublic=n_public, nCoefs=len(coefs), mix=mix, seed=seed, g1_only=g1_only)
+    info = dict(domainSize=domain, nVars=nvars, nPublic=n_public, nCoefs=n_coefs, mix=mix, seed=seed, g1_only=g1_only)
     return zkey, wtns, info
 
 
