@@ -68,6 +68,15 @@ int  ug_ctx_sync(ug_ctx* ctx);
  * sharded prover can hold a slice. */
 int  ug_bases_create_g1(ug_ctx* ctx, const void* host_points, uint64_t n, uint64_t global_first, ug_bases** out);
 int  ug_bases_create_g2(ug_ctx* ctx, const void* host_points, uint64_t n, uint64_t global_first, ug_bases** out);
+/* Fixed-base window tables (no reference counterpart: the zkey's points never change between proofs, and 288 GB of
+ * HBM holds them): extend the set by tables 2^(c j) * P_i, j = 1 .. ceil(255/c) - 1, c in [16, 24]. A schedule built
+ * with ug_schedule_build_tables(.., c) then puts every window digit into ONE bucket set. Fails (nothing changed)
+ * when device memory is short. ug_msm_table_window: the cost-model width for n scalars; ug_bases_tables_bytes: the
+ * additional device memory the tables take. */
+int      ug_msm_table_window(uint64_t n);
+uint64_t ug_bases_tables_bytes(uint64_t n, int g2, int c);
+int      ug_bases_precompute(ug_bases* b, int c);
+int      ug_ctx_mem_info(ug_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 void ug_bases_destroy(ug_bases* b);
 
 /* device vectors of n 32-byte elements */
@@ -88,6 +97,8 @@ void ug_dvec_destroy(ug_dvec* v);
  * digits grouped by bucket. One schedule serves every base set multiplied by the same scalars. */
 int  ug_schedule_create(ug_ctx* ctx, ug_schedule** out);
 int  ug_schedule_build(ug_schedule* s, const ug_dvec* scalars, uint64_t first, uint64_t count);
+/* the same for base sets that hold window tables of width c (ug_bases_precompute); count <= 2^27 */
+int  ug_schedule_build_tables(ug_schedule* s, const ug_dvec* scalars, uint64_t first, uint64_t count, int c);
 void ug_schedule_destroy(ug_schedule* s);
 
 /* out = sum over the schedule's scalars s_i (global index i) of s_i * P_{i - index_shift}; points whose

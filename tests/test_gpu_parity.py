@@ -128,6 +128,52 @@ def test_msm_g2_edge_scalars(device, zkey, n):
     assert device.msm_g2(pts, sc, n) == O.g2_msm(pts, sc, n)
 
 
+@pytest.mark.parametrize("n,c", [(1, 16), (5, 17), (1000, 16), (1000, 24)])
+def test_msm_window_tables_g1(device, zkey, n, c):
+    """fixed-base window tables (ug_bases_precompute + ug_schedule_build_tables): same sums as the oracle for edge
+    scalars, with points at infinity in the set (B1 of the fixture has three) and a classic schedule on the same bases"""
+    rng = random.Random(11 * n + c)
+    pts = _sec(zkey, "zkey", 6)[:64 * n]
+    sc = b"".join(O.to_le(v) for v in _scalar_mix(rng, n))
+    exp = O.g1_msm(pts, sc, n)
+    assert device.msm_g1(pts, sc, n, table_c=c) == exp
+    b = device.bases(pts, n, table_c=c)
+    v = device.dvec(n, sc)
+    assert device.msm(b, device.schedule(v, 0, n)) == exp                  # classic schedule reads table 0 only
+    # a sub-range of the scalars against the table set: indices line up through the schedule's first index
+    if n >= 1000:
+        lo, cnt = 137, 700
+        exp_sub = O.g1_msm(pts[64 * lo:64 * (lo + cnt)], sc[32 * lo:32 * (lo + cnt)], cnt)
+        assert device.msm(b, device.schedule(v, lo, cnt, table_c=c)) == exp_sub
+        # index shift, as the C section uses it: scalar i multiplies point i - 3
+        exp_shift = O.g1_msm(pts[:64 * (n - 3)], sc[32 * 3:], n - 3)
+        assert device.msm(b, device.schedule(v, 0, n, table_c=c), index_shift=3) == exp_shift
+
+
+@pytest.mark.parametrize("n,c", [(1, 16), (300, 18)])
+def test_msm_window_tables_g2(device, zkey, n, c):
+    rng = random.Random(13 * n + c)
+    pts = _sec(zkey, "zkey", 7)[:128 * n]
+    sc = b"".join(O.to_le(v) for v in _scalar_mix(rng, n))
+    assert device.msm_g2(pts, sc, n, table_c=c) == O.g2_msm(pts, sc, n)
+
+
+def test_msm_window_tables_errors(device, zkey):
+    pts = _sec(zkey, "zkey", 5)[:64 * 10]
+    sc = b"".join(O.to_le(i + 1) for i in range(10))
+    import ultragroth_amd as ug
+    with pytest.raises(ug.DeviceError, match="outside \\[16, 24\\]"):
+        device.bases(pts, 10, table_c=15)
+    b = device.bases(pts, 10)
+    v = device.dvec(10, sc)
+    with pytest.raises(ug.DeviceError, match="hold no tables"):
+        device.msm(b, device.schedule(v, 0, 10, table_c=16))
+    b16 = device.bases(pts, 10, table_c=16)
+    with pytest.raises(ug.DeviceError, match="tables of width 16"):
+        device.msm(b16, device.schedule(v, 0, 10, table_c=17))
+    assert 16 <= device.table_window(1 << 24) <= 24
+
+
 def test_hpoly_matches_oracle_and_known_answers(device, zkey, wtns):
     info = O.zkey_info(zkey)
     coefs = _sec(zkey, "zkey", 4)[4:]

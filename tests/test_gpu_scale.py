@@ -290,3 +290,53 @@ def test_tiny_circuits_and_public_counts(device, log_domain, n_public):
         assert pub == "null"
     else:
         assert len(json.loads(pub)) == n_public
+
+
+@pytest.mark.parametrize("tables", ["1", "0"])
+@pytest.mark.parametrize("log_domain,mix", [(15, "C"), (17, "U")])
+def test_created_prover_with_and_without_window_tables(device, monkeypatch, tables, log_domain, mix):
+    """a created prover builds fixed-base window tables (ULTRAGROTH_TABLES unset or 1) or runs the classic windows (0):
+    both give the oracle's proof, and proving twice on one prover gives the same proof"""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    monkeypatch.setenv("ULTRAGROTH_TABLES", tables)
+    zkey, wtns, info = synth.build_circuit(device, log_domain, mix=mix, seed=0x5EED0200 + log_domain)
+    r, s = fixed_rs()
+    exp = O.groth16_prove(zkey, wtns, int.from_bytes(r, "little"), int.from_bytes(s, "little"))
+    free_before, _ = device.mem_info()
+    with ug.Groth16Prover(zkey) as p:
+        free_created, _ = device.mem_info()
+        for _ in range(2):
+            ug.set_test_blinding(r + s)
+            try:
+                proof, pub = p.prove(wtns)
+            finally:
+                ug.set_test_blinding(b"")
+            assert (proof, pub) == (exp[0], exp[1])
+    # the tables are really there (or really absent): 5 G1-sized sets + one G2 set, c = 16 -> 15 extra tables each
+    n = info["nVars"]
+    extra = 15 * n * (64 * 4 + 128)
+    used = free_before - free_created
+    if tables == "1":
+        assert used > extra
+    else:
+        assert used < extra
+
+
+def test_ultragroth_created_prover_with_window_tables(device):
+    """UltraGroth on a created prover at 2^17: the witness, round (C1), final (C2) and H groups each get tables of
+    their own width (C1 has ~2^15 points, the others ~2^17); proof == oracle, twice"""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, uwtns, info = synth.build_ultra_circuit(device, 17)
+    assert info["nC1"] >= 1 << 14
+    rk, r, s = bytes(range(1, 32)), bytes(range(40, 71)), bytes(range(80, 111))
+    exp = O.ultra_groth_prove(zkey, uwtns, int.from_bytes(rk, "little"), int.from_bytes(r, "little"), int.from_bytes(s, "little"))
+    with ug.UltraGrothProver(zkey) as p:
+        for _ in range(2):
+            ug.set_test_blinding(rk + r + s)
+            try:
+                got = p.prove(uwtns)
+            finally:
+                ug.set_test_blinding(b"")
+            assert got == exp

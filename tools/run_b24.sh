@@ -1,0 +1,11 @@
+# quick 2^24 bench with the per-kernel split (no tests): bash tools/run_b24.sh [extra bench args]
+set -o pipefail
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout -k 10 400 python bench.py --log-domain 24 --steps 3 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/q24.json 2> gpurun_out/q24.err || { tail -5 gpurun_out/q24.err; exit 1; }
+python - <<'PY'
+import json
+d=json.load(open("gpurun_out/q24.json"))
+r=d["roofline"]
+print("%.1f ms/proof (%.2f proofs/s)  msm %.1f  fft %.1f | G1 acc %.2f ms  G2 acc %.2f ms" % (d["ms_per_step"], d["value"], d["msm_ms_per_proof"], d["fft_ms_per_proof"], r["avg_launch_ms"], r["g2_kernel"]["avg_launch_ms"]))
+PY

@@ -282,11 +282,15 @@ class Device:
             pass
 
     # -- raw handles
-    def bases(self, points, n, g2=False, global_first=0):
+    def bases(self, points, n, g2=False, global_first=0, table_c=0):
+        """table_c: also precompute the fixed-base window tables of that width (ug_bases_precompute)"""
         h = C.c_void_p()
         fn = self._L.ug_bases_create_g2 if g2 else self._L.ug_bases_create_g1
         _check(fn(self._h, points, n, global_first, C.byref(h)))
-        return _Handle(h, self._L.ug_bases_destroy, self)
+        b = _Handle(h, self._L.ug_bases_destroy, self)
+        if table_c:
+            _check(self._L.ug_bases_precompute(h, table_c))
+        return b
 
     def dvec(self, n, data=None):
         h = C.c_void_p()
@@ -301,12 +305,23 @@ class Device:
         _check(self._L.ug_dvec_download(dvec.h, out, first, n))
         return out.raw
 
-    def schedule(self, dvec, first, count):
+    def schedule(self, dvec, first, count, table_c=0):
         h = C.c_void_p()
         _check(self._L.ug_schedule_create(self._h, C.byref(h)))
         s = _Handle(h, self._L.ug_schedule_destroy, self)
-        _check(self._L.ug_schedule_build(h, dvec.h, first, count))
+        if table_c:
+            _check(self._L.ug_schedule_build_tables(h, dvec.h, first, count, table_c))
+        else:
+            _check(self._L.ug_schedule_build(h, dvec.h, first, count))
         return s
+
+    def table_window(self, n):
+        return self._L.ug_msm_table_window(n)
+
+    def mem_info(self):
+        f, t = C.c_uint64(), C.c_uint64()
+        _check(self._L.ug_ctx_mem_info(self._h, C.byref(f), C.byref(t)))
+        return f.value, t.value
 
     def msm(self, bases, schedule, index_shift=0, g2=False):
         out = C.create_string_buffer(128 if g2 else 64)
@@ -315,15 +330,15 @@ class Device:
         return out.raw
 
     # -- one-shot helpers
-    def msm_g1(self, points, scalars, n):
+    def msm_g1(self, points, scalars, n, table_c=0):
         """sum scalars[i] * points[i]; points n x 64 B zkey records, scalars n x 32 B plain integers."""
-        b = self.bases(points, n)
-        s = self.schedule(self.dvec(max(n, 1), scalars if n else None), 0, n)
+        b = self.bases(points, n, table_c=table_c)
+        s = self.schedule(self.dvec(max(n, 1), scalars if n else None), 0, n, table_c=table_c)
         return self.msm(b, s)
 
-    def msm_g2(self, points, scalars, n):
-        b = self.bases(points, n, g2=True)
-        s = self.schedule(self.dvec(max(n, 1), scalars if n else None), 0, n)
+    def msm_g2(self, points, scalars, n, table_c=0):
+        b = self.bases(points, n, g2=True, table_c=table_c)
+        s = self.schedule(self.dvec(max(n, 1), scalars if n else None), 0, n, table_c=table_c)
         return self.msm(b, s, g2=True)
 
     def ntt(self, data, logn, inverse=False):

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_CSRC, "libultragroth_hip.so")
 INNER_SYMBOLS = [
     "ug_last_error", "ug_device_count", "ug_ctx_create", "ug_ctx_destroy", "ug_ctx_sync",
     "ug_bases_create_g1", "ug_bases_create_g2", "ug_bases_destroy",
+    "ug_msm_table_window", "ug_bases_tables_bytes", "ug_bases_precompute", "ug_ctx_mem_info", "ug_schedule_build_tables",
     "ug_dvec_create", "ug_dvec_upload", "ug_dvec_download", "ug_dvec_gather", "ug_dvec_scatter", "ug_dvec_wrap", "ug_dvec_size", "ug_dvec_destroy",
     "ug_schedule_create", "ug_schedule_build", "ug_schedule_destroy",
     "ug_msm_g1", "ug_msm_g2",
@@ -67,6 +68,11 @@ def load():
     for n in ("ug_bases_create_g1", "ug_bases_create_g2"):
         getattr(L, n).argtypes = [vp, vp, u64, u64, pp]
     L.ug_bases_destroy.argtypes = [vp]; L.ug_bases_destroy.restype = None
+    L.ug_msm_table_window.argtypes = [u64]
+    L.ug_bases_tables_bytes.argtypes = [u64, C.c_int, C.c_int]; L.ug_bases_tables_bytes.restype = u64
+    L.ug_bases_precompute.argtypes = [vp, C.c_int]
+    L.ug_ctx_mem_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.ug_schedule_build_tables.argtypes = [vp, vp, u64, u64, C.c_int]
     L.ug_dvec_create.argtypes = [vp, u64, pp]
     L.ug_dvec_upload.argtypes = [vp, vp, u64]
     L.ug_dvec_download.argtypes = [vp, vp, u64, u64]

@@ -31,11 +31,18 @@ struct NttPlan {
 struct MsmGeometry {
     u64 n = 0;          // number of scalars
     int c = 0;          // window bits
-    int windows = 0;    // ceil(255 / c)
-    u32 buckets = 0;    // per window: 2^(c-1)
+    int windows = 0;    // digits per scalar: ceil(255 / c)
+    u32 buckets = 0;    // per bucket set: 2^(c-1)
+    bool tables = false;  // fixed-base window tables: digit j of scalar i multiplies 2^(c j) P_i, read from table j, so
+                          // every digit of every window lands in ONE bucket set (no Horner, 1/windows of the reduction)
     static MsmGeometry choose(u64 n, int force_c = 0);
-    u64 total_buckets() const { return (u64)windows * buckets; }
+    static MsmGeometry choose_tables(u64 n, int c);
+    static int table_window(u64 n);                                    // cost-model window width for the tables mode
+    int bucket_windows() const { return tables ? 1 : windows; }
+    u64 total_buckets() const { return (u64)bucket_windows() * buckets; }
 };
+constexpr int TABLE_INDEX_BITS = 27;                                   // entry = index | table << 27 | sign << 31
+constexpr int TABLE_MIN_C = 16, TABLE_MAX_C = 24;                      // <= 16 tables (4 bits), <= 2^23 buckets
 
 struct HeavyBucket { u32 bucket, first_seg, last_seg, pad; };  // a bucket cut into many segment pieces
 
@@ -44,7 +51,7 @@ struct HeavyBucket { u32 bucket, first_seg, last_seg, pad; };  // a bucket cut i
 struct MsmSchedule {
     MsmGeometry geo;
     const u32* keys = nullptr;    // sorted bucket ids (sentinel = total_buckets at the end)
-    const u32* vals = nullptr;    // sorted entries: scalar index | sign << 31
+    const u32* vals = nullptr;    // sorted entries: scalar index | table << 27 | sign << 31
     const u32* tkeys = nullptr;   // lane-transposed copies of keys / vals (see msm.hip: transposed_index)
     const u32* tvals = nullptr;
     u32* bucket_start = nullptr;  // per bucket: first entry
@@ -95,6 +102,9 @@ G2XYZZ msm_g2(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_ba
 // zkey affine records (reference Montgomery form, R = 2^256) -> device form, in place on the device
 void convert_points_g1(u32* pts, u64 n, hipStream_t stream);
 void convert_points_g2(u32* pts, u64 n, hipStream_t stream);
+
+// pts = `tables` tables of n records, table 0 filled: table j = 2^(c j) * table 0 (fixed-base window tables)
+void build_window_tables(bool g2, u32* pts, u64 n, int c, int tables, hipStream_t stream);
 
 // bench / test tooling: out[i] = (seed + i) * G as zkey-format records (device buffer); G given as a host record
 void synth_points(bool g2, u32* out_dev, const u32* gen_record_host, u64 seed, u64 n, hipStream_t stream);

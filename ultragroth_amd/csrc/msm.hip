@@ -38,7 +38,7 @@ constexpr int CHUNK = 32;             // buckets per running-sum chunk
 // ---- curve configurations -------------------------------------------------------------------------
 struct G1Cfg {
     typedef Fq F;
-    static constexpr int AFF_WORDS = 16, PT_WORDS = 36, BLOCK = 256;
+    static constexpr int AFF_WORDS = 16, PT_WORDS = 36, BLOCK = 256, ACC_WAVES = 3;
     static __device__ __forceinline__ bool load_affine(const u32* p, F& x, F& y) {
         u32 w[16];
         load8(w, p); load8(w + 8, p + 8);
@@ -84,7 +84,7 @@ struct G1Cfg {
 };
 struct G2Cfg {
     typedef Fq2 F;
-    static constexpr int AFF_WORDS = 32, PT_WORDS = 72, BLOCK = 128;
+    static constexpr int AFF_WORDS = 32, PT_WORDS = 72, BLOCK = 128, ACC_WAVES = 1;
     static __device__ __forceinline__ bool load_affine(const u32* p, F& x, F& y) {
         u32 w[32];
         load8(w, p); load8(w + 8, p + 8); load8(w + 16, p + 16); load8(w + 24, p + 24);
@@ -142,7 +142,7 @@ __device__ __forceinline__ bool geq_r(const u32* s) {
     }
     return true;
 }
-__global__ void msm_digits_kernel(const u32* scalars, u64 n, int c, int windows, u32 buckets, u32 sentinel,
+__global__ void msm_digits_kernel(const u32* scalars, u64 n, int c, int windows, u32 buckets, u32 sentinel, int tables,
                                   u32* keys, u32* vals) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -164,14 +164,17 @@ __global__ void msm_digits_kernel(const u32* scalars, u64 n, int c, int windows,
         int bit = w * c, word = bit >> 5, sh = bit & 31;
         u64 two = (u64)s[word] | ((u64)s[word + 1] << 32);
         u32 raw = ((u32)(two >> sh) & mask) + carry;
+        // classic: one bucket set per window; tables: one set, the window selects the table the base is read from
+        const u32 set0 = tables ? 0u : (u32)w * buckets;
+        const u32 tag = tables ? (u32)w << TABLE_INDEX_BITS : 0u;
         u32 key, val;
         if (raw > half) {                       // negative digit raw - 2^c, carry into the next window
             u32 mag = full - raw;               // 0 when the window was all ones and a carry came in
             carry = 1;
-            key = mag ? (u32)w * buckets + mag - 1 : sentinel;
-            val = (u32)i | 0x80000000u;
+            key = mag ? set0 + mag - 1 : sentinel;
+            val = (u32)i | tag | 0x80000000u;
         }
-        else { carry = 0; key = raw ? (u32)w * buckets + raw - 1 : sentinel; val = (u32)i; }
+        else { carry = 0; key = raw ? set0 + raw - 1 : sentinel; val = (u32)i | tag; }
         keys[(u64)w * n + i] = key;
         vals[(u64)w * n + i] = val;
     }
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(1024) void transpose_entries_kernel(const u32* __re
 }
 
 template <class Cfg>
-__global__ __launch_bounds__(256) void segment_accumulate_kernel(const u32* __restrict__ bases, u64 n_bases, int64_t delta,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Cfg::ACC_WAVES, Cfg::ACC_WAVES))) void segment_accumulate_kernel(const u32* __restrict__ bases, u64 n_bases, int64_t delta,
                                                                  const u32* __restrict__ keys, const u32* __restrict__ tkeys,
                                                                  const u32* __restrict__ tvals, u32 n_valid, int log_seg,
                                                                  u32* __restrict__ bucket_pts, u32* __restrict__ slot_pts) {
@@ -264,10 +267,12 @@ __global__ __launch_bounds__(256) void segment_accumulate_kernel(const u32* __re
     XYZZ<F> acc = xyzz_inf<F>();
     // software pipeline: the raw record of entry k + 1 is in flight while entry k is added
     u32 raw[Cfg::AFF_WORDS];
+    // entry = scalar index | table << 27 | sign << 31; table j of a base set starts j * n_bases records in
+    const u32 IDX_MASK = (1u << TABLE_INDEX_BITS) - 1;
     u32 nkey = cur, nval = tvals[tbase];
-    int64_t nidx = (int64_t)(nval & 0x7fffffffu) + delta;
+    int64_t nidx = (int64_t)(nval & IDX_MASK) + delta;
     bool nin = nidx >= 0 && (u64)nidx < n_bases;
-    if (nin) Cfg::load_raw(raw, bases + (u64)nidx * Cfg::AFF_WORDS);
+    if (nin) Cfg::load_raw(raw, bases + ((u64)((nval >> TABLE_INDEX_BITS) & 15u) * n_bases + (u64)nidx) * Cfg::AFF_WORDS);
     for (u32 k = 0; k < cnt; k++) {
         F x, y;
         bool valid = nin && Cfg::decode_affine(raw, x, y);
@@ -276,9 +281,9 @@ __global__ __launch_bounds__(256) void segment_accumulate_kernel(const u32* __re
         if (k + 1 < cnt) {
             nkey = tkeys[tbase + ((u64)(k + 1) << 6)];
             nval = tvals[tbase + ((u64)(k + 1) << 6)];
-            nidx = (int64_t)(nval & 0x7fffffffu) + delta;
+            nidx = (int64_t)(nval & IDX_MASK) + delta;
             nin = nidx >= 0 && (u64)nidx < n_bases;
-            if (nin) Cfg::load_raw(raw, bases + (u64)nidx * Cfg::AFF_WORDS);
+            if (nin) Cfg::load_raw(raw, bases + ((u64)((nval >> TABLE_INDEX_BITS) & 15u) * n_bases + (u64)nidx) * Cfg::AFF_WORDS);
         }
         if (key != cur) {                          // the previous run ended inside the segment
             u32* dst = (first_run && start_open) ? slot_pts + (size_t)(2 * t) * Cfg::PT_WORDS : bucket_pts + (size_t)cur * Cfg::PT_WORDS;
@@ -470,6 +475,51 @@ __global__ void convert_coords_kernel(u32* pts, u64 n_coords_groups, int coords_
     }
 }
 
+// ---- fixed-base window tables ------------------------------------------------------------------------------
+// pts holds `tables` tables of n affine records; table 0 is given, table j = 2^(c j) * table 0. A lane carries K
+// consecutive points through c doublings per table and shares one field inversion among them for the conversion
+// back to affine (Montgomery's trick); infinity stays (0,0) in every table.
+template <class Cfg, int K>
+__global__ __launch_bounds__(128) void window_tables_kernel(u32* pts, u64 n, int c, int tables) {
+    typedef typename Cfg::F F;
+    const u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * K;
+    if (i0 >= n) return;
+    F x[K], y[K];
+    bool live[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) live[k] = i0 + k < n && Cfg::load_affine(pts + (i0 + k) * Cfg::AFF_WORDS, x[k], y[k]);
+    for (int j = 1; j < tables; j++) {
+        XYZZ<F> p[K];
+        F pre[K];
+        F run = field_one((F*)0);
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            pre[k] = run;
+            if (!live[k]) continue;
+            p[k] = xyzz_dbl_affine(x[k], y[k]);
+            for (int d = 1; d < c; d++) p[k] = xyzz_dbl(p[k]);
+            run = mulk<8>(run, p[k].zzz);
+        }
+        F irun = inv(run);                                               // 1 / prod zzz_k
+#pragma unroll
+        for (int k = K - 1; k >= 0; k--) {
+            u32* o = pts + ((u64)j * n + i0 + k) * Cfg::AFF_WORDS;
+            if (i0 + k >= n) continue;
+            if (!live[k]) {
+                for (int w = 0; w < Cfg::AFF_WORDS; w++) o[w] = 0;
+                continue;
+            }
+            F izzz = mulk<8>(irun, pre[k]);                              // 1 / zzz_k
+            irun = mulk<8>(irun, p[k].zzz);
+            F iz = mulk<8>(izzz, p[k].zz);                               // zz / zzz = 1 / z
+            F izz = sqrk<8>(iz);
+            x[k] = canon(mulk<8>(p[k].x, izz));
+            y[k] = canon(mulk<8>(p[k].y, izzz));
+            Cfg::store_affine_packed(o, x[k], y[k]);
+        }
+    }
+}
+
 // ---- synthetic base points (bench / test tooling): record i = (seed + i) * G ------------------------------
 // table: 64 affine records 2^j * G in device form; output: zkey-format records (Montgomery R = 2^256)
 template <class Cfg>
@@ -523,6 +573,25 @@ MsmGeometry MsmGeometry::choose(u64 n, int force_c) {
     return g;
 }
 
+// Tables mode: W = ceil(255/c) digits per scalar, ONE bucket set of 2^(c-1): cost W n + 4 * 2^(c-1) additions.
+int MsmGeometry::table_window(u64 n) {
+    int c = 0;
+    double best = 0;
+    for (int k = TABLE_MIN_C; k <= TABLE_MAX_C; k++) {
+        double cost = (double)((255 + k - 1) / k) * (double)n + 4.0 * (double)((u64)1 << (k - 1));
+        if (!c || cost < best) { best = cost; c = k; }
+    }
+    return c;
+}
+MsmGeometry MsmGeometry::choose_tables(u64 n, int c) {
+    if (c < TABLE_MIN_C || c > TABLE_MAX_C) throw std::invalid_argument("msm: table window width outside [16, 24]");
+    MsmGeometry g;
+    g.n = n; g.c = c; g.tables = true;
+    g.windows = (255 + c - 1) / c;
+    g.buckets = 1u << (c - 1);
+    return g;
+}
+
 // ---- schedule -----------------------------------------------------------------------------------------------
 void MsmSchedule::reserve(const MsmGeometry& g) {
     u64 total = g.n * g.windows;
@@ -559,10 +628,11 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
     if (g.n == 0) return;
     u64 total = g.n * g.windows;
     if (total >= ((u64)1 << 31)) throw std::invalid_argument("msm: n * windows exceeds 2^31 entries");
+    if (g.n > ((u64)1 << TABLE_INDEX_BITS)) throw std::invalid_argument("msm: more than 2^27 scalars in one schedule");
     u32 nb = (u32)g.total_buckets();
     u32 sentinel = nb;
     hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, stream,
-                       scalars_dev, g.n, g.c, g.windows, g.buckets, sentinel, keys_a, vals_a);
+                       scalars_dev, g.n, g.c, g.windows, g.buckets, sentinel, g.tables ? 1 : 0, keys_a, vals_a);
     UG_KERNEL_CHECK();
     int end_bit = 1;
     while (((u64)1 << end_bit) <= sentinel) end_bit++;
@@ -616,7 +686,7 @@ void MsmWorkspace::reserve(const MsmGeometry& g, bool g2, u64 n_segments, u32 n_
     size_t need = (size_t)g.total_buckets() * ptw * 4;
     if (need > bucket_bytes) { dev_alloc(bucket_pts, need); bucket_bytes = need; }
     int chunk = g.buckets < (u32)CHUNK ? (int)g.buckets : CHUNK;
-    size_t cneed = (size_t)g.windows * (g.buckets / chunk) * ptw * 4;
+    size_t cneed = (size_t)g.bucket_windows() * (g.buckets / chunk) * ptw * 4;
     if (cneed > chunk_bytes) { dev_alloc(chunk_pts, cneed); dev_alloc(chunk_pts2, cneed); chunk_bytes = cneed; }
     size_t sneed = (size_t)n_segments * 2 * ptw * 4;
     if (sneed > slot_bytes) { dev_alloc(slot_pts, sneed); slot_bytes = sneed; }
@@ -665,21 +735,22 @@ XYZZ<typename Cfg::F> msm_run(const MsmSchedule& s, MsmWorkspace& ws, const u32*
         UG_KERNEL_CHECK();
     }
     int chunk = g.buckets < (u32)CHUNK ? (int)g.buckets : CHUNK;
-    u32 cpw = g.buckets / chunk;                       // chunks per window
-    u32 nchunks = cpw * g.windows;
+    const int bw = g.bucket_windows();                 // bucket sets: one per window, or one in all with window tables
+    u32 cpw = g.buckets / chunk;                       // chunks per bucket set
+    u32 nchunks = cpw * bw;
     hipLaunchKernelGGL(bucket_chunk_reduce_kernel<Cfg>, dim3((nchunks + 127) / 128), dim3(128), 0, stream,
                        ws.bucket_pts, s.bucket_count, g.buckets, chunk, nchunks, g.c, ws.chunk_pts);
     UG_KERNEL_CHECK();
     u32* cur = ws.chunk_pts; u32* nxt = ws.chunk_pts2;
     while (cpw > 1) {
         int group = cpw >= 16 ? 16 : (int)cpw;
-        u32 n_out = (cpw / group) * g.windows;
+        u32 n_out = (cpw / group) * bw;
         hipLaunchKernelGGL(ec_sum_groups_kernel<Cfg>, dim3((n_out + 127) / 128), dim3(128), 0, stream, cur, nxt, n_out, group);
         UG_KERNEL_CHECK();
         std::swap(cur, nxt);
         cpw /= group;
     }
-    std::vector<u32> host((size_t)g.windows * Cfg::PT_WORDS);
+    std::vector<u32> host((size_t)bw * Cfg::PT_WORDS);
     UG_HIP(hipMemcpyAsync(host.data(), cur, host.size() * 4, hipMemcpyDeviceToHost, stream));
     UG_HIP(hipStreamSynchronize(stream));
     if (stats) {
@@ -689,7 +760,7 @@ XYZZ<typename Cfg::F> msm_run(const MsmSchedule& s, MsmWorkspace& ws, const u32*
     }
     // Horner over the windows, top first
     XYZZ<F> acc = xyzz_inf<F>();
-    for (int w = g.windows - 1; w >= 0; w--) {
+    for (int w = bw - 1; w >= 0; w--) {
         for (int k = 0; k < g.c; k++) acc = xyzz_dbl(acc);
         acc = xyzz_add(acc, Cfg::from_words(host.data() + (size_t)w * Cfg::PT_WORDS, 1));
     }
@@ -741,6 +812,16 @@ void synth_points(bool g2, u32* out_dev, const u32* gen_record_host, u64 seed, u
     if (!n) return;
     if (g2) synth_points_run<G2Cfg>(out_dev, gen_record_host, seed, n, stream);
     else synth_points_run<G1Cfg>(out_dev, gen_record_host, seed, n, stream);
+}
+
+void build_window_tables(bool g2, u32* pts, u64 n, int c, int tables, hipStream_t stream) {
+    if (!n || tables < 2) return;
+    if (g2) {
+        hipLaunchKernelGGL((window_tables_kernel<G2Cfg, 2>), dim3((unsigned)(((n + 1) / 2 + 127) / 128)), dim3(128), 0, stream, pts, n, c, tables);
+    } else {
+        hipLaunchKernelGGL((window_tables_kernel<G1Cfg, 4>), dim3((unsigned)(((n + 3) / 4 + 127) / 128)), dim3(128), 0, stream, pts, n, c, tables);
+    }
+    UG_KERNEL_CHECK();
 }
 
 void convert_points_g1(u32* pts, u64 n, hipStream_t stream) {

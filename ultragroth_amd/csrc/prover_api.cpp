@@ -190,6 +190,54 @@ struct DeviceProver {
     }
 };
 
+// ---- fixed-base window tables ---------------------------------------------------------------------------------
+// A zkey's points never change between proofs, so a created prover may trade HBM for work: with tables 2^(c j) P_i
+// every window digit of an MSM lands in one bucket set (ultragroth_hip.h: ug_bases_precompute). A group is the base
+// sets that share one schedule (they must share the window width). Tables are built when ULTRAGROTH_TABLES is not
+// "0", a group has at least 2^14 scalars (below that the classic windows are cheaper) and everything fits the free
+// device memory with room left for schedules, buckets and NTT vectors; otherwise the classic path runs.
+struct TableGroup {
+    std::vector<ug_bases*> g1, g2;     // sets of the group with their point counts
+    std::vector<uint64_t> n1, n2;
+    uint64_t scalars = 0;              // scalars per schedule
+    int* c = nullptr;                  // out: window width, 0 = classic
+};
+constexpr uint64_t TABLES_MIN_SCALARS = (uint64_t)1 << 14, TABLES_MAX_SCALARS = (uint64_t)1 << 26;
+
+thread_local bool g_oneShotProver = false;      // create + one prove + destroy (groth16_prover, the CLIs): tables cannot pay
+
+void planWindowTables(ug_ctx* ctx, std::vector<TableGroup>& groups) {
+    for (auto& g : groups) *g.c = 0;
+    const char* e = getenv("ULTRAGROTH_TABLES");
+    if ((e && e[0] == '0') || (g_oneShotProver && !(e && e[0] == '2'))) return;     // "2": tables even for one-shot calls
+    uint64_t need = 0, workspace = (uint64_t)2 << 30;
+    std::vector<int> width(groups.size(), 0);
+    for (size_t k = 0; k < groups.size(); k++) {
+        const TableGroup& g = groups[k];
+        if (g.scalars < TABLES_MIN_SCALARS || g.scalars > TABLES_MAX_SCALARS) continue;
+        int c = ug_msm_table_window(g.scalars);
+        width[k] = c;
+        for (uint64_t n : g.n1) need += ug_bases_tables_bytes(n, 0, c);
+        for (uint64_t n : g.n2) need += ug_bases_tables_bytes(n, 1, c);
+        workspace += 24 * g.scalars * (uint64_t)((255 + c - 1) / c);       // sorted entries + segment slots
+    }
+    if (!need) return;
+    uint64_t freeB = 0, totalB = 0;
+    ugCheck(ug_ctx_mem_info(ctx, &freeB, &totalB));
+    if (need + workspace > freeB) return;
+    for (size_t k = 0; k < groups.size(); k++) {
+        if (!width[k]) continue;
+        bool ok = true;
+        for (ug_bases* b : groups[k].g1) ok = ok && ug_bases_precompute(b, width[k]) == 0;
+        for (ug_bases* b : groups[k].g2) ok = ok && ug_bases_precompute(b, width[k]) == 0;
+        if (ok) *groups[k].c = width[k];       // a group left half built keeps using table 0 of each set
+    }
+}
+void buildSchedule(ug_schedule* s, const ug_dvec* scalars, uint64_t first, uint64_t count, int tableC) {
+    if (tableC) ugCheck(ug_schedule_build_tables(s, scalars, first, count, tableC));
+    else ugCheck(ug_schedule_build(s, scalars, first, count));
+}
+
 struct ProverBase {        // what the extern "C" layer stores behind the opaque handle
     virtual ~ProverBase() {}
     virtual void prove(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub) = 0;
@@ -258,6 +306,13 @@ public:
         ugCheck(ug_dvec_create(d_.ctx2, N, &d_.h));
         ugCheck(ug_schedule_create(d_.ctx, &d_.sw));
         ugCheck(ug_schedule_create(d_.ctx2, &d_.sh));
+        std::vector<TableGroup> groups(2);
+        groups[0].g1 = {d_.A, d_.B1, d_.C}; groups[0].n1 = {wr_.hi - wr_.lo, wr_.hi - wr_.lo, cHi - cLo};
+        groups[0].g2 = {d_.B2}; groups[0].n2 = {wr_.hi - wr_.lo};
+        groups[0].scalars = wr_.hi - wr_.lo; groups[0].c = &tableW_;
+        groups[1].g1 = {d_.H}; groups[1].n1 = {hr_.hi - hr_.lo};
+        groups[1].scalars = hr_.hi - hr_.lo; groups[1].c = &tableH_;
+        planWindowTables(d_.ctx, groups);
     }
 
     const ZkeyHeader& header() const { return hdr_; }
@@ -287,7 +342,7 @@ public:
             uint64_t n = std::min<uint64_t>(MAX_RANGE, wr_.hi - lo);
             uint8_t* out = (lo == wr_.lo) ? partials : part;
             memset(part, 0, sizeof part);
-            ugCheck(ug_schedule_build(d_.sw, d_.w, lo, n));
+            buildSchedule(d_.sw, d_.w, lo, n, tableW_);
             ugCheck(ug_msm_g1(d_.ctx, d_.A, d_.sw, 0, out));                                   // S1  :55
             ugCheck(ug_msm_g1(d_.ctx, d_.B1, d_.sw, 0, out + 64));                             // S2  :58
             ugCheck(ug_msm_g2(d_.ctx, d_.B2, d_.sw, 0, out + 128));                            // S3  :61
@@ -304,7 +359,7 @@ public:
             uint64_t n = std::min<uint64_t>(MAX_RANGE, hr_.hi - lo);
             uint8_t* out = (lo == hr_.lo) ? partials : part;
             memset(part, 0, sizeof part);
-            ugCheck(ug_schedule_build(d_.sh, d_.h, lo, n));
+            buildSchedule(d_.sh, d_.h, lo, n, tableH_);
             ugCheck(ug_msm_g1(d_.ctx2, d_.H, d_.sh, 0, out + 320));                            // S10 :154
             if (out == part && ug_groth16_partials_add(partials, part) != PROVER_OK) throw std::runtime_error("partial sum failed");
         }
@@ -417,6 +472,7 @@ public:
 
 private:
     static constexpr uint64_t MAX_RANGE = (uint64_t)1 << 26;       // 2^26 scalars * <= 16 windows < 2^31 entries
+    int tableW_ = 0, tableH_ = 0;      // window widths of the fixed-base tables (0: classic windows), planWindowTables
     int rank_, count_;
     ZkeyHeader hdr_;
     std::vector<uint8_t> vk_, publicPart_;
@@ -470,6 +526,13 @@ public:
         ugCheck(ug_schedule_create(d_.ctx, &d_.sw));
         ugCheck(ug_schedule_create(d_.ctx, &d_.sh));
         ugCheck(ug_schedule_create(d_.ctx, &d_.saux));
+        std::vector<TableGroup> groups(4);
+        groups[0].g1 = {d_.A, d_.B1}; groups[0].n1 = {M, M}; groups[0].g2 = {d_.B2}; groups[0].n2 = {M};
+        groups[0].scalars = M; groups[0].c = &tableW_;
+        groups[1].g1 = {d_.roundC}; groups[1].n1 = {hdr_.numIndexesC1}; groups[1].scalars = hdr_.numIndexesC1; groups[1].c = &tableC1_;
+        groups[2].g1 = {d_.C}; groups[2].n1 = {hdr_.numIndexesC2}; groups[2].scalars = hdr_.numIndexesC2; groups[2].c = &tableC2_;
+        groups[3].g1 = {d_.H}; groups[3].n1 = {N}; groups[3].scalars = N; groups[3].c = &tableH_;
+        planWindowTables(d_.ctx, groups);
     }
 
     const ZkeyHeader& header() const { return hdr_; }
@@ -497,7 +560,7 @@ public:
         // ---- round 1: commitment to the round witnesses (ultra_groth.cpp:415-419, execute_round :161-184)
         ugCheck(ug_dvec_upload(d_.w, signals0, M));
         ugCheck(ug_dvec_gather(d_.aux, d_.w, roundIdx_.data(), roundIdx_.size()));
-        ugCheck(ug_schedule_build(d_.saux, d_.aux, 0, roundIdx_.size()));
+        buildSchedule(d_.saux, d_.aux, 0, roundIdx_.size(), tableC1_);
         uint8_t commitRec[64];
         ugCheck(ug_msm_g1(d_.ctx, d_.roundC, d_.saux, 0, commitRec));
         uint8_t rk[32];
@@ -532,16 +595,16 @@ public:
             if (patchIdx[i] <= hdr_.nPublic) memcpy(publicPart.data() + (size_t)patchIdx[i] * 32, patchVal.data() + i * 32, 32);
 
         // ---- final round (execute_final_round :187-399)
-        ugCheck(ug_schedule_build(d_.sw, d_.w, 0, M));
+        buildSchedule(d_.sw, d_.w, 0, M, tableW_);
         uint8_t sums[UG_GROTH16_PARTIALS_SIZE];
         ugCheck(ug_msm_g1(d_.ctx, d_.A, d_.sw, 0, sums));                                   // MSM1 :201
         ugCheck(ug_msm_g1(d_.ctx, d_.B1, d_.sw, 0, sums + 64));                             // MSM2 :214
         ugCheck(ug_msm_g2(d_.ctx, d_.B2, d_.sw, 0, sums + 128));                            // MSM3 :227
         ugCheck(ug_dvec_gather(d_.aux, d_.w, finalIdx_.data(), finalIdx_.size()));          // :439-445
-        ugCheck(ug_schedule_build(d_.saux, d_.aux, 0, finalIdx_.size()));
+        buildSchedule(d_.saux, d_.aux, 0, finalIdx_.size(), tableC2_);
         ugCheck(ug_msm_g1(d_.ctx, d_.C, d_.saux, 0, sums + 256));                           // MSM4 :234
         ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                           // FFT block :243-320
-        ugCheck(ug_schedule_build(d_.sh, d_.h, 0, hdr_.domainSize));
+        buildSchedule(d_.sh, d_.h, 0, hdr_.domainSize, tableH_);
         ugCheck(ug_msm_g1(d_.ctx, d_.H, d_.sh, 0, sums + 320));                             // MSM5 :322
         ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
 
@@ -625,6 +688,7 @@ private:
     ZkeyHeader hdr_;
     std::vector<uint8_t> vk_;
     std::vector<uint32_t> roundIdx_, finalIdx_, lastPos_;
+    int tableW_ = 0, tableC1_ = 0, tableC2_ = 0, tableH_ = 0;      // fixed-base table widths per schedule group (0: classic)
     DeviceProver d_;
     double msmMs_ = 0, fftMs_ = 0, totalMs_ = 0;
 };
@@ -752,7 +816,9 @@ int groth16_prover(const void* zkey_buffer, unsigned long long zkey_size, const 
                    char* proof_buffer, unsigned long long* proof_size, char* public_buffer, unsigned long long* public_size,
                    char* error_msg, unsigned long long error_msg_maxsize) {
     void* prover = NULL;
+    g_oneShotProver = true;
     int error = groth16_prover_create(&prover, zkey_buffer, zkey_size, error_msg, error_msg_maxsize);
+    g_oneShotProver = false;
     if (error != PROVER_OK) return error;
     error = groth16_prover_prove(prover, wtns_buffer, wtns_size, proof_buffer, proof_size, public_buffer, public_size, error_msg,
                                  error_msg_maxsize);
@@ -763,7 +829,9 @@ int ultra_groth_prover(const void* zkey_buffer, unsigned long long zkey_size, co
                        char* proof_buffer, unsigned long long* proof_size, char* public_buffer, unsigned long long* public_size,
                        char* error_msg, unsigned long long error_msg_maxsize) {
     void* prover = NULL;
+    g_oneShotProver = true;
     int error = ultra_groth_prover_create(&prover, zkey_buffer, zkey_size, error_msg, error_msg_maxsize);
+    g_oneShotProver = false;
     if (error != PROVER_OK) return error;
     error = ultra_groth_prover_prove(prover, wtns_buffer, wtns_size, proof_buffer, proof_size, public_buffer, public_size,
                                      error_msg, error_msg_maxsize);

@@ -33,6 +33,7 @@ struct ug_ctx {
 };
 struct ug_bases {
     ug_ctx* ctx; bool g2; u64 n; u64 global_first; u32* pts;
+    int table_c = 0;          // window width of the precomputed tables (0: none, pts holds the n points only)
 };
 struct ug_dvec {
     ug_ctx* ctx; u64 n; u32* data; bool owns;
@@ -107,7 +108,7 @@ static int bases_create(ug_ctx* c, const void* host, u64 n, u64 global_first, bo
     UG_TRY
     if (!c || !out || (!host && n)) throw std::invalid_argument("null argument");
     c->use();
-    ug_bases* b = new ug_bases{c, g2, n, global_first, nullptr};
+    ug_bases* b = new ug_bases{c, g2, n, global_first, nullptr, 0};
     size_t bytes = (size_t)n * (g2 ? 128 : 64);
     UG_HIP(hipMalloc(&b->pts, bytes ? bytes : 4));
     if (n) {
@@ -120,6 +121,45 @@ static int bases_create(ug_ctx* c, const void* host, u64 n, u64 global_first, bo
 }
 int ug_bases_create_g1(ug_ctx* c, const void* host, uint64_t n, uint64_t gf, ug_bases** out) { return bases_create(c, host, n, gf, false, out); }
 int ug_bases_create_g2(ug_ctx* c, const void* host, uint64_t n, uint64_t gf, ug_bases** out) { return bases_create(c, host, n, gf, true, out); }
+int ug_msm_table_window(uint64_t n) { return MsmGeometry::table_window(n); }
+uint64_t ug_bases_tables_bytes(uint64_t n, int g2, int c) {
+    if (c < TABLE_MIN_C || c > TABLE_MAX_C) return 0;
+    return (uint64_t)((255 + c - 1) / c - 1) * n * (g2 ? 128 : 64);
+}
+int ug_bases_precompute(ug_bases* b, int c) {
+    UG_TRY
+    if (!b) throw std::invalid_argument("null argument");
+    if (b->table_c) throw std::invalid_argument("bases already hold window tables");
+    MsmGeometry g = MsmGeometry::choose_tables(b->n, c);             // validates c
+    if (b->n > ((u64)1 << TABLE_INDEX_BITS)) throw std::invalid_argument("window tables need at most 2^27 points per set");
+    ug_ctx* ctx = b->ctx;
+    ctx->use();
+    if (b->n) {
+        size_t rec = b->g2 ? 128 : 64;
+        u32* all = nullptr;
+        if (hipMalloc(&all, (size_t)g.windows * b->n * rec) != hipSuccess) {
+            (void)hipGetLastError();
+            throw std::runtime_error("not enough device memory for the window tables");
+        }
+        UG_HIP(hipMemcpyAsync(all, b->pts, (size_t)b->n * rec, hipMemcpyDeviceToDevice, ctx->stream));
+        build_window_tables(b->g2, all, b->n, c, g.windows, ctx->stream);
+        UG_HIP(hipStreamSynchronize(ctx->stream));
+        hipFree(b->pts);
+        b->pts = all;
+    }
+    b->table_c = c;
+    UG_CATCH
+}
+int ug_ctx_mem_info(ug_ctx* c, uint64_t* free_bytes, uint64_t* total_bytes) {
+    UG_TRY
+    if (!c) throw std::invalid_argument("null argument");
+    c->use();
+    size_t f = 0, t = 0;
+    UG_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    UG_CATCH
+}
 void ug_bases_destroy(ug_bases* b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);
@@ -219,6 +259,19 @@ int ug_schedule_build(ug_schedule* s, const ug_dvec* scalars, uint64_t first, ui
     tm.stop();
     UG_CATCH
 }
+int ug_schedule_build_tables(ug_schedule* s, const ug_dvec* scalars, uint64_t first, uint64_t count, int c) {
+    UG_TRY
+    if (!s || !scalars) throw std::invalid_argument("null argument");
+    if (first + count > scalars->n) throw std::invalid_argument("schedule range outside the scalar vector");
+    ug_ctx* ctx = s->ctx;
+    ctx->use();
+    MsmGeometry g = MsmGeometry::choose_tables(count, c);
+    ScopedTimer tm(ctx, &ctx->msm_ms);
+    s->first = first;
+    s->sched.build(scalars->data + first * 8, g, ctx->stream);
+    tm.stop();
+    UG_CATCH
+}
 void ug_schedule_destroy(ug_schedule* s) {
     if (!s) return;
     hipSetDevice(s->ctx->device);
@@ -243,10 +296,17 @@ static void affine_out_g2(uint8_t* out, const G2XYZZ& p) {
     memcpy(out, w, 128);
 }
 
+// a schedule built for window tables needs bases that hold tables of the same width (a classic schedule reads table 0 only)
+static void check_tables(const ug_bases* b, const ug_schedule* s) {
+    if (s->sched.geo.tables && s->sched.geo.c != b->table_c)
+        throw std::invalid_argument("schedule built for window tables of width " + std::to_string(s->sched.geo.c) +
+                                    " but the bases hold " + (b->table_c ? "tables of width " + std::to_string(b->table_c) : std::string("no tables")));
+}
 int ug_msm_g1(ug_ctx* c, const ug_bases* b, const ug_schedule* s, int64_t index_shift, void* out) {
     UG_TRY
     if (!c || !b || !s || !out) throw std::invalid_argument("null argument");
     if (b->g2) throw std::invalid_argument("ug_msm_g1 called with G2 bases");
+    check_tables(b, s);
     c->use();
     ScopedTimer tm(c, &c->msm_ms);
     int64_t delta = (int64_t)s->first - index_shift - (int64_t)b->global_first;
@@ -259,6 +319,7 @@ int ug_msm_g2(ug_ctx* c, const ug_bases* b, const ug_schedule* s, int64_t index_
     UG_TRY
     if (!c || !b || !s || !out) throw std::invalid_argument("null argument");
     if (!b->g2) throw std::invalid_argument("ug_msm_g2 called with G1 bases");
+    check_tables(b, s);
     c->use();
     ScopedTimer tm(c, &c->msm_ms);
     int64_t delta = (int64_t)s->first - index_shift - (int64_t)b->global_first;
