@@ -213,6 +213,11 @@ def test_full_size_g1_msm_in_the_exponent(device):
     lo = device.msm(b, device.schedule(v, 0, half))
     hi = device.msm(b, device.schedule(v, half, n - half))
     assert O.g1_add(lo, hi) == got
+    # the same sum through the fixed-base window tables of the cost-model width (12 tables of 2^24 points at c = 22)
+    del b
+    c = device.table_window(n)
+    bt = device.bases(synth.synth_points(device, n, seed), n, table_c=c)
+    assert device.msm(bt, device.schedule(v, 0, n, table_c=c)) == got
 
 
 def test_full_size_g2_msm_in_the_exponent(device):
@@ -223,8 +228,13 @@ def test_full_size_g2_msm_in_the_exponent(device):
     sc = synth.scalars(n, "C", 98)
     b = device.bases(pts, n, g2=True)
     del pts
-    got = device.msm(b, device.schedule(device.dvec(n, sc.tobytes()), 0, n), g2=True)
+    v = device.dvec(n, sc.tobytes())
+    got = device.msm(b, device.schedule(v, 0, n), g2=True)
     assert got == O.g2_mul(synth.g2_generator_record(), O.fr_dot_walk(sc.tobytes(), n, seed))
+    del b
+    c = device.table_window(n)
+    bt = device.bases(synth.synth_points(device, n, seed, g2=True), n, g2=True, table_c=c)
+    assert device.msm(bt, device.schedule(v, 0, n, table_c=c), g2=True) == got
 
 
 def test_full_size_ntt_round_trip_and_delta(device):

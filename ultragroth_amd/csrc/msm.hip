@@ -476,6 +476,17 @@ __global__ void convert_coords_kernel(u32* pts, u64 n_coords_groups, int coords_
 }
 
 // ---- fixed-base window tables ------------------------------------------------------------------------------
+// compile-time loop: the bodies below are far above the compiler's pragma-unroll budget, and a rolled loop would
+// index the per-point arrays dynamically, i.e. keep them in scratch memory
+template <int I, int N> struct StaticFor {
+    template <class Fn> static __device__ __forceinline__ void up(Fn&& f) { f(std::integral_constant<int, I>()); StaticFor<I + 1, N>::up(f); }
+    template <class Fn> static __device__ __forceinline__ void down(Fn&& f) { StaticFor<I + 1, N>::down(f); f(std::integral_constant<int, I>()); }
+};
+template <int N> struct StaticFor<N, N> {
+    template <class Fn> static __device__ __forceinline__ void up(Fn&&) {}
+    template <class Fn> static __device__ __forceinline__ void down(Fn&&) {}
+};
+
 // pts holds `tables` tables of n affine records; table 0 is given, table j = 2^(c j) * table 0. A lane carries K
 // consecutive points through c doublings per table and shares one field inversion among them for the conversion
 // back to affine (Montgomery's trick); infinity stays (0,0) in every table.
@@ -486,37 +497,34 @@ __global__ __launch_bounds__(128) void window_tables_kernel(u32* pts, u64 n, int
     if (i0 >= n) return;
     F x[K], y[K];
     bool live[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) live[k] = i0 + k < n && Cfg::load_affine(pts + (i0 + k) * Cfg::AFF_WORDS, x[k], y[k]);
+    StaticFor<0, K>::up([&](auto k) { live[k] = i0 + k < n && Cfg::load_affine(pts + (i0 + k) * Cfg::AFF_WORDS, x[k], y[k]); });
     for (int j = 1; j < tables; j++) {
         XYZZ<F> p[K];
+        StaticFor<0, K>::up([&](auto k) { p[k] = live[k] ? xyzz_dbl_affine(x[k], y[k]) : xyzz_inf<F>(); });
+        for (int d = 1; d < c; d++)
+            StaticFor<0, K>::up([&](auto k) { p[k] = xyzz_dbl(p[k]); });     // infinity stays infinity
         F pre[K];
         F run = field_one((F*)0);
-#pragma unroll
-        for (int k = 0; k < K; k++) {
+        StaticFor<0, K>::up([&](auto k) {
             pre[k] = run;
-            if (!live[k]) continue;
-            p[k] = xyzz_dbl_affine(x[k], y[k]);
-            for (int d = 1; d < c; d++) p[k] = xyzz_dbl(p[k]);
-            run = mulk<8>(run, p[k].zzz);
-        }
+            if (live[k]) run = mulk<8>(run, p[k].zzz);
+        });
         F irun = inv(run);                                               // 1 / prod zzz_k
-#pragma unroll
-        for (int k = K - 1; k >= 0; k--) {
+        StaticFor<0, K>::down([&](auto k) {
+            if (i0 + k >= n) return;
             u32* o = pts + ((u64)j * n + i0 + k) * Cfg::AFF_WORDS;
-            if (i0 + k >= n) continue;
-            if (!live[k]) {
+            if (live[k]) {
+                F izzz = mulk<8>(irun, pre[k]);                          // 1 / zzz_k
+                irun = mulk<8>(irun, p[k].zzz);
+                F iz = mulk<8>(izzz, p[k].zz);                           // zz / zzz = 1 / z
+                F izz = sqrk<8>(iz);
+                x[k] = canon(mulk<8>(p[k].x, izz));
+                y[k] = canon(mulk<8>(p[k].y, izzz));
+                Cfg::store_affine_packed(o, x[k], y[k]);
+            } else {
                 for (int w = 0; w < Cfg::AFF_WORDS; w++) o[w] = 0;
-                continue;
             }
-            F izzz = mulk<8>(irun, pre[k]);                              // 1 / zzz_k
-            irun = mulk<8>(irun, p[k].zzz);
-            F iz = mulk<8>(izzz, p[k].zz);                               // zz / zzz = 1 / z
-            F izz = sqrk<8>(iz);
-            x[k] = canon(mulk<8>(p[k].x, izz));
-            y[k] = canon(mulk<8>(p[k].y, izzz));
-            Cfg::store_affine_packed(o, x[k], y[k]);
-        }
+        });
     }
 }
 
