@@ -33,7 +33,7 @@ constexpr int LOG_SEG = 7;            // at most 2^7 entries per lane of the seg
 constexpr u32 FIX_MAX = 32;           // buckets cut into more pieces than this take the block-parallel path
 constexpr u32 MEDIUM_MAX = 4096;      // up to this many pieces: one wave per bucket; above: two-level heavy path
 constexpr u32 HEAVY_TASK = 1024;      // pieces summed by one workgroup of the heavy path
-constexpr int CHUNK = 32;             // buckets per running-sum chunk
+constexpr int CHUNK = 32;             // buckets per running-sum chunk, at most (reduce_chunk)
 
 // ---- curve configurations -------------------------------------------------------------------------
 struct G1Cfg {
@@ -550,6 +550,14 @@ __global__ __launch_bounds__(128) void synth_points_kernel(const u32* table, u64
     Cfg::store_affine_mont256(o, ax, ay);
 }
 
+// buckets per thread of the reduction: a single lane's chain of dependent EC additions runs at ~5 us each, so the
+// kernel is latency-bound below ~2 waves/SIMD: halve the chunk (down to 8) until there are 2^17 threads
+int reduce_chunk(const MsmGeometry& g) {
+    int chunk = g.buckets < (u32)CHUNK ? (int)g.buckets : CHUNK;
+    while (chunk > 8 && (u64)g.bucket_windows() * (g.buckets / chunk) < ((u64)1 << 17)) chunk >>= 1;
+    return chunk;
+}
+
 template <class T> void dev_alloc(T*& p, size_t bytes) { if (p) hipFree(p); p = nullptr; UG_HIP(hipMalloc(&p, bytes ? bytes : 4)); }
 template <class T> void dev_free(T*& p) { if (p) hipFree(p); p = nullptr; }
 
@@ -693,7 +701,7 @@ void MsmWorkspace::reserve(const MsmGeometry& g, bool g2, u64 n_segments, u32 n_
     size_t ptw = g2 ? G2Cfg::PT_WORDS : G1Cfg::PT_WORDS;
     size_t need = (size_t)g.total_buckets() * ptw * 4;
     if (need > bucket_bytes) { dev_alloc(bucket_pts, need); bucket_bytes = need; }
-    int chunk = g.buckets < (u32)CHUNK ? (int)g.buckets : CHUNK;
+    int chunk = reduce_chunk(g);
     size_t cneed = (size_t)g.bucket_windows() * (g.buckets / chunk) * ptw * 4;
     if (cneed > chunk_bytes) { dev_alloc(chunk_pts, cneed); dev_alloc(chunk_pts2, cneed); chunk_bytes = cneed; }
     size_t sneed = (size_t)n_segments * 2 * ptw * 4;
@@ -742,7 +750,7 @@ XYZZ<typename Cfg::F> msm_run(const MsmSchedule& s, MsmWorkspace& ws, const u32*
                            (const HeavyBucket*)s.heavy_list, s.heavy_offsets, ws.task_pts, ws.bucket_pts);
         UG_KERNEL_CHECK();
     }
-    int chunk = g.buckets < (u32)CHUNK ? (int)g.buckets : CHUNK;
+    int chunk = reduce_chunk(g);
     const int bw = g.bucket_windows();                 // bucket sets: one per window, or one in all with window tables
     u32 cpw = g.buckets / chunk;                       // chunks per bucket set
     u32 nchunks = cpw * bw;
