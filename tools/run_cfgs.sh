@@ -10,6 +10,8 @@ PY
 }
 timeout -k 10 600 python bench.py --log-domain 20 --g1-only --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/cfg1.json 2> gpurun_out/cfg1.err && show gpurun_out/cfg1.json || tail -3 gpurun_out/cfg1.err
 timeout -k 10 600 python bench.py --log-domain 24 --mix C --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/cfg2c.json 2> gpurun_out/cfg2c.err && show gpurun_out/cfg2c.json || tail -3 gpurun_out/cfg2c.err
+timeout -k 10 600 python bench.py --log-domain 20 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/q20.json 2> gpurun_out/q20.err && show gpurun_out/q20.json || tail -3 gpurun_out/q20.err
+timeout -k 10 600 python bench.py --log-domain 22 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/q22.json 2> gpurun_out/q22.err && show gpurun_out/q22.json || tail -3 gpurun_out/q22.err
 timeout -k 10 600 python bench.py --log-domain 22 --ultra --steps 3 --warmup 1 > gpurun_out/cfg4.json 2> gpurun_out/cfg4.err && show gpurun_out/cfg4.json || tail -3 gpurun_out/cfg4.err
 ( time timeout -k 10 900 python bench.py --log-domain 26 --steps 2 --warmup 1 --no-cpu-baseline ) > gpurun_out/cfg3.json 2> gpurun_out/cfg3.err && show gpurun_out/cfg3.json || tail -5 gpurun_out/cfg3.err
 tail -4 gpurun_out/cfg3.err
