@@ -216,3 +216,26 @@ def test_groth16_random_blinding_still_verifies(zkey, wtns, vkey):
     import ultragroth_amd as ug
     proof, pub = ug.groth16_prover(zkey, wtns)
     assert pairing.groth16_verify(vkey, pub, proof)
+
+
+def test_one_prover_object_from_several_threads(zkey, wtns, vkey):
+    """the reference's prover object keeps no per-proof state, so callers may share it between threads; here the calls
+    take turns on the object's device buffers: every proof (fresh OS-entropy blinding each) verifies, all differ"""
+    import threading
+    import ultragroth_amd as ug
+    results, errors = [], []
+    with ug.Groth16Prover(zkey) as p:
+        def work():
+            try:
+                for _ in range(2):
+                    results.append(p.prove(wtns))
+            except Exception as e:             # noqa: BLE001 - reported below
+                errors.append(e)
+        threads = [threading.Thread(target=work) for _ in range(3)]
+        for t in threads: t.start()
+        for t in threads: t.join()
+    assert not errors
+    assert len(results) == 6 and len({pr for pr, _ in results}) == 6
+    assert all(pub == results[0][1] for _, pub in results)
+    for proof, pub in results[:3]:
+        assert pairing.groth16_verify(vkey, pub, proof)

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <exception>
 #include <string>
 #include <thread>
@@ -239,6 +240,7 @@ void buildSchedule(ug_schedule* s, const ug_dvec* scalars, uint64_t first, uint6
 }
 
 struct ProverBase {        // what the extern "C" layer stores behind the opaque handle
+    std::mutex proveMutex;
     virtual ~ProverBase() {}
     virtual void prove(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub) = 0;
     virtual unsigned long long proofBufferMinSize() const = 0;
@@ -717,7 +719,12 @@ int proveImpl(void* prover_object, const void* wtns_buffer, unsigned long long w
     ProverBase* prover = static_cast<ProverBase*>(prover_object);
     checkBufferSizes(prover->proofBufferMinSize(), proof_size, prover->publicBufferMinSize(), public_size, "Minimum");
     std::string stringProof, stringPublic;
-    prover->prove(wtns_buffer, wtns_size, stringProof, stringPublic);
+    {
+        // the reference's prover keeps no per-proof state, so callers may prove from several threads on one object;
+        // here the object owns the device buffers of a proof: concurrent calls take turns
+        std::lock_guard<std::mutex> turn(prover->proveMutex);
+        prover->prove(wtns_buffer, wtns_size, stringProof, stringPublic);
+    }
     checkBufferSizes(stringProof.length(), proof_size, stringPublic.length(), public_size, "Required");
     std::strncpy(proof_buffer, stringProof.c_str(), *proof_size);
     std::strncpy(public_buffer, stringPublic.c_str(), *public_size);
