@@ -16,6 +16,7 @@
 #include <memory>
 #include <mutex>
 #include <exception>
+#include <future>
 #include <string>
 #include <thread>
 #include <vector>
@@ -115,31 +116,45 @@ void drawBlinding(uint8_t out[32]) {
     randomBytes(out, 31);
 }
 
-// S12: the seven single scalar multiplications and the sums (src/groth16.cpp:168-195). All five sums come
-// in as affine records; outputs are the affine records of pi_a, pi_b, pi_c.
+// S12: the seven single scalar multiplications and the sums (src/groth16.cpp:168-195). Four of the seven need only
+// the verification key and the blinding scalars: blindingTerms() forms them on four host threads, and a prover that
+// has drawn r and s before its device work starts runs it concurrently with that work.
+struct BlindingTerms {
+    G1XYZZ rDelta1, sDelta1, rsDelta1;
+    G2XYZZ sDelta2;
+};
+BlindingTerms blindingTerms(const ZkeyHeader& h, const uint8_t r[32], const uint8_t s[32]) {
+    u32 rw[8], sw[8], rsw[8];
+    memcpy(rw, r, 32); memcpy(sw, s, 32);
+    // :191-192  rs = toMontgomery(MMul(r, s)) = r * s mod q as a plain integer
+    to_normal(rsw, mul(from_normal<FrParams>(rw), from_normal<FrParams>(sw)));
+    const G1XYZZ delta1 = g1FromRecord(h.delta1);
+    const G2XYZZ delta2 = g2FromRecord(h.delta2);
+    BlindingTerms t;
+    auto f2 = std::async(std::launch::async, [&] { return xyzz_mul_scalar(delta2, sw, 256); });     // :176-177
+    auto fr = std::async(std::launch::async, [&] { return xyzz_mul_scalar(delta1, rw, 256); });     // :172-173
+    auto fs = std::async(std::launch::async, [&] { return xyzz_mul_scalar(delta1, sw, 256); });     // :180-181
+    t.rsDelta1 = xyzz_mul_scalar(delta1, rsw, 256);                                                 // :194-195
+    t.sDelta1 = fs.get(); t.rDelta1 = fr.get(); t.sDelta2 = f2.get();
+    return t;
+}
+// All five sums come in as affine records; outputs are the affine records of pi_a, pi_b, pi_c.
 void blind(uint8_t* outA, uint8_t* outB, uint8_t* outC, const uint8_t* sumA, const uint8_t* sumB1, const uint8_t* sumB2,
            const uint8_t* sumC, const uint8_t* sumH, const ZkeyHeader& h, const uint8_t r[32], const uint8_t s[32],
-           const G1XYZZ* extraSubtract) {
+           const BlindingTerms& t, const G1XYZZ* extraSubtract) {
     u32 rw[8], sw[8];
     memcpy(rw, r, 32); memcpy(sw, s, 32);
     G1XYZZ pi_a = g1FromRecord(sumA), pib1 = g1FromRecord(sumB1), pi_c = g1FromRecord(sumC), pih = g1FromRecord(sumH);
     G2XYZZ pi_b = g2FromRecord(sumB2);
-    G1XYZZ alpha1 = g1FromRecord(h.alpha1), beta1 = g1FromRecord(h.beta1), delta1 = g1FromRecord(h.delta1);
-    G2XYZZ beta2 = g2FromRecord(h.beta2), delta2 = g2FromRecord(h.delta2);
-
-    pi_a = xyzz_add(pi_a, alpha1);                                        // :171
-    pi_a = xyzz_add(pi_a, xyzz_mul_scalar(delta1, rw, 256));              // :172-173
-    pi_b = xyzz_add(pi_b, beta2);                                         // :175
-    pi_b = xyzz_add(pi_b, xyzz_mul_scalar(delta2, sw, 256));              // :176-177
-    pib1 = xyzz_add(pib1, beta1);                                         // :179
-    pib1 = xyzz_add(pib1, xyzz_mul_scalar(delta1, sw, 256));              // :180-181
+    pi_a = xyzz_add(xyzz_add(pi_a, g1FromRecord(h.alpha1)), t.rDelta1);   // :171-173
+    pi_b = xyzz_add(xyzz_add(pi_b, g2FromRecord(h.beta2)), t.sDelta2);    // :175-177
+    pib1 = xyzz_add(xyzz_add(pib1, g1FromRecord(h.beta1)), t.sDelta1);    // :179-181
+    auto fa = std::async(std::launch::async, [&] { return xyzz_mul_scalar(pi_a, sw, 256); });       // :185-186
+    G1XYZZ rB1 = xyzz_mul_scalar(pib1, rw, 256);                          // :188-189
     pi_c = xyzz_add(pi_c, pih);                                           // :183
-    pi_c = xyzz_add(pi_c, xyzz_mul_scalar(pi_a, sw, 256));                // :185-186
-    pi_c = xyzz_add(pi_c, xyzz_mul_scalar(pib1, rw, 256));                // :188-189
-    // :191-192  rs = toMontgomery(MMul(r, s)) = r * s mod q as a plain integer
-    u32 rsw[8];
-    to_normal(rsw, mul(from_normal<FrParams>(rw), from_normal<FrParams>(sw)));
-    pi_c = xyzz_add(pi_c, xyzz_neg(xyzz_mul_scalar(delta1, rsw, 256)));   // :194-195
+    pi_c = xyzz_add(pi_c, fa.get());
+    pi_c = xyzz_add(pi_c, rB1);
+    pi_c = xyzz_add(pi_c, xyzz_neg(t.rsDelta1));                          // :194-195
     if (extraSubtract) pi_c = xyzz_add(pi_c, xyzz_neg(*extraSubtract));   // ultra_groth.cpp:386-388
     g1ToRecord(outA, pi_a); g2ToRecord(outB, pi_b); g1ToRecord(outC, pi_c);   // :197-200
 }
@@ -447,8 +462,12 @@ public:
     void finish(const uint8_t* sums, std::string& proof, std::string& pub) {
         uint8_t r[32], s[32];
         drawBlinding(r); drawBlinding(s);                                                      // S11 :158-166
+        finishWith(sums, r, s, blindingTerms(hdr_, r, s), proof, pub);
+    }
+    void finishWith(const uint8_t* sums, const uint8_t r[32], const uint8_t s[32], const BlindingTerms& terms, std::string& proof,
+                    std::string& pub) {
         uint8_t A[64], B[128], C[64];
-        blind(A, B, C, sums, sums + 64, sums + 128, sums + 256, sums + 320, hdr_, r, s, nullptr);
+        blind(A, B, C, sums, sums + 64, sums + 128, sums + 256, sums + 320, hdr_, r, s, terms, nullptr);
         // nlohmann dump(): keys in lexicographic order, no whitespace (src/groth16.cpp:217-250)
         proof = "{\"pi_a\":" + g1Json(A) + ",\"pi_b\":" + g2Json(B) + ",\"pi_c\":" + g1Json(C) + ",\"protocol\":\"groth16\"}";
         pub = publicJson(publicPart_.data(), hdr_.nPublic, 0);
@@ -457,9 +476,14 @@ public:
     void prove(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub) override {
         auto t0 = std::chrono::steady_clock::now();
         loadWitness(wtns, wtnsSize);
+        // S11 (:158-166) drawn up front, in the reference's order: the multiples of delta that need only r and s are
+        // formed on host threads while the device runs S1-S10
+        uint8_t r[32], s[32];
+        drawBlinding(r); drawBlinding(s);
+        auto terms = std::async(std::launch::async, [&] { return blindingTerms(hdr_, r, s); });
         uint8_t partials[UG_GROTH16_PARTIALS_SIZE];
-        run(partials);
-        finish(partials, proof, pub);
+        run(partials);                                   // (the future joins in its destructor if this throws)
+        finishWith(partials, r, s, terms.get(), proof, pub);
         totalMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 
@@ -597,6 +621,19 @@ public:
             if (patchIdx[i] <= hdr_.nPublic) memcpy(publicPart.data() + (size_t)patchIdx[i] * 32, patchVal.data() + i * 32, 32);
 
         // ---- final round (execute_final_round :187-399)
+        // r and s (:345-346) are drawn here, still after the round randomness as in the reference, so that the multiples
+        // of the deltas that need only the blinding scalars are formed on host threads beside the device work
+        uint8_t r[32], s[32];
+        drawBlinding(r); drawBlinding(s);
+        struct HostTerms { BlindingTerms b; G1XYZZ roundTerm; };
+        auto terms = std::async(std::launch::async, [&] {
+            HostTerms t;
+            auto fr = std::async(std::launch::async, [&] { return xyzz_mul_scalar(g1FromRecord(hdr_.roundDelta1), rkw, 256); });   // :386-388
+            t.b = blindingTerms(hdr_, r, s);
+            t.roundTerm = fr.get();
+            return t;
+        });
+        // (a std::async future joins in its destructor, and r, s, rkw are declared before it: they outlive the threads)
         buildSchedule(d_.sw, d_.w, 0, M, tableW_);
         uint8_t sums[UG_GROTH16_PARTIALS_SIZE];
         ugCheck(ug_msm_g1(d_.ctx, d_.A, d_.sw, 0, sums));                                   // MSM1 :201
@@ -610,11 +647,9 @@ public:
         ugCheck(ug_msm_g1(d_.ctx, d_.H, d_.sh, 0, sums + 320));                             // MSM5 :322
         ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
 
-        uint8_t r[32], s[32];
-        drawBlinding(r); drawBlinding(s);                                                   // :345-346
-        G1XYZZ roundTerm = xyzz_mul_scalar(g1FromRecord(hdr_.roundDelta1), rkw, 256);       // :386-388
+        HostTerms ht = terms.get();
         uint8_t A[64], B[128], C[64];
-        blind(A, B, C, sums, sums + 64, sums + 128, sums + 256, sums + 320, hdr_, r, s, &roundTerm);
+        blind(A, B, C, sums, sums + 64, sums + 128, sums + 256, sums + 320, hdr_, r, s, ht.b, &ht.roundTerm);
         // keys pi_a, pi_b, pi_f, pi_r, protocol (src/ultra_groth.cpp:476-513)
         proof = "{\"pi_a\":" + g1Json(A) + ",\"pi_b\":" + g2Json(B) + ",\"pi_f\":" + g1Json(C) + ",\"pi_r\":" + g1Json(commitRec) +
                 ",\"protocol\":\"ultragroth\"}";
