@@ -92,6 +92,27 @@ def cpu_baseline(dev, args, log_domain):
     }
 
 
+# One iFFT/twist/FFT chain costs about this fraction of ALL the witness MSMs of a proof (2^24, measured with
+# tools/phase_times.py: chains a, b 7.1 ms and c 9.0 ms -- it also forms a.b -- against 113 ms; both sides grow ~linearly)
+CHAIN_SHARE = (0.063, 0.063, 0.080)
+
+
+def witness_slice(info, rank, world):
+    """Rank k's slice of the witness-indexed sections. Chain k of the H polynomial runs on rank k mod N beside that
+    rank's witness MSMs, so the ranks that carry chains get fewer points: shares s_k = base - chains_k, sum s_k = 1."""
+    if world == 1 or info["domainSize"] % world:
+        return None                              # even split (and no split H polynomial)
+    extra = [sum(CHAIN_SHARE[c] for c in range(3) if c % world == k) for k in range(world)]
+    base = (1.0 + sum(extra)) / world
+    shares = [max(base - e, 0.0) for e in extra]
+    tot = sum(shares)
+    n = info["nVars"]
+    cuts = [0]
+    for k in range(world):
+        cuts.append(n if k == world - 1 else min(n, int(round(n * sum(shares[:k + 1]) / tot))))
+    return cuts[rank], cuts[rank + 1]
+
+
 def bench_ultra(args, dev, ug, synth):
     """UltraGroth: the whole ultra_groth_prover_prove call (witness upload, round-1 commitment MSM, Keccak
     challenge, host lookup completion, final-round MSMs + H polynomial, blinding, JSON)."""
@@ -155,7 +176,7 @@ def main():
         return bench_ultra(args, dev, ug, synth)
     zkey, wtns, info = synth.build_circuit(dev, log_domain, mix=args.mix, g1_only=args.g1_only)
     t0 = time.perf_counter()
-    prover = ug.ShardedGroth16Prover(zkey, local_rank, rank, world)
+    prover = ug.ShardedGroth16Prover(zkey, local_rank, rank, world, witness_range=witness_slice(info, rank, world))
     create_s = time.perf_counter() - t0
     zkey_bytes = len(zkey)
     del zkey
@@ -253,7 +274,8 @@ def main():
     if rank == 0:
         acc_ms, launches, entries = prover.kernel_stats(g2=False)
         g2_ms, g2_launches, _ = prover.kernel_stats(g2=True)
-        n_local = info["nVars"] // world
+        ws = witness_slice(info, 0, world)
+        n_local = (ws[1] - ws[0]) if ws else info["nVars"] // world
         # G1 bucket accumulation: algorithmic bytes of one G1 MSM launch = 96 B per point of the slice
         # (64 B affine base + 32 B scalar, each read once)
         g1_bytes = 96.0 * n_local

@@ -126,6 +126,13 @@ int ug_prover_kernel_stats(void *prover_object, int g2, double *accumulate_ms_av
 int ug_groth16_prover_create_sharded(void **prover_object, const void *zkey_buffer, unsigned long long zkey_size,
                                      int device, int shard_rank, int shard_count,
                                      char *error_msg, unsigned long long error_msg_maxsize);
+/* The same with the rank's slice [witness_first, witness_end) of the witness-indexed sections (A, B1, B2 and, shifted
+ * by nPublic + 1, C) chosen by the caller, whose ranks must tile [0, nVars): ranks that also run an H-polynomial chain
+ * (ug_groth16_prover_hpoly_chain) can be given fewer points. The H section stays split evenly. */
+int ug_groth16_prover_create_sharded_range(void **prover_object, const void *zkey_buffer, unsigned long long zkey_size,
+                                           int device, int shard_rank, int shard_count,
+                                           unsigned long long witness_first, unsigned long long witness_end,
+                                           char *error_msg, unsigned long long error_msg_maxsize);
 /* upload the witness (wtns file buffer) to the device; returns PROVER_INVALID_WITNESS_LENGTH etc. */
 int ug_groth16_prover_load_witness(void *prover_object, const void *wtns_buffer, unsigned long long wtns_size,
                                    char *error_msg, unsigned long long error_msg_maxsize);

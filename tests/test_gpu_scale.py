@@ -111,6 +111,32 @@ def test_sharded_prover_equals_unsharded(device, zkey, wtns):
         p.close()
 
 
+def test_sharded_prover_with_caller_chosen_ranges(device, zkey, wtns):
+    """uneven witness slices (bench.py gives ranks that also run an NTT chain fewer points), one of them empty and one
+    cutting through the public signals, so the C section's shifted range starts mid-slice"""
+    import ultragroth_amd as ug
+    r, s = fixed_rs()
+    n = O.zkey_info(zkey)["nVars"]
+    cuts = [0, 1, 1, n // 3, n]
+    ranks = [ug.ShardedGroth16Prover(zkey, 0, k, 4, witness_range=(cuts[k], cuts[k + 1])) for k in range(4)]
+    total = None
+    for p in ranks:
+        p.load_witness(wtns)
+        part = p.run()
+        total = part if total is None else ug.ShardedGroth16Prover.add_partials(total, part)
+    ug.set_test_blinding(r + s)
+    try:
+        proof, pub = ranks[0].finish(total)
+    finally:
+        ug.set_test_blinding(b"")
+    exp = O.groth16_prove(zkey, wtns, int.from_bytes(r, "little"), int.from_bytes(s, "little"))
+    assert (proof, pub) == (exp[0], exp[1])
+    with pytest.raises(ug.ProverError, match="witness range outside"):
+        ug.ShardedGroth16Prover(zkey, 0, 0, 2, witness_range=(0, n + 1))
+    for p in ranks:
+        p.close()
+
+
 def test_sharded_prover_with_split_hpoly(device):
     """the N > 1 path with the H-polynomial chains split over ranks (as bench.py does over RCCL), on one GPU:
     rank k mod 2 computes chain k into a device buffer, each rank combines its slices, proofs match the oracle"""

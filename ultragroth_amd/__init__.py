@@ -172,11 +172,17 @@ def ultra_groth_prover(zkey, wtns):
 class ShardedGroth16Prover:
     """One rank of a base-point-sharded Groth16 prover (one process per GPU): see include/prover.h."""
 
-    def __init__(self, zkey, device, rank, world):
+    def __init__(self, zkey, device, rank, world, witness_range=None):
+        """witness_range = (first, end): this rank's slice of the witness-indexed sections, chosen by the caller
+        (ug_groth16_prover_create_sharded_range); None = the even split"""
         L = load()
         self._h = C.c_void_p()
         err = C.create_string_buffer(1024)
-        rc = L.ug_groth16_prover_create_sharded(C.byref(self._h), zkey, len(zkey), device, rank, world, err, len(err) - 1)
+        if witness_range is None:
+            rc = L.ug_groth16_prover_create_sharded(C.byref(self._h), zkey, len(zkey), device, rank, world, err, len(err) - 1)
+        else:
+            rc = L.ug_groth16_prover_create_sharded_range(C.byref(self._h), zkey, len(zkey), device, rank, world,
+                                                          witness_range[0], witness_range[1], err, len(err) - 1)
         if rc != PROVER_OK:
             self._h = None
             raise ProverError(rc, err.value.decode(errors="replace"))

@@ -282,7 +282,9 @@ const uint8_t* checkedSection(const BinFile& f, uint32_t id, uint64_t needBytes)
 // =================================================================================================================
 class Groth16Prover : public ProverBase {
 public:
-    Groth16Prover(const void* zkey, unsigned long long zkeySize, int device, int rank, int count)
+    // witnessRange: the slice of the witness-indexed sets (A, B1, B2, C) this rank owns, when the caller balances the
+    // ranks itself (ug_groth16_prover_create_sharded_range); nullptr = the even split
+    Groth16Prover(const void* zkey, unsigned long long zkeySize, int device, int rank, int count, const Range* witnessRange = nullptr)
         : rank_(rank), count_(count) {
         if (count < 1 || rank < 0 || rank >= count) throw std::invalid_argument("invalid shard rank / count");
         BinFile f(zkey, zkeySize, "zkey", 1);
@@ -303,6 +305,10 @@ public:
         const uint8_t* pH = checkedSection(f, 9, N * 64);
 
         wr_ = shardRange(M, rank, count);        // witness scalars (and A/B1/B2 points) of this rank
+        if (witnessRange) {
+            if (witnessRange->lo > witnessRange->hi || witnessRange->hi > M) throw std::invalid_argument("witness range outside [0, nVars]");
+            wr_ = *witnessRange;
+        }
         hr_ = shardRange(N, rank, count);        // h scalars (and H points) of this rank
         const uint64_t shift = (uint64_t)hdr_.nPublic + 1;
         uint64_t cLo = wr_.lo > shift ? wr_.lo - shift : 0, cHi = wr_.hi > shift ? wr_.hi - shift : 0;
@@ -921,6 +927,16 @@ int ug_groth16_prover_create_sharded(void** prover_object, const void* zkey_buff
     if (prover_object == NULL) throw std::invalid_argument("Null prover object");
     if (zkey_buffer == NULL) throw std::invalid_argument("Null zkey buffer");
     *prover_object = static_cast<ProverBase*>(new Groth16Prover(zkey_buffer, zkey_size, device, shard_rank, shard_count));
+    API_CATCH
+}
+int ug_groth16_prover_create_sharded_range(void** prover_object, const void* zkey_buffer, unsigned long long zkey_size, int device,
+                                           int shard_rank, int shard_count, unsigned long long witness_first,
+                                           unsigned long long witness_end, char* error_msg, unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL) throw std::invalid_argument("Null prover object");
+    if (zkey_buffer == NULL) throw std::invalid_argument("Null zkey buffer");
+    Range wr{witness_first, witness_end};
+    *prover_object = static_cast<ProverBase*>(new Groth16Prover(zkey_buffer, zkey_size, device, shard_rank, shard_count, &wr));
     API_CATCH
 }
 int ug_groth16_prover_load_witness(void* prover_object, const void* wtns_buffer, unsigned long long wtns_size, char* error_msg,
