@@ -458,6 +458,26 @@ __global__ __launch_bounds__(128) void ec_sum_groups_kernel(const u32* in, u32* 
     Cfg::to_words(out + (size_t)t * Cfg::PT_WORDS, acc, 1);
 }
 
+// The same sum with one WAVE per output: lanes stride over the group, then a cross-lane butterfly. A single lane's
+// dependent EC additions run at ~5 us each, so the short last levels of the tree are latency-bound: 16 serial additions
+// per level become group/64 + 6.
+template <class Cfg>
+__global__ __launch_bounds__(256) void ec_sum_wave_kernel(const u32* in, u32* out, u32 n_out, int group) {
+    typedef typename Cfg::F F;
+    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= n_out) return;
+    XYZZ<F> acc = xyzz_inf<F>();
+    for (int g = (int)lane; g < group; g += 64) acc = xyzz_add(acc, Cfg::from_words(in + ((size_t)wave * group + g) * Cfg::PT_WORDS, 1));
+    u32 w[Cfg::PT_WORDS];
+    for (int off = 32; off > 0; off >>= 1) {
+        Cfg::to_words(w, acc, 1);
+#pragma unroll
+        for (int i = 0; i < Cfg::PT_WORDS; i++) w[i] = __shfl_xor(w[i], off, 64);
+        acc = xyzz_add(acc, Cfg::from_words(w, 1));
+    }
+    if (lane == 0) Cfg::to_words(out + (size_t)wave * Cfg::PT_WORDS, acc, 1);
+}
+
 // ---- zkey point conversion ------------------------------------------------------------------------------
 __global__ void convert_coords_kernel(u32* pts, u64 n_coords_groups, int coords_per_point) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -759,12 +779,20 @@ XYZZ<typename Cfg::F> msm_run(const MsmSchedule& s, MsmWorkspace& ws, const u32*
     UG_KERNEL_CHECK();
     u32* cur = ws.chunk_pts; u32* nxt = ws.chunk_pts2;
     while (cpw > 1) {
-        int group = cpw >= 16 ? 16 : (int)cpw;
-        u32 n_out = (cpw / group) * bw;
-        hipLaunchKernelGGL(ec_sum_groups_kernel<Cfg>, dim3((n_out + 127) / 128), dim3(128), 0, stream, cur, nxt, n_out, group);
+        // a lane per output (16 serial additions) while that still fills the chip, then a wave per output
+        if ((u64)(cpw / 16) * bw >= 8192) {
+            const int group = 16;
+            u32 n_out = (cpw / group) * bw;
+            hipLaunchKernelGGL(ec_sum_groups_kernel<Cfg>, dim3((n_out + 127) / 128), dim3(128), 0, stream, cur, nxt, n_out, group);
+            cpw /= group;
+        } else {
+            const int group = cpw >= 256 ? 256 : (int)cpw;
+            u32 n_out = (cpw / group) * bw;
+            hipLaunchKernelGGL(ec_sum_wave_kernel<Cfg>, dim3((n_out + 3) / 4), dim3(256), 0, stream, cur, nxt, n_out, group);
+            cpw /= group;
+        }
         UG_KERNEL_CHECK();
         std::swap(cur, nxt);
-        cpw /= group;
     }
     std::vector<u32> host((size_t)bw * Cfg::PT_WORDS);
     UG_HIP(hipMemcpyAsync(host.data(), cur, host.size() * 4, hipMemcpyDeviceToHost, stream));
