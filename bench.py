@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also compare the proof with the oracle (small sizes)")
     ap.add_argument("--g1-only", action="store_true", help="BASELINE.json configs[1]: G1 MSM + NTT only (B1/B2/C sets at infinity)")
+    ap.add_argument("--overlap", action="store_true", help="ULTRAGROTH_OVERLAP=1: H branch on a second stream beside the witness MSMs "
+                                                           "(faster, but per-kernel times and the MSM | FFT split stretch)")
     ap.add_argument("--ultra", action="store_true", help="BASELINE.json configs[4]: UltraGroth two-round prove (single GPU)")
     return ap.parse_args()
 
@@ -155,6 +157,8 @@ def main():
     import torch
     import ultragroth_amd as ug
     from ultragroth_amd import synth
+    if args.overlap:
+        os.environ["ULTRAGROTH_OVERLAP"] = "1"
 
     # UG_BENCH_BACKEND=gloo + UG_BENCH_ONE_DEVICE=1 rehearse the N > 1 control flow on a one-GPU box
     # (RCCL refuses two ranks on one device); the driver's multi-GPU runs use the defaults: nccl, one GPU per rank.
@@ -297,7 +301,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "groth16-bn254 2^%d constraints, nVars 2^%d-1, nCoefs 4N, full G1+G2 MSM + H-poly FFT, "
                                    "scalar mix %s (BASELINE.json configs[%d] shape)" % (log_domain, log_domain, args.mix, 1 if args.g1_only else 2),
-                       "log_domain": log_domain, "mix": args.mix, "parallelism": "base-range shard x%d%s" % (world, ", H-poly chains split over ranks" if split_h else "")},
+                       "log_domain": log_domain, "mix": args.mix, "overlap": bool(os.environ.get("ULTRAGROTH_OVERLAP", "0") not in ("", "0")), "parallelism": "base-range shard x%d%s" % (world, ", H-poly chains split over ranks" if split_h else "")},
             "msm_ms_per_proof": msm_ms / args.steps, "fft_ms_per_proof": fft_ms / args.steps,
             "create_s": create_s, "witness_upload_s": upload_s, "zkey_bytes": zkey_bytes,
             "host_peak_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 2),

@@ -423,14 +423,15 @@ public:
     // S1-S10 on this rank's slices with the H-polynomial block computed locally (replicated when sharded).
     // With ULTRAGROTH_OVERLAP=1 two host threads drive two streams: S1-S4 on one, S5-S10 (H polynomial, its schedule,
     // the H MSM) on the other, so the memory-bound kernels of one branch overlap the integer-bound kernels of the other
-    // (measured: 168 -> 162 ms per 2^24 proof). Off by default: overlapped kernels stretch each other, which blurs the
+    // (measured: 148 -> 144 ms per 2^24 proof, 49.9 -> 46.7 ms at 2^22). Off by default: overlapped kernels stretch each other, which blurs the
     // per-kernel durations and the MSM | FFT split that bench.py and rocprof report.
     void run(uint8_t* partials) {
         if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
         ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1));
         ugCheck(ug_ctx_timings(d_.ctx2, nullptr, nullptr, 1));
         uint8_t hpart[UG_GROTH16_PARTIALS_SIZE];
-        static const bool overlap = getenv("ULTRAGROTH_OVERLAP") && atoi(getenv("ULTRAGROTH_OVERLAP")) != 0;
+        const char* ov = getenv("ULTRAGROTH_OVERLAP");
+        const bool overlap = ov && atoi(ov) != 0;
         if (!overlap) {
             runWitnessMsm(partials, /*resetTimers*/ false);
             ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                          // S5-S9 :66-148
