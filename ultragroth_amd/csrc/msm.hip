@@ -38,7 +38,8 @@ constexpr int CHUNK = 32;             // buckets per running-sum chunk, at most 
 // ---- curve configurations -------------------------------------------------------------------------
 struct G1Cfg {
     typedef Fq F;
-    static constexpr int AFF_WORDS = 16, PT_WORDS = 36, BLOCK = 256, ACC_WAVES = 3;
+    static constexpr int AFF_WORDS = 16, PT_WORDS = 36, BLOCK = 256, ACC_WAVES = 3;      // accumulate kernel: 168 VGPRs, 3 waves/SIMD
+    static constexpr bool PREFETCH = true;  // (4 waves at 128 VGPRs without the prefetch registers: 18.1 vs 15.2 ms)
     static __device__ __forceinline__ bool load_affine(const u32* p, F& x, F& y) {
         u32 w[16];
         load8(w, p); load8(w + 8, p + 8);
@@ -84,7 +85,8 @@ struct G1Cfg {
 };
 struct G2Cfg {
     typedef Fq2 F;
-    static constexpr int AFF_WORDS = 32, PT_WORDS = 72, BLOCK = 128, ACC_WAVES = 1;
+    static constexpr int AFF_WORDS = 32, PT_WORDS = 72, BLOCK = 128, ACC_WAVES = 2;      // 256 VGPRs with ~30 spilled registers beat 1 wave/SIMD at 392 (41.5 vs 43.4 ms)
+    static constexpr bool PREFETCH = false; // ... once the 32 prefetch registers are given up; the second wave hides the gather
     static __device__ __forceinline__ bool load_affine(const u32* p, F& x, F& y) {
         u32 w[32];
         load8(w, p); load8(w + 8, p + 8); load8(w + 16, p + 16); load8(w + 24, p + 24);
@@ -265,34 +267,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Cfg::ACC_WA
     bool first_run = true;
     const bool start_open = lo > 0 && keys[lo - 1] == cur;
     XYZZ<F> acc = xyzz_inf<F>();
-    // software pipeline: the raw record of entry k + 1 is in flight while entry k is added
-    u32 raw[Cfg::AFF_WORDS];
     // entry = scalar index | table << 27 | sign << 31; table j of a base set starts j * n_bases records in
     const u32 IDX_MASK = (1u << TABLE_INDEX_BITS) - 1;
-    u32 nkey = cur, nval = tvals[tbase];
-    int64_t nidx = (int64_t)(nval & IDX_MASK) + delta;
-    bool nin = nidx >= 0 && (u64)nidx < n_bases;
-    if (nin) Cfg::load_raw(raw, bases + ((u64)((nval >> TABLE_INDEX_BITS) & 15u) * n_bases + (u64)nidx) * Cfg::AFF_WORDS);
-    for (u32 k = 0; k < cnt; k++) {
-        F x, y;
-        bool valid = nin && Cfg::decode_affine(raw, x, y);
-        if (valid && (nval >> 31)) y = neg<1>(y);
-        u32 key = nkey;
-        if (k + 1 < cnt) {
-            nkey = tkeys[tbase + ((u64)(k + 1) << 6)];
-            nval = tvals[tbase + ((u64)(k + 1) << 6)];
-            nidx = (int64_t)(nval & IDX_MASK) + delta;
-            nin = nidx >= 0 && (u64)nidx < n_bases;
-            if (nin) Cfg::load_raw(raw, bases + ((u64)((nval >> TABLE_INDEX_BITS) & 15u) * n_bases + (u64)nidx) * Cfg::AFF_WORDS);
+    auto close_run = [&](u32 key) {                // the previous run ended inside the segment
+        u32* dst = (first_run && start_open) ? slot_pts + (size_t)(2 * t) * Cfg::PT_WORDS : bucket_pts + (size_t)cur * Cfg::PT_WORDS;
+        Cfg::to_words(dst, acc, 1);
+        acc = xyzz_inf<F>();
+        cur = key;
+        first_run = false;
+    };
+    if constexpr (Cfg::PREFETCH) {
+        // software pipeline: the raw record of entry k + 1 is in flight while entry k is added
+        u32 raw[Cfg::AFF_WORDS];
+        u32 nkey = cur, nval = tvals[tbase];
+        int64_t nidx = (int64_t)(nval & IDX_MASK) + delta;
+        bool nin = nidx >= 0 && (u64)nidx < n_bases;
+        if (nin) Cfg::load_raw(raw, bases + ((u64)((nval >> TABLE_INDEX_BITS) & 15u) * n_bases + (u64)nidx) * Cfg::AFF_WORDS);
+        for (u32 k = 0; k < cnt; k++) {
+            F x, y;
+            bool valid = nin && Cfg::decode_affine(raw, x, y);
+            if (valid && (nval >> 31)) y = neg<1>(y);
+            u32 key = nkey;
+            if (k + 1 < cnt) {
+                nkey = tkeys[tbase + ((u64)(k + 1) << 6)];
+                nval = tvals[tbase + ((u64)(k + 1) << 6)];
+                nidx = (int64_t)(nval & IDX_MASK) + delta;
+                nin = nidx >= 0 && (u64)nidx < n_bases;
+                if (nin) Cfg::load_raw(raw, bases + ((u64)((nval >> TABLE_INDEX_BITS) & 15u) * n_bases + (u64)nidx) * Cfg::AFF_WORDS);
+            }
+            if (key != cur) close_run(key);
+            if (valid) acc = xyzz_madd(acc, x, y);
         }
-        if (key != cur) {                          // the previous run ended inside the segment
-            u32* dst = (first_run && start_open) ? slot_pts + (size_t)(2 * t) * Cfg::PT_WORDS : bucket_pts + (size_t)cur * Cfg::PT_WORDS;
-            Cfg::to_words(dst, acc, 1);
-            acc = xyzz_inf<F>();
-            cur = key;
-            first_run = false;
+    } else {
+        // no prefetch registers: a second resident wave hides the gather instead
+        for (u32 k = 0; k < cnt; k++) {
+            const u32 key = tkeys[tbase + ((u64)k << 6)], val = tvals[tbase + ((u64)k << 6)];
+            const int64_t idx = (int64_t)(val & IDX_MASK) + delta;
+            F x, y;
+            bool valid = idx >= 0 && (u64)idx < n_bases &&
+                         Cfg::load_affine(bases + ((u64)((val >> TABLE_INDEX_BITS) & 15u) * n_bases + (u64)idx) * Cfg::AFF_WORDS, x, y);
+            if (valid && (val >> 31)) y = neg<1>(y);
+            if (key != cur) close_run(key);
+            if (valid) acc = xyzz_madd(acc, x, y);
         }
-        if (valid) acc = xyzz_madd(acc, x, y);
     }
     const bool end_open = hi < n_valid && keys[hi] == cur;
     u32* dst;
