@@ -88,6 +88,13 @@ int  ug_dvec_gather(ug_dvec* out, const ug_dvec* src, const uint32_t* host_index
 /* dst[index[i]] = values[i] for i < n; indices must be distinct (UltraGroth lookup signals written back into the
  * witness, src/ultra_groth.cpp:99-105) */
 int  ug_dvec_scatter(ug_dvec* dst, const uint32_t* host_index, const void* host_values, uint64_t n);
+/* UltraGroth lookup completion (the loop of compute_lookup, src/ultra_groth.cpp:99-105, with its push_vector :62-98
+ * left implicit): for i < n in order  dst[w_idx[i]] = push[p_idx[i]],  where
+ *   push = [ table[0] | table[1 + chunks[j]] for j < n_chunks | table[1], ..., table[2 L] ],
+ * table = [challenge | inv2[0..L) | prod[0..L)] as plain 32-byte integers (L = lookup_size). Writes to one index keep
+ * the last. All arrays are host arrays; indices out of range fail with nothing written. */
+int  ug_dvec_apply_lookup(ug_dvec* dst, const uint32_t* w_idx, const uint32_t* p_idx, uint64_t n,
+                          const uint32_t* chunks, uint64_t n_chunks, const void* table, uint64_t lookup_size);
 /* non-owning view of n 32-byte elements already in device memory (e.g. a torch / RCCL buffer) */
 int  ug_dvec_wrap(ug_ctx* ctx, void* device_ptr, uint64_t n, ug_dvec** out);
 uint64_t ug_dvec_size(const ug_dvec* v);

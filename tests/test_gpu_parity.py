@@ -174,6 +174,39 @@ def test_msm_window_tables_errors(device, zkey):
     assert 16 <= device.table_window(1 << 24) <= 24
 
 
+def test_lookup_completion_last_write_wins(device):
+    """ug_dvec_apply_lookup == the reference's loop `wtns[w_idx[i]] = push[p_idx[i]]` over the explicit push vector
+    [rand | inv2[chunks[j]] | inv2 | prod], with repeated targets (the last write must win) and every region of push"""
+    import numpy as np
+    import ultragroth_amd as ug
+    rng = np.random.Generator(np.random.PCG64(21))
+    n_dst, L, n_chunks, n = 5000, 16, 300, 4000
+    table = rng.integers(0, 256, size=(1 + 2 * L, 32), dtype=np.uint8)
+    chunks = rng.integers(0, L, size=n_chunks, dtype=np.uint32)
+    push = np.concatenate([table[0:1], table[1 + chunks], table[1:]])
+    assert len(push) == 1 + n_chunks + 2 * L
+    w_idx = rng.integers(0, 600, size=n, dtype=np.uint32)                 # heavy repetition
+    w_idx[::7] = rng.integers(0, n_dst, size=len(w_idx[::7]), dtype=np.uint32)
+    p_idx = rng.integers(0, len(push), size=n, dtype=np.uint32)
+    p_idx[:3] = (0, n_chunks, len(push) - 1)
+    start = rng.integers(0, 256, size=(n_dst, 32), dtype=np.uint8)
+    exp = start.copy()
+    for i in range(n):
+        exp[w_idx[i]] = push[p_idx[i]]
+    v = device.dvec(n_dst, start.tobytes())
+    device.apply_lookup(v, w_idx, p_idx, chunks, table.tobytes(), L)
+    assert device.download(v, 0, n_dst) == exp.tobytes()
+    device.apply_lookup(v, w_idx, p_idx, chunks, table.tobytes(), L)       # scratch left clean: same result again
+    assert device.download(v, 0, n_dst) == exp.tobytes()
+    bad = p_idx.copy(); bad[5] = len(push)
+    with pytest.raises(ug.DeviceError, match="lookup index out of range"):
+        device.apply_lookup(v, w_idx, bad, chunks, table.tobytes(), L)
+    badc = chunks.copy(); badc[0] = L
+    with pytest.raises(ug.DeviceError, match="chunk index outside"):
+        device.apply_lookup(v, w_idx, p_idx, badc, table.tobytes(), L)
+    assert device.download(v, 0, n_dst) == exp.tobytes()
+
+
 def test_hpoly_matches_oracle_and_known_answers(device, zkey, wtns):
     info = O.zkey_info(zkey)
     coefs = _sec(zkey, "zkey", 4)[4:]

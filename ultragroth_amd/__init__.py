@@ -311,6 +311,13 @@ class Device:
         _check(self._L.ug_dvec_download(dvec.h, out, first, n))
         return out.raw
 
+    def apply_lookup(self, dvec, w_idx, p_idx, chunks, table, lookup_size):
+        """ug_dvec_apply_lookup: dvec[w_idx[i]] = push[p_idx[i]] in order (numpy uint32 index arrays, table bytes)"""
+        import numpy as np
+        w = np.ascontiguousarray(w_idx, dtype=np.uint32); p = np.ascontiguousarray(p_idx, dtype=np.uint32)
+        c = np.ascontiguousarray(chunks, dtype=np.uint32)
+        _check(self._L.ug_dvec_apply_lookup(dvec.h, w.ctypes.data, p.ctypes.data, len(w), c.ctypes.data, len(c), table, lookup_size))
+
     def schedule(self, dvec, first, count, table_c=0):
         h = C.c_void_p()
         _check(self._L.ug_schedule_create(self._h, C.byref(h)))

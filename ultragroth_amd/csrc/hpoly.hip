@@ -133,6 +133,33 @@ __global__ void scatter_kernel(u32* dst, const u32* index, const u32* values, u6
     store8(dst + j * 8, w);
 }
 
+// ---- UltraGroth lookup completion (src/ultra_groth.cpp:62-106) --------------------------------------------
+// The reference runs  for i in order: wtns[w_idx[i]] = push[p_idx[i]]  on the host, with
+// push = [rand | inv2[chunks[j]] for every chunk j | inv2[0..L) | prod[0..L)]. Here push is never materialised:
+// `table` = [rand | inv2 | prod] (1 + 2L elements) and the chunk indirection is resolved per write. Writes to the
+// same index keep the LAST one: pass 1 records the highest i per target, pass 2 lets only that i write, pass 3
+// clears the scratch.
+__global__ void lookup_mark_kernel(u32* last, const u32* w_idx, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicMax(&last[w_idx[i]], (u32)i + 1);
+}
+__global__ void lookup_write_kernel(u32* dst, const u32* last, const u32* w_idx, const u32* p_idx, u64 n, const u32* chunks,
+                                    u64 n_chunks, const u32* table) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 j = w_idx[i];
+    if (last[j] != (u32)i + 1) return;
+    const u64 p = p_idx[i];
+    u64 t = p == 0 ? 0 : p <= n_chunks ? 1 + (u64)chunks[p - 1] : p - n_chunks;      // element of `table`
+    u32 w[8];
+    load8(w, table + t * 8);
+    store8(dst + (u64)j * 8, w);
+}
+__global__ void lookup_clear_kernel(u32* last, const u32* w_idx, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) last[w_idx[i]] = 0;
+}
+
 template <class T> void dev_alloc(T*& p, size_t bytes) { if (p) hipFree(p); p = nullptr; UG_HIP(hipMalloc(&p, bytes ? bytes : 4)); }
 inline unsigned grid_for(u64 n, int block) { return (unsigned)((n + block - 1) / block); }
 
@@ -215,6 +242,16 @@ void gather_elements(u32* out, const u32* src, const u32* index_dev, u64 n, u64 
 void scatter_elements(u32* dst, const u32* index_dev, const u32* values_dev, u64 n, u64 dst_n, hipStream_t stream) {
     if (!n) return;
     hipLaunchKernelGGL(scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, dst, index_dev, values_dev, n, dst_n);
+    UG_KERNEL_CHECK();
+}
+void apply_lookup(u32* dst, u32* last_scratch, const u32* w_idx, const u32* p_idx, u64 n, const u32* chunks, u64 n_chunks,
+                  const u32* table, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(lookup_mark_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, last_scratch, w_idx, n);
+    UG_KERNEL_CHECK();
+    hipLaunchKernelGGL(lookup_write_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, dst, last_scratch, w_idx, p_idx, n, chunks, n_chunks, table);
+    UG_KERNEL_CHECK();
+    hipLaunchKernelGGL(lookup_clear_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, last_scratch, w_idx, n);
     UG_KERNEL_CHECK();
 }
 void f_op_mont256(int which, int op, u32* out, const u32* a, const u32* b, u64 n, hipStream_t stream) {

@@ -11,6 +11,7 @@
 //   extern "C" entry points and error mapping     src/prover.cpp:311-891
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -589,13 +590,27 @@ public:
         std::vector<uint32_t> chunks = u32Section(3), freq = u32Section(4), wIdx = u32Section(5), pIdx = u32Section(6);
         if (wIdx.size() != pIdx.size()) throw std::range_error("uwtns: wtns_indxs and push_indxs differ in length");
 
+        // ULTRAGROTH_TRACE=1: host wall-clock per phase on stderr (where the non-MSM, non-FFT time of a proof goes)
+        const bool trace = getenv("ULTRAGROTH_TRACE") && atoi(getenv("ULTRAGROTH_TRACE")) != 0;
+        auto tPhase = std::chrono::steady_clock::now();
+        auto mark = [&](const char* what) {
+            if (!trace) return;
+            ug_ctx_sync(d_.ctx);
+            auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "[ultragroth] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - tPhase).count());
+            tPhase = now;
+        };
+        mark("parse uwtns");
         ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1));
         // ---- round 1: commitment to the round witnesses (ultra_groth.cpp:415-419, execute_round :161-184)
         ugCheck(ug_dvec_upload(d_.w, signals0, M));
+        mark("witness upload");
         ugCheck(ug_dvec_gather(d_.aux, d_.w, roundIdx_.data(), roundIdx_.size()));
+        mark("round gather");
         buildSchedule(d_.saux, d_.aux, 0, roundIdx_.size(), tableC1_);
         uint8_t commitRec[64];
         ugCheck(ug_msm_g1(d_.ctx, d_.roundC, d_.saux, 0, commitRec));
+        mark("round MSM");
         uint8_t rk[32];
         drawBlinding(rk);                                                                   // :173
         u32 rkw[8];
@@ -617,15 +632,12 @@ public:
         for (int i = 0; i < 32; i++) chw[7 - (i >> 2)] |= (u32)ch[i] << (24 - 8 * (i & 3));
         Fr rand = from_normal<FrParams>(chw);              // reduces values >= r, like fromMpz + toMontgomery
 
-        // ---- lookup signals (compute_lookup :62-106): batched inversion instead of one GMP call each; the new
-        // values are scattered into the device copy of the witness (last write wins, as in the reference's loop)
-        std::vector<uint32_t> patchIdx;
-        std::vector<uint8_t> patchVal;
-        computeLookup(patchIdx, patchVal, chunks, freq, wIdx, pIdx, rand);
-        ugCheck(ug_dvec_scatter(d_.w, patchIdx.data(), patchVal.data(), patchIdx.size()));
+        // ---- lookup signals (compute_lookup :62-106): the new values are written into the device copy of the witness
+        // (last write wins, as in the reference's loop)
+        mark("commit + challenge");
         std::vector<uint8_t> publicPart(signals0, signals0 + ((size_t)hdr_.nPublic + 1) * 32);
-        for (size_t i = 0; i < patchIdx.size(); i++)
-            if (patchIdx[i] <= hdr_.nPublic) memcpy(publicPart.data() + (size_t)patchIdx[i] * 32, patchVal.data() + i * 32, 32);
+        applyLookup(publicPart, chunks, freq, wIdx, pIdx, rand);
+        mark("lookup");
 
         // ---- final round (execute_final_round :187-399)
         // r and s (:345-346) are drawn here, still after the round randomness as in the reference, so that the multiples
@@ -646,12 +658,17 @@ public:
         ugCheck(ug_msm_g1(d_.ctx, d_.A, d_.sw, 0, sums));                                   // MSM1 :201
         ugCheck(ug_msm_g1(d_.ctx, d_.B1, d_.sw, 0, sums + 64));                             // MSM2 :214
         ugCheck(ug_msm_g2(d_.ctx, d_.B2, d_.sw, 0, sums + 128));                            // MSM3 :227
+        mark("A, B1, B2 MSMs");
         ugCheck(ug_dvec_gather(d_.aux, d_.w, finalIdx_.data(), finalIdx_.size()));          // :439-445
+        mark("final gather");
         buildSchedule(d_.saux, d_.aux, 0, finalIdx_.size(), tableC2_);
         ugCheck(ug_msm_g1(d_.ctx, d_.C, d_.saux, 0, sums + 256));                           // MSM4 :234
+        mark("C MSM");
         ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                           // FFT block :243-320
+        mark("H polynomial");
         buildSchedule(d_.sh, d_.h, 0, hdr_.domainSize, tableH_);
         ugCheck(ug_msm_g1(d_.ctx, d_.H, d_.sh, 0, sums + 320));                             // MSM5 :322
+        mark("H MSM");
         ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
 
         HostTerms ht = terms.get();
@@ -661,6 +678,7 @@ public:
         proof = "{\"pi_a\":" + g1Json(A) + ",\"pi_b\":" + g2Json(B) + ",\"pi_f\":" + g1Json(C) + ",\"pi_r\":" + g1Json(commitRec) +
                 ",\"protocol\":\"ultragroth\"}";
         pub = publicJson(publicPart.data(), hdr_.nPublic, hdr_.randIndx);                   // prover.cpp:89-105
+        mark("blinding + JSON");
         totalMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 
@@ -675,16 +693,16 @@ public:
 
 private:
     static void putPlain(uint8_t* dst, const Fr& v) { u32 w[8]; to_normal(w, v); memcpy(dst, w, 32); }
-    // produces the (witness index, value) patches of compute_lookup; duplicate targets keep the LAST write
-    void computeLookup(std::vector<uint32_t>& patchIdx, std::vector<uint8_t>& patchVal, const std::vector<uint32_t>& chunks,
-                       const std::vector<uint32_t>& freq, const std::vector<uint32_t>& wIdx, const std::vector<uint32_t>& pIdx,
-                       const Fr& rand) {
+    // compute_lookup (src/ultra_groth.cpp:62-106). Host: the 2 L table values inv2[i] = 1 / (i + rand) (0 when the sum
+    // is 0) and prod[i] = freq[i] * inv2[i], with one shared inversion. Device: the writes into the witness
+    // (ug_dvec_apply_lookup; the reference's push_vector with its per-chunk copies of inv2 is never materialised).
+    // publicPart receives the writes that land on public signals (they go into public.json).
+    void applyLookup(std::vector<uint8_t>& publicPart, const std::vector<uint32_t>& chunks, const std::vector<uint32_t>& freq,
+                     const std::vector<uint32_t>& wIdx, const std::vector<uint32_t>& pIdx, const Fr& rand) {
         const size_t L = freq.size(), Cn = chunks.size();
-        // push_vector = [rand | inv1 (chunks) | inv2 (lookup) | prod (lookup)], plain integers
-        std::vector<uint8_t> push((2 * L + Cn + 1) * 32);
-        putPlain(push.data(), rand);
-        uint8_t* inv1 = push.data() + 32;
-        uint8_t* inv2 = inv1 + Cn * 32;
+        std::vector<uint8_t> table((2 * L + 1) * 32);                 // [rand | inv2 | prod], plain integers
+        putPlain(table.data(), rand);
+        uint8_t* inv2 = table.data() + 32;
         uint8_t* prod = inv2 + L * 32;
         // sums i + rand, then Montgomery's trick: prefix products, one inversion, unwind
         std::vector<Fr> sum(L), pre(L);
@@ -704,34 +722,19 @@ private:
             u32 fw[8] = {freq[i], 0, 0, 0, 0, 0, 0, 0};
             putPlain(prod + i * 32, mul(from_normal<FrParams>(fw), inv_i));
         }
-        for (size_t j = 0; j < Cn; j++) {
-            if (chunks[j] >= L) throw std::range_error("uwtns: chunk index outside the lookup table");
-            memcpy(inv1 + j * 32, inv2 + (size_t)chunks[j] * 32, 32);
-        }
-        const size_t total = 2 * L + Cn + 1;
-        // keep, for every target index, only its last assignment (the reference applies them in order)
-        if (lastPos_.size() != hdr_.nVars) lastPos_.assign(hdr_.nVars, UINT32_MAX);
+        ugCheck(ug_dvec_apply_lookup(d_.w, wIdx.data(), pIdx.data(), wIdx.size(), chunks.data(), Cn, table.data(), L));
+        // the same writes for the public signals, in order (a later write overwrites an earlier one)
         for (size_t i = 0; i < wIdx.size(); i++) {
-            if (wIdx[i] >= hdr_.nVars || pIdx[i] >= total) {
-                for (size_t k = 0; k < i; k++) lastPos_[wIdx[k]] = UINT32_MAX;
-                throw std::range_error("uwtns: lookup index out of range");
-            }
-            lastPos_[wIdx[i]] = (uint32_t)i;
+            if (wIdx[i] > hdr_.nPublic) continue;
+            const uint64_t p = pIdx[i];
+            const uint64_t t = p == 0 ? 0 : p <= Cn ? 1 + (uint64_t)chunks[p - 1] : p - Cn;
+            memcpy(publicPart.data() + (size_t)wIdx[i] * 32, table.data() + t * 32, 32);
         }
-        patchIdx.clear(); patchVal.clear();
-        patchIdx.reserve(wIdx.size()); patchVal.reserve(wIdx.size() * 32);
-        for (size_t i = 0; i < wIdx.size(); i++) {
-            if (lastPos_[wIdx[i]] != (uint32_t)i) continue;
-            patchIdx.push_back(wIdx[i]);
-            const uint8_t* src = push.data() + (size_t)pIdx[i] * 32;
-            patchVal.insert(patchVal.end(), src, src + 32);
-        }
-        for (size_t i = 0; i < wIdx.size(); i++) lastPos_[wIdx[i]] = UINT32_MAX;     // leave the scratch clean
     }
 
     ZkeyHeader hdr_;
     std::vector<uint8_t> vk_;
-    std::vector<uint32_t> roundIdx_, finalIdx_, lastPos_;
+    std::vector<uint32_t> roundIdx_, finalIdx_;
     int tableW_ = 0, tableC1_ = 0, tableC2_ = 0, tableH_ = 0;      // fixed-base table widths per schedule group (0: classic)
     DeviceProver d_;
     double msmMs_ = 0, fftMs_ = 0, totalMs_ = 0;

@@ -29,6 +29,7 @@ struct ug_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     double msm_ms = 0, fft_ms = 0;
     NttPlan raw_ntt;                       // cache for ug_fr_ntt
+    u32* lookup_last = nullptr; u64 lookup_last_n = 0;   // zeroed scratch of ug_dvec_apply_lookup
     void use() const { UG_HIP(hipSetDevice(device)); }
 };
 struct ug_bases {
@@ -92,6 +93,7 @@ void ug_ctx_destroy(ug_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     c->ws_g1.release(); c->ws_g2.release(); c->raw_ntt.release();
+    if (c->lookup_last) hipFree(c->lookup_last);
     hipEventDestroy(c->t0); hipEventDestroy(c->t1);
     for (int k = 0; k < 2; k++) { hipEventDestroy(c->stats[k].ev0); hipEventDestroy(c->stats[k].ev1); }
     hipStreamDestroy(c->stream);
@@ -223,6 +225,40 @@ int ug_dvec_scatter(ug_dvec* dst, const uint32_t* host_index, const void* host_v
     scatter_elements(dst->data, idx, val, n, dst->n, c->stream);
     UG_HIP(hipStreamSynchronize(c->stream));
     hipFree(idx); hipFree(val);
+    UG_CATCH
+}
+int ug_dvec_apply_lookup(ug_dvec* dst, const uint32_t* w_idx, const uint32_t* p_idx, uint64_t n, const uint32_t* chunks,
+                         uint64_t n_chunks, const void* table, uint64_t lookup_size) {
+    UG_TRY
+    if (!dst || ((!w_idx || !p_idx) && n) || (!chunks && n_chunks) || !table) throw std::invalid_argument("null argument");
+    if (n >= 0xffffffffull) throw std::invalid_argument("too many lookup writes");
+    const uint64_t total = 1 + n_chunks + 2 * lookup_size;          // length of the reference's push_vector
+    for (uint64_t j = 0; j < n_chunks; j++)
+        if (chunks[j] >= lookup_size) throw std::range_error("uwtns: chunk index outside the lookup table");
+    for (uint64_t i = 0; i < n; i++)
+        if (w_idx[i] >= dst->n || p_idx[i] >= total) throw std::range_error("uwtns: lookup index out of range");
+    if (!n) return UG_OK;
+    ug_ctx* c = dst->ctx;
+    c->use();
+    if (c->lookup_last_n < dst->n) {
+        if (c->lookup_last) hipFree(c->lookup_last);
+        c->lookup_last = nullptr; c->lookup_last_n = 0;
+        UG_HIP(hipMalloc(&c->lookup_last, (size_t)dst->n * 4));
+        UG_HIP(hipMemsetAsync(c->lookup_last, 0, (size_t)dst->n * 4, c->stream));
+        c->lookup_last_n = dst->n;
+    }
+    // one staging allocation: w_idx | p_idx | chunks | table
+    const size_t tbytes = (size_t)(1 + 2 * lookup_size) * 32;
+    u32* stage = nullptr;
+    UG_HIP(hipMalloc(&stage, (size_t)(2 * n + n_chunks) * 4 + tbytes));
+    u32 *d_w = stage, *d_p = stage + n, *d_c = stage + 2 * n, *d_t = stage + 2 * n + n_chunks;
+    UG_HIP(hipMemcpyAsync(d_w, w_idx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    UG_HIP(hipMemcpyAsync(d_p, p_idx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    if (n_chunks) UG_HIP(hipMemcpyAsync(d_c, chunks, (size_t)n_chunks * 4, hipMemcpyHostToDevice, c->stream));
+    UG_HIP(hipMemcpyAsync(d_t, table, tbytes, hipMemcpyHostToDevice, c->stream));
+    apply_lookup(dst->data, c->lookup_last, d_w, d_p, n, d_c, n_chunks, d_t, c->stream);
+    UG_HIP(hipStreamSynchronize(c->stream));
+    hipFree(stage);
     UG_CATCH
 }
 uint64_t ug_dvec_size(const ug_dvec* v) { return v ? v->n : 0; }
