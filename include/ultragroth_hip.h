@@ -50,6 +50,7 @@ extern "C" {
 typedef struct ug_ctx ug_ctx;            /* one device + one stream + reusable workspaces           */
 typedef struct ug_bases ug_bases;        /* a G1 or G2 base-point array resident in HBM              */
 typedef struct ug_dvec ug_dvec;          /* a device vector of 32-byte elements (witness, h, ...)    */
+typedef struct ug_index ug_index;        /* a list of 32-bit indices resident in HBM                  */
 typedef struct ug_schedule ug_schedule;  /* signed-digit bucket schedule of a range of a ug_dvec     */
 typedef struct ug_hpoly ug_hpoly;        /* coefficient matrix + NTT tables of one circuit           */
 
@@ -85,6 +86,10 @@ int  ug_dvec_upload(ug_dvec* v, const void* host, uint64_t n);           /* host
 int  ug_dvec_download(const ug_dvec* v, void* host, uint64_t first, uint64_t n);
 /* out[i] = src[index[i]] for i < n (UltraGroth round / final witness gathers, src/ultra_groth.cpp:415-445) */
 int  ug_dvec_gather(ug_dvec* out, const ug_dvec* src, const uint32_t* host_index, uint64_t n);
+/* the same with the index list kept on the device (the two lists are part of the zkey: upload once at create) */
+int  ug_index_create(ug_ctx* ctx, const uint32_t* host_index, uint64_t n, ug_index** out);
+void ug_index_destroy(ug_index* index);
+int  ug_dvec_gather_index(ug_dvec* out, const ug_dvec* src, const ug_index* index);
 /* dst[index[i]] = values[i] for i < n; indices must be distinct (UltraGroth lookup signals written back into the
  * witness, src/ultra_groth.cpp:99-105) */
 int  ug_dvec_scatter(ug_dvec* dst, const uint32_t* host_index, const void* host_values, uint64_t n);

@@ -15,7 +15,7 @@ INNER_SYMBOLS = [
     "ug_last_error", "ug_device_count", "ug_ctx_create", "ug_ctx_destroy", "ug_ctx_sync",
     "ug_bases_create_g1", "ug_bases_create_g2", "ug_bases_destroy",
     "ug_msm_table_window", "ug_bases_tables_bytes", "ug_bases_precompute", "ug_ctx_mem_info", "ug_schedule_build_tables",
-    "ug_dvec_create", "ug_dvec_upload", "ug_dvec_download", "ug_dvec_gather", "ug_dvec_scatter", "ug_dvec_apply_lookup", "ug_dvec_wrap", "ug_dvec_size", "ug_dvec_destroy",
+    "ug_dvec_create", "ug_dvec_upload", "ug_dvec_download", "ug_dvec_gather", "ug_dvec_scatter", "ug_dvec_apply_lookup", "ug_index_create", "ug_index_destroy", "ug_dvec_gather_index", "ug_dvec_wrap", "ug_dvec_size", "ug_dvec_destroy",
     "ug_schedule_create", "ug_schedule_build", "ug_schedule_destroy",
     "ug_msm_g1", "ug_msm_g2",
     "ug_hpoly_create", "ug_hpoly_run", "ug_hpoly_chain", "ug_hpoly_combine", "ug_hpoly_debug_abc", "ug_hpoly_destroy",
@@ -78,6 +78,9 @@ def load():
     L.ug_dvec_download.argtypes = [vp, vp, u64, u64]
     L.ug_dvec_gather.argtypes = [vp, vp, vp, u64]
     L.ug_dvec_scatter.argtypes = [vp, vp, vp, u64]
+    L.ug_index_create.argtypes = [vp, vp, u64, pp]
+    L.ug_index_destroy.argtypes = [vp]; L.ug_index_destroy.restype = None
+    L.ug_dvec_gather_index.argtypes = [vp, vp, vp]
     L.ug_dvec_apply_lookup.argtypes = [vp, vp, vp, u64, vp, u64, vp, u64]
     L.ug_dvec_wrap.argtypes = [vp, vp, u64, pp]
     L.ug_dvec_size.argtypes = [vp]; L.ug_dvec_size.restype = u64

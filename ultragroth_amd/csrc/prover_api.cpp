@@ -196,7 +196,9 @@ struct DeviceProver {
     ug_hpoly* hp = nullptr;
     ug_dvec *w = nullptr, *h = nullptr, *aux = nullptr;
     ug_schedule *sw = nullptr, *sh = nullptr, *saux = nullptr;
+    ug_index *roundIdx = nullptr, *finalIdx = nullptr;      // UltraGroth: zkey sections 10 and 11, resident
     ~DeviceProver() {
+        ug_index_destroy(roundIdx); ug_index_destroy(finalIdx);
         ug_schedule_destroy(sw); ug_schedule_destroy(sh); ug_schedule_destroy(saux);
         ug_dvec_destroy(w); ug_dvec_destroy(h); ug_dvec_destroy(aux);
         ug_hpoly_destroy(hp);
@@ -560,6 +562,8 @@ public:
         ugCheck(ug_schedule_create(d_.ctx, &d_.sw));
         ugCheck(ug_schedule_create(d_.ctx, &d_.sh));
         ugCheck(ug_schedule_create(d_.ctx, &d_.saux));
+        ugCheck(ug_index_create(d_.ctx, roundIdx_.data(), roundIdx_.size(), &d_.roundIdx));
+        ugCheck(ug_index_create(d_.ctx, finalIdx_.data(), finalIdx_.size(), &d_.finalIdx));
         std::vector<TableGroup> groups(4);
         groups[0].g1 = {d_.A, d_.B1}; groups[0].n1 = {M, M}; groups[0].g2 = {d_.B2}; groups[0].n2 = {M};
         groups[0].scalars = M; groups[0].c = &tableW_;
@@ -605,7 +609,7 @@ public:
         // ---- round 1: commitment to the round witnesses (ultra_groth.cpp:415-419, execute_round :161-184)
         ugCheck(ug_dvec_upload(d_.w, signals0, M));
         mark("witness upload");
-        ugCheck(ug_dvec_gather(d_.aux, d_.w, roundIdx_.data(), roundIdx_.size()));
+        ugCheck(ug_dvec_gather_index(d_.aux, d_.w, d_.roundIdx));
         mark("round gather");
         buildSchedule(d_.saux, d_.aux, 0, roundIdx_.size(), tableC1_);
         uint8_t commitRec[64];
@@ -659,7 +663,7 @@ public:
         ugCheck(ug_msm_g1(d_.ctx, d_.B1, d_.sw, 0, sums + 64));                             // MSM2 :214
         ugCheck(ug_msm_g2(d_.ctx, d_.B2, d_.sw, 0, sums + 128));                            // MSM3 :227
         mark("A, B1, B2 MSMs");
-        ugCheck(ug_dvec_gather(d_.aux, d_.w, finalIdx_.data(), finalIdx_.size()));          // :439-445
+        ugCheck(ug_dvec_gather_index(d_.aux, d_.w, d_.finalIdx));                           // :439-445
         mark("final gather");
         buildSchedule(d_.saux, d_.aux, 0, finalIdx_.size(), tableC2_);
         ugCheck(ug_msm_g1(d_.ctx, d_.C, d_.saux, 0, sums + 256));                           // MSM4 :234

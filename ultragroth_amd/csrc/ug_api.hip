@@ -39,6 +39,9 @@ struct ug_bases {
 struct ug_dvec {
     ug_ctx* ctx; u64 n; u32* data; bool owns;
 };
+struct ug_index {
+    ug_ctx* ctx; u64 n; u32* data;
+};
 struct ug_schedule {
     ug_ctx* ctx; MsmSchedule sched; u64 first = 0;
 };
@@ -208,6 +211,34 @@ int ug_dvec_gather(ug_dvec* out, const ug_dvec* src, const uint32_t* host_index,
     gather_elements(out->data, src->data, idx, n, src->n, c->stream);
     UG_HIP(hipStreamSynchronize(c->stream));
     hipFree(idx);
+    UG_CATCH
+}
+// index lists that stay on the device (UltraGroth's round_indexes / final_round_indexes are part of the zkey)
+int ug_index_create(ug_ctx* c, const uint32_t* host_index, uint64_t n, ug_index** out) {
+    UG_TRY
+    if (!c || !out || (!host_index && n)) throw std::invalid_argument("null argument");
+    c->use();
+    ug_index* ix = new ug_index{c, n, nullptr};
+    UG_HIP(hipMalloc(&ix->data, n ? (size_t)n * 4 : 4));
+    if (n) UG_HIP(hipMemcpyAsync(ix->data, host_index, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    UG_HIP(hipStreamSynchronize(c->stream));
+    *out = ix;
+    UG_CATCH
+}
+void ug_index_destroy(ug_index* ix) {
+    if (!ix) return;
+    hipSetDevice(ix->ctx->device);
+    hipFree(ix->data);
+    delete ix;
+}
+int ug_dvec_gather_index(ug_dvec* out, const ug_dvec* src, const ug_index* index) {
+    UG_TRY
+    if (!out || !src || !index) throw std::invalid_argument("null argument");
+    if (index->n > out->n) throw std::invalid_argument("gather larger than the output vector");
+    ug_ctx* c = out->ctx;
+    c->use();
+    gather_elements(out->data, src->data, index->data, index->n, src->n, c->stream);
+    UG_HIP(hipStreamSynchronize(c->stream));
     UG_CATCH
 }
 int ug_dvec_scatter(ug_dvec* dst, const uint32_t* host_index, const void* host_values, uint64_t n) {
