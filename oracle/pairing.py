@@ -224,3 +224,38 @@ def groth16_verify(vk, public, proof):
     f = f12_mul(f, miller(_g2(vk["vk_gamma_2"]), g1_neg(vkx)))
     f = f12_mul(f, miller(_g2(vk["vk_delta_2"]), g1_neg(c)))
     return final_exp(f) == F12_ONE
+
+
+def derive_challenge(commit):
+    """derive_challenge (src/ultra_groth.cpp:33-58): keccak256(x_BE32 || y_BE32) of the affine round commitment, read as a
+    big-endian integer, mod r. commit = (x, y) ints."""
+    from . import keccak256
+    d = keccak256(commit[0].to_bytes(32, "big") + commit[1].to_bytes(32, "big"))
+    return int.from_bytes(d, "big") % R
+
+
+def ultra_groth_verify(vk, public, proof):
+    """UltraGroth::Verifier::verify (src/ultra_groth.cpp:581-648):
+        vkX = IC[0] + sum_i public[i] * IC[i+1] + derive_challenge(pi_r) * IC_rand
+        e(A, B) e(-alpha1, beta2) e(-vkX, gamma2) e(-pi_f, delta_c2_2) e(-pi_r, delta_c1_2) == 1"""
+    if isinstance(vk, (str, bytes)): vk = json.loads(vk)
+    if isinstance(public, (str, bytes)): public = json.loads(public)
+    if isinstance(proof, (str, bytes)): proof = json.loads(proof)
+    a, b = _g1(proof["pi_a"]), _g2(proof["pi_b"])
+    fin, rnd = _g1(proof["pi_f"]), _g1(proof["pi_r"])
+    if not (g1_on_curve(a) and g1_on_curve(fin) and g1_on_curve(rnd) and g2_on_curve(b)):
+        return False
+    ic = [_g1(x) for x in vk["IC"]]
+    if len(public) + 1 != len(ic):
+        return False
+    vkx = ic[0]
+    for v, pt in zip(public, ic[1:]):
+        vkx = g1_add(vkx, g1_mul(pt, int(v) % R))
+    vkx = g1_add(vkx, g1_mul(_g1(vk["IC_rand"]), derive_challenge(rnd)))
+    f = F12_ONE
+    for g1p, g2p in ((a, b), (g1_neg(_g1(vk["vk_alpha_1"])), _g2(vk["vk_beta_2"])), (g1_neg(vkx), _g2(vk["vk_gamma_2"])),
+                     (g1_neg(fin), _g2(vk["vk_delta_c2_2"])), (g1_neg(rnd), _g2(vk["vk_delta_c1_2"]))):
+        if g1p is None or g2p is None:
+            continue
+        f = f12_mul(f, miller(g2p, g1p))
+    return final_exp(f) == F12_ONE

@@ -26,10 +26,11 @@ def _declared(header):
 
 
 def test_every_declared_symbol_is_exported(lib):
-    inner, outer = _declared("ultragroth_hip.h"), _declared("prover.h")
+    inner, outer, verifier = _declared("ultragroth_hip.h"), _declared("prover.h"), _declared("verifier.h")
     assert inner == set(_lib.INNER_SYMBOLS)
     assert outer == set(_lib.OUTER_SYMBOLS)
-    for name in inner | outer:
+    assert verifier == set(_lib.VERIFIER_SYMBOLS)             # the reference's src/verifier.h:22-38
+    for name in inner | outer | verifier:
         assert hasattr(lib, name), name
 
 

@@ -296,6 +296,17 @@ def test_cli_prover_end_to_end(tmp_path, zkey, wtns, vkey):
     proof, pub = open(proof_path).read(), open(public_path).read()
     assert "\0" not in proof and pub == '["7713112592372404476342535432037683616424591277138491596200192981572885523208"]'
     assert pairing.groth16_verify(vkey, pub, proof)
+    # the reference's CI (.github/workflows/build.yml:69-81): `verifier` accepts the files, and rejects them after public[0] -= 1
+    vk_path = os.path.join(golden, "verification_key.json")
+    ver = os.path.join(root, "ultragroth_amd", "csrc", "verifier")
+    r = subprocess.run([ver, vk_path, public_path, proof_path], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stderr == "Result: Valid proof\n"
+    bad = json.loads(pub)
+    bad[0] = str(int(bad[0]) - 1)
+    bad_path = str(tmp_path / "public_bad.json")
+    open(bad_path, "w").write(json.dumps(bad))
+    r = subprocess.run([ver, vk_path, bad_path, proof_path], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stderr == "Result: Invalid proof\n"
     # wrong argument count and unreadable file: exit code 1 and the reference's messages
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 1 and "Usage: prover <circuit.zkey> <witness.wtns> <proof.json> <public.json>" in r.stderr

@@ -88,6 +88,34 @@ def ultra_groth_public_size_for_zkey_buf(zkey):
     return _public_size(load().ultra_groth_public_size_for_zkey_buf, zkey)
 
 
+# ---------------------------------------------------------------------------------------------------
+# verifier mirror (src/verifier.h)
+VERIFIER_VALID_PROOF, VERIFIER_INVALID_PROOF, VERIFIER_ERROR = 0, 1, 2
+
+
+class VerifierError(RuntimeError):
+    pass
+
+
+def _verify(fn, proof, inputs, verification_key):
+    import json
+    enc = lambda v: v if isinstance(v, bytes) else (v if isinstance(v, str) else json.dumps(v)).encode()
+    err = C.create_string_buffer(256)
+    rc = fn(enc(proof), enc(inputs), enc(verification_key), err, 255)
+    if rc == VERIFIER_ERROR:
+        raise VerifierError(err.value.decode(errors="replace"))
+    return rc == VERIFIER_VALID_PROOF
+
+
+def groth16_verify(proof, inputs, verification_key):
+    """groth16_verify (src/verifier.h:22-29): JSON texts or parsed objects; True / False, VerifierError on bad data"""
+    return _verify(load().groth16_verify, proof, inputs, verification_key)
+
+
+def ultra_groth_verify(proof, inputs, verification_key):
+    return _verify(load().ultra_groth_verify, proof, inputs, verification_key)
+
+
 class _ProverBase:
     _create = _prove = _destroy = _public_size_fn = None
     _proof_size = staticmethod(groth16_proof_size)

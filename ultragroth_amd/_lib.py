@@ -21,6 +21,7 @@ INNER_SYMBOLS = [
     "ug_hpoly_create", "ug_hpoly_run", "ug_hpoly_chain", "ug_hpoly_combine", "ug_hpoly_debug_abc", "ug_hpoly_destroy",
     "ug_fr_ntt", "ug_field_op", "ug_synth_points", "ug_ctx_timings", "ug_ctx_kernel_stats",
 ]
+VERIFIER_SYMBOLS = ["groth16_verify", "ultra_groth_verify"]        # include/verifier.h
 OUTER_SYMBOLS = [
     "groth16_public_size_for_zkey_buf", "ultra_groth_public_size_for_zkey_buf",
     "groth16_public_size_for_zkey_file", "ultra_groth_public_size_for_zkey_file",
@@ -101,6 +102,8 @@ def load():
     L.ug_synth_points.argtypes = [vp, C.c_int, vp, u64, u64, vp]
     L.ug_ctx_timings.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
     L.ug_ctx_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64), C.c_int]
+    for n in VERIFIER_SYMBOLS:
+        getattr(L, n).argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_ulong]
     # outer API (include/prover.h)
     for n in ("groth16_public_size_for_zkey_buf", "ultra_groth_public_size_for_zkey_buf"):
         getattr(L, n).argtypes = [vp, ull, pull, vp, ull]
