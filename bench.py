@@ -309,6 +309,11 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": g1_bytes,
                          "avg_launch_ms": acc_ms, "launches": launches,
+                         # the bound that actually binds: v_mad_u64_u32 issue (29 T mad/s measured, tools/ubench_int.hip);
+                         # one G1 mixed addition = 1467 mads, entries = (scalar, window) digits
+                         "issue_bound": {"unit": "T mad/s", "peak": 29.0,
+                                         "achieved": (1467.0 * entries / max(launches, 1) / (acc_ms * 1e-3) / 1e12) if acc_ms > 0 else 0.0,
+                                         "frac": (1467.0 * entries / max(launches, 1) / (acc_ms * 1e-3) / 29.0e12) if acc_ms > 0 else 0.0},
                          "g2_kernel": {"avg_launch_ms": g2_ms, "launches": g2_launches,
                                        "achieved": (160.0 * n_local / (g2_ms * 1e-3) / 1e9) if g2_ms > 0 else 0.0},
                          "note": "integer-issue-bound kernel: see DESIGN.md for modmul/s against the v_mad_u64_u32 peak"},
