@@ -64,3 +64,27 @@ def test_sharded_partials_sum_to_the_unsharded_result(world, zkey, wtns):
     r, s = 5, 7
     _, _, raw = O.groth16_prove(zkey, wtns, r, s, want_raw=True)
     assert total == raw
+
+
+def test_bench_witness_slices_tile_the_witness():
+    """bench.py gives the ranks that also run an NTT chain smaller witness slices: for every world size the slices are
+    contiguous, ordered, cover [0, nVars) exactly, and the chain-carrying ranks get the smaller ones"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for log_domain in (3, 10, 24):
+        info = {"nVars": (1 << log_domain) - 1, "domainSize": 1 << log_domain}
+        assert bench.witness_slice(info, 0, 1) is None
+        for world in (2, 3, 4, 8):
+            if info["domainSize"] % world:
+                assert bench.witness_slice(info, 0, world) is None         # falls back to the even split
+                continue
+            cuts = [bench.witness_slice(info, k, world) for k in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == info["nVars"]
+            for a, b in zip(cuts, cuts[1:]):
+                assert a[1] == b[0] and a[0] <= a[1]
+            if log_domain == 24 and world == 8:
+                sizes = [hi - lo for lo, hi in cuts]
+                assert max(sizes[:3]) < min(sizes[3:])
