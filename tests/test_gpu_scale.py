@@ -387,3 +387,21 @@ def test_ultragroth_created_prover_with_window_tables(device):
             finally:
                 ug.set_test_blinding(b"")
             assert got == exp
+
+
+def test_ranges_above_the_schedule_limit_are_proved_in_pieces(device, monkeypatch):
+    """a schedule holds at most 2^26 scalars, so the reference's largest legal domain (2^27) is proved in pieces whose
+    partial sums are added; ULTRAGROTH_MAX_RANGE lowers the limit so that a 2^13 circuit takes that path (7 pieces)"""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, wtns, info = synth.build_circuit(device, 13, mix="C", seed=0x5EED0300)
+    r, s = fixed_rs()
+    exp = O.groth16_prove(zkey, wtns, int.from_bytes(r, "little"), int.from_bytes(s, "little"))
+    monkeypatch.setenv("ULTRAGROTH_MAX_RANGE", "1234")
+    with ug.Groth16Prover(zkey) as p:
+        ug.set_test_blinding(r + s)
+        try:
+            got = p.prove(wtns)
+        finally:
+            ug.set_test_blinding(b"")
+    assert got == (exp[0], exp[1])

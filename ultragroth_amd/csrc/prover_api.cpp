@@ -332,12 +332,18 @@ public:
         ugCheck(ug_dvec_create(d_.ctx2, N, &d_.h));
         ugCheck(ug_schedule_create(d_.ctx, &d_.sw));
         ugCheck(ug_schedule_create(d_.ctx2, &d_.sh));
+        if (const char* mr = getenv("ULTRAGROTH_MAX_RANGE")) {
+            uint64_t v = strtoull(mr, nullptr, 10);
+            if (v >= 1 && v < MAX_RANGE) maxRange_ = v;
+        }
         std::vector<TableGroup> groups(2);
         groups[0].g1 = {d_.A, d_.B1, d_.C}; groups[0].n1 = {wr_.hi - wr_.lo, wr_.hi - wr_.lo, cHi - cLo};
         groups[0].g2 = {d_.B2}; groups[0].n2 = {wr_.hi - wr_.lo};
         groups[0].scalars = wr_.hi - wr_.lo; groups[0].c = &tableW_;
+        if (wr_.hi - wr_.lo > maxRange_) groups[0].scalars = 0;          // proved in pieces: classic windows per piece
         groups[1].g1 = {d_.H}; groups[1].n1 = {hr_.hi - hr_.lo};
         groups[1].scalars = hr_.hi - hr_.lo; groups[1].c = &tableH_;
+        if (hr_.hi - hr_.lo > maxRange_) groups[1].scalars = 0;
         planWindowTables(d_.ctx, groups);
     }
 
@@ -364,8 +370,8 @@ public:
         // reference's largest legal domain, 2^27, needs it) are proved in pieces whose partial sums are added.
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
         uint8_t part[UG_GROTH16_PARTIALS_SIZE];
-        for (uint64_t lo = wr_.lo; lo < wr_.hi; lo += MAX_RANGE) {
-            uint64_t n = std::min<uint64_t>(MAX_RANGE, wr_.hi - lo);
+        for (uint64_t lo = wr_.lo; lo < wr_.hi; lo += maxRange_) {
+            uint64_t n = std::min<uint64_t>(maxRange_, wr_.hi - lo);
             uint8_t* out = (lo == wr_.lo) ? partials : part;
             memset(part, 0, sizeof part);
             buildSchedule(d_.sw, d_.w, lo, n, tableW_);
@@ -381,8 +387,8 @@ public:
     void runHMsm(uint8_t* partials) {
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
         uint8_t part[UG_GROTH16_PARTIALS_SIZE];
-        for (uint64_t lo = hr_.lo; lo < hr_.hi; lo += MAX_RANGE) {
-            uint64_t n = std::min<uint64_t>(MAX_RANGE, hr_.hi - lo);
+        for (uint64_t lo = hr_.lo; lo < hr_.hi; lo += maxRange_) {
+            uint64_t n = std::min<uint64_t>(maxRange_, hr_.hi - lo);
             uint8_t* out = (lo == hr_.lo) ? partials : part;
             memset(part, 0, sizeof part);
             buildSchedule(d_.sh, d_.h, lo, n, tableH_);
@@ -508,6 +514,7 @@ public:
 
 private:
     static constexpr uint64_t MAX_RANGE = (uint64_t)1 << 26;       // 2^26 scalars * <= 16 windows < 2^31 entries
+    uint64_t maxRange_ = MAX_RANGE;    // ULTRAGROTH_MAX_RANGE lowers it (tests: the piecewise path without a 2^27 circuit)
     int tableW_ = 0, tableH_ = 0;      // window widths of the fixed-base tables (0: classic windows), planWindowTables
     int rank_, count_;
     ZkeyHeader hdr_;
