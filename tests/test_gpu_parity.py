@@ -222,6 +222,32 @@ def test_hpoly_matches_oracle_and_known_answers(device, zkey, wtns):
     assert a == abc[:n] and b == abc[n:2 * n] and c == abc[2 * n:]
 
 
+@pytest.mark.parametrize("domain", [1, 2, 64])
+def test_hpoly_degenerate_matrices(device, zkey, domain):
+    """no coefficients at all (h = 0), a single row, records that repeat the same (matrix, row, signal) -- the reference
+    adds every record it meets -- and a matrix index that is neither 0 nor 1 rejected at create"""
+    import struct
+    import ultragroth_amd as ug
+    nvars = 5
+    w = b"".join(O.to_le(v) for v in (1, 7, O.R_MOD - 2, 12345678901234567890, 3))
+    wv = device.dvec(nvars, w)
+    hp = device.hpoly(b"", 0, domain, nvars)
+    assert device.download(hp.run(wv), 0, domain) == bytes(32 * domain)
+    val = O.to_le(5 * pow(2, 512, O.R_MOD) % O.R_MOD)                          # the zkey stores coefficients times R^2
+    recs = []
+    for m, c, s_ in ((0, 0, 1), (0, 0, 1), (1, 0, 2), (1, domain - 1, 4), (0, domain - 1, 3), (1, 0, 2)):
+        recs.append(struct.pack("<III", m, c, s_) + val)
+    coefs = b"".join(recs)
+    hp = device.hpoly(coefs, len(recs), domain, nvars)
+    assert device.download(hp.run(wv), 0, domain) == O.hpoly(coefs, len(recs), w, nvars, domain)
+    with pytest.raises(ug.DeviceError, match="coefficient record out of range"):
+        device.hpoly(struct.pack("<III", 2, 0, 0) + val, 1, domain, nvars)
+    with pytest.raises(ug.DeviceError, match="coefficient record out of range"):
+        device.hpoly(struct.pack("<III", 0, domain, 0) + val, 1, domain, nvars)
+    with pytest.raises(ug.DeviceError, match="coefficient record out of range"):
+        device.hpoly(struct.pack("<III", 1, 0, nvars) + val, 1, domain, nvars)
+
+
 def test_groth16_proof_bit_exact_and_valid(zkey, wtns, vkey):
     """Full prove through the reference's C API with the Appendix A blinding: byte-identical to the oracle and to
     the committed known answer, and accepted by the reference's acceptance test (pairing check)."""
