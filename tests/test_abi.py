@@ -113,3 +113,29 @@ def test_partials_add_is_host_only_and_exact(lib, zkey):
     assert s[128:256] == O.g2_add(g2[0], g2[1])
     assert s[256:320] == O.g1_mul(g1[2], 2)
     assert s[320:384] == O.g1_add(g1[3], g1[5])
+
+
+def test_headers_are_plain_c(tmp_path):
+    """include/*.h are what a cgo / JNI / bindgen user includes: they must compile as C99 on their own, and a C program
+    must link against the library with nothing but them"""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    inc = os.path.join(ROOT, "include")
+    for h in ("prover.h", "verifier.h", "ultragroth_hip.h"):
+        r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, "-x", "c", "-"],
+                           input='#include "%s"\n' % h, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    src = tmp_path / "link.c"
+    src.write_text('#include <stdio.h>\n#include "prover.h"\n#include "verifier.h"\n#include "ultragroth_hip.h"\n'
+                   'int main(void) {\n  unsigned long long n = 0; char err[64] = {0};\n  groth16_proof_size(&n);\n'
+                   '  int rc = groth16_verify("{", "[]", "{}", err, 63);\n'
+                   '  printf("%llu %d %s %d\\n", n, rc, err, ug_msm_table_window(1u << 24));\n  return 0;\n}\n')
+    exe = tmp_path / "link"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lultragroth_hip", "-Wl,-rpath," + libdir],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "810 2 invalid proof data 22"
