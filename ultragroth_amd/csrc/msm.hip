@@ -601,11 +601,30 @@ template <class T> void dev_free(T*& p) { if (p) hipFree(p); p = nullptr; }
 }  // namespace
 
 // ---- geometry ---------------------------------------------------------------------------------------------
+namespace {
+// entries per lane of the segmented accumulation: long segments cut fewer buckets into pieces, but keep about a
+// million lanes in flight
+int segment_log(u64 total_entries) {
+    int log_seg = 5;
+    while (log_seg < LOG_SEG && (total_entries >> (log_seg + 1)) >= ((u64)1 << 20)) log_seg++;
+    return log_seg;
+}
+// Modelled cost of one MSM in mixed additions: one per entry, about four per bucket for the reduction, and a penalty
+// when the average bucket is longer than a lane's segment -- such buckets are cut into pieces that a single lane adds
+// up afterwards (measured at 2^20..2^24 with tools/run_tablec.sh: +4 % of the entry cost per segment length by which
+// the average bucket exceeds one segment; e.g. 2^22, c = 20 -> 22: 48.2 -> 45.9 ms per proof).
+double msm_cost(u64 n, int c, bool tables) {
+    const int windows = (255 + c - 1) / c;
+    const double entries = (double)windows * (double)n, buckets = (double)((u64)1 << (c - 1));
+    const double per_bucket = (tables ? entries : (double)n) / buckets;
+    const double over = per_bucket / (double)((u64)1 << segment_log((u64)entries)) - 1.0;
+    return entries * (1.0 + (over > 0 ? 0.04 * over : 0.0)) + 4.0 * buckets * (tables ? 1.0 : (double)windows);
+}
+}  // namespace
+
 MsmGeometry MsmGeometry::choose(u64 n, int force_c) {
     MsmGeometry g;
     g.n = n;
-    // Window size: minimise windows * (entries + 4 * buckets) -- one mixed addition per (point, window) entry against
-    // about four addition-equivalents per bucket in the reduction (measured ratio at 2^20..2^24 on MI355X).
     int c = force_c;
     if (!c) {
         static const int env_c = getenv("UG_MSM_C") ? atoi(getenv("UG_MSM_C")) : 0;      // tuning knob
@@ -614,7 +633,7 @@ MsmGeometry MsmGeometry::choose(u64 n, int force_c) {
     if (!c) {
         double best = 0;
         for (int k = 6; k <= 22; k++) {
-            double cost = (double)((255 + k - 1) / k) * ((double)n + 4.0 * (double)((u64)1 << (k - 1)));
+            double cost = msm_cost(n, k, false);
             if (!c || cost < best) { best = cost; c = k; }
         }
     }
@@ -626,12 +645,16 @@ MsmGeometry MsmGeometry::choose(u64 n, int force_c) {
     return g;
 }
 
-// Tables mode: W = ceil(255/c) digits per scalar, ONE bucket set of 2^(c-1): cost W n + 4 * 2^(c-1) additions.
+// Tables mode: W = ceil(255/c) digits per scalar, ONE bucket set of 2^(c-1).
 int MsmGeometry::table_window(u64 n) {
+    if (const char* e = getenv("UG_TABLE_C")) {                       // tuning knob
+        int v = atoi(e);
+        if (v >= TABLE_MIN_C && v <= TABLE_MAX_C) return v;
+    }
     int c = 0;
     double best = 0;
     for (int k = TABLE_MIN_C; k <= TABLE_MAX_C; k++) {
-        double cost = (double)((255 + k - 1) / k) * (double)n + 4.0 * (double)((u64)1 << (k - 1));
+        double cost = msm_cost(n, k, true);
         if (!c || cost < best) { best = cost; c = k; }
     }
     return c;
@@ -675,9 +698,7 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
     geo = g;
     reserve(g);
     n_heavy = 0; n_medium = 0; n_heavy_tasks = 0; n_valid = 0;
-    // entries per lane: long segments cut fewer buckets into pieces, but keep about a million lanes in flight
-    log_seg = 5;
-    while (log_seg < LOG_SEG && ((g.n * g.windows) >> (log_seg + 1)) >= ((u64)1 << 20)) log_seg++;
+    log_seg = segment_log(g.n * g.windows);
     if (g.n == 0) return;
     u64 total = g.n * g.windows;
     if (total >= ((u64)1 << 31)) throw std::invalid_argument("msm: n * windows exceeds 2^31 entries");
