@@ -605,8 +605,9 @@ namespace {
 // entries per lane of the segmented accumulation: long segments cut fewer buckets into pieces, but keep about a
 // million lanes in flight
 int segment_log(u64 total_entries) {
+    static const int lanes_log = getenv("UG_SEG_LANES_LOG") ? atoi(getenv("UG_SEG_LANES_LOG")) : 20;      // tuning knob
     int log_seg = 5;
-    while (log_seg < LOG_SEG && (total_entries >> (log_seg + 1)) >= ((u64)1 << 20)) log_seg++;
+    while (log_seg < LOG_SEG && (total_entries >> (log_seg + 1)) >= ((u64)1 << lanes_log)) log_seg++;
     return log_seg;
 }
 // Modelled cost of one MSM in mixed additions: one per entry, about four per bucket for the reduction, and a penalty
