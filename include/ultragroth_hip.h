@@ -118,6 +118,10 @@ void ug_schedule_destroy(ug_schedule* s);
  * format (64 bytes for G1, 128 for G2; all zero = infinity). */
 int  ug_msm_g1(ug_ctx* ctx, const ug_bases* bases, const ug_schedule* s, int64_t index_shift, void* out_affine);
 int  ug_msm_g2(ug_ctx* ctx, const ug_bases* bases, const ug_schedule* s, int64_t index_shift, void* out_affine);
+/* count <= 8 products over ONE schedule (G1 and G2 sets mixed freely; index_shifts may be NULL), queued back to back with
+ * a single host synchronisation: outs[k] receives what ug_msm_g1 / ug_msm_g2 would write for bases[k]. */
+int  ug_msm_batch(ug_ctx* ctx, int count, const ug_bases* const* bases, const ug_schedule* s, const int64_t* index_shifts,
+                  void* const* outs_affine);
 
 /* coefs: n_coefs packed 44-byte records {u32 m, u32 c, u32 s, Fr coef} (zkey section 4 past its 4-byte
  * count, src/groth16.cpp:38). Builds the row-sorted matrix and the NTT tables for domain_size. */

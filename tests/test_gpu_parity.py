@@ -207,6 +207,25 @@ def test_lookup_completion_last_write_wins(device):
     assert device.download(v, 0, n_dst) == exp.tobytes()
 
 
+def test_msm_batch_equals_single_products(device, zkey, wtns):
+    """ug_msm_batch queues A, B1, B2, C (G1 and G2 mixed, C with its index shift) back to back and synchronises once:
+    the same records as one call each, with and without window tables, and for an empty batch"""
+    info = O.zkey_info(zkey)
+    n, shift = info["nVars"], info["nPublic"] + 1
+    w = device.dvec(n, _sec(wtns, "wtns", 2))
+    for c in (0, 16):
+        a = device.bases(_sec(zkey, "zkey", 5), n, table_c=c)
+        b1 = device.bases(_sec(zkey, "zkey", 6), n, table_c=c)
+        b2 = device.bases(_sec(zkey, "zkey", 7), n, g2=True, table_c=c)
+        cc = device.bases(_sec(zkey, "zkey", 8), n - shift, table_c=c)
+        s = device.schedule(w, 0, n, table_c=c)
+        got = device.msm_batch([(a, False), (b1, False), (b2, True), (cc, False)], s, [0, 0, 0, shift])
+        assert got == [device.msm(a, s), device.msm(b1, s), device.msm(b2, s, g2=True), device.msm(cc, s, index_shift=shift)]
+        assert got[0] == O.g1_msm(_sec(zkey, "zkey", 5), _sec(wtns, "wtns", 2), n)
+        assert device.msm_batch([], s) == []
+        assert device.msm_batch([(b2, True)], s) == [got[2]]
+
+
 def test_hpoly_matches_oracle_and_known_answers(device, zkey, wtns):
     info = O.zkey_info(zkey)
     coefs = _sec(zkey, "zkey", 4)[4:]

@@ -370,6 +370,17 @@ class Device:
         _check(fn(self._h, bases.h, schedule.h, index_shift, out))
         return out.raw
 
+    def msm_batch(self, bases_list, schedule, index_shifts=None):
+        """ug_msm_batch: several products over one schedule with one host synchronisation; bases_list holds
+        (bases handle, is_g2) pairs; returns the affine records"""
+        n = len(bases_list)
+        outs = [C.create_string_buffer(128 if g2 else 64) for _, g2 in bases_list]
+        arr_b = (C.c_void_p * n)(*[b.h for b, _ in bases_list])
+        arr_o = (C.c_void_p * n)(*[C.cast(o, C.c_void_p) for o in outs])
+        arr_s = (C.c_int64 * n)(*index_shifts) if index_shifts is not None else None
+        _check(self._L.ug_msm_batch(self._h, n, arr_b, schedule.h, arr_s, arr_o))
+        return [o.raw for o in outs]
+
     # -- one-shot helpers
     def msm_g1(self, points, scalars, n, table_c=0):
         """sum scalars[i] * points[i]; points n x 64 B zkey records, scalars n x 32 B plain integers."""

@@ -17,7 +17,7 @@ INNER_SYMBOLS = [
     "ug_msm_table_window", "ug_bases_tables_bytes", "ug_bases_precompute", "ug_ctx_mem_info", "ug_schedule_build_tables",
     "ug_dvec_create", "ug_dvec_upload", "ug_dvec_download", "ug_dvec_gather", "ug_dvec_scatter", "ug_dvec_apply_lookup", "ug_index_create", "ug_index_destroy", "ug_dvec_gather_index", "ug_dvec_wrap", "ug_dvec_size", "ug_dvec_destroy",
     "ug_schedule_create", "ug_schedule_build", "ug_schedule_destroy",
-    "ug_msm_g1", "ug_msm_g2",
+    "ug_msm_g1", "ug_msm_g2", "ug_msm_batch",
     "ug_hpoly_create", "ug_hpoly_run", "ug_hpoly_chain", "ug_hpoly_combine", "ug_hpoly_debug_abc", "ug_hpoly_destroy",
     "ug_fr_ntt", "ug_field_op", "ug_synth_points", "ug_ctx_timings", "ug_ctx_kernel_stats",
 ]
@@ -91,6 +91,7 @@ def load():
     L.ug_schedule_destroy.argtypes = [vp]; L.ug_schedule_destroy.restype = None
     L.ug_msm_g1.argtypes = [vp, vp, vp, i64, vp]
     L.ug_msm_g2.argtypes = [vp, vp, vp, i64, vp]
+    L.ug_msm_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.ug_hpoly_create.argtypes = [vp, vp, u64, u32, u32, pp]
     L.ug_hpoly_run.argtypes = [vp, vp, vp]
     L.ug_hpoly_chain.argtypes = [vp, vp, C.c_int, vp]

@@ -89,9 +89,32 @@ struct MsmWorkspace {
 };
 
 struct MsmStats {                 // HIP-event timing of the bucket-accumulation launches
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    static constexpr int SLOTS = 8;                 // launches that may be in flight before collect()
+    hipEvent_t ev0[SLOTS] = {}, ev1[SLOTS] = {};
+    u64 slot_entries[SLOTS] = {};
+    int pending = 0;
     double accumulate_ms = 0; u64 launches = 0; u64 entries = 0;
+    void create();
+    void destroy();
+    void collect();                                 // after the stream has been synchronised
 };
+
+// An MSM whose kernels and result copy are queued on the stream; the window sums arrive in `host` (pinned memory,
+// bucket_windows * PT_WORDS words) once the stream is synchronised. Several may be queued back to back: the stream
+// orders their use of the shared workspace.
+struct MsmPending {
+    bool g2 = false;
+    bool empty = true;           // nothing was queued: the sum is the point at infinity
+    int c = 0, bucket_windows = 0;
+    u32* host = nullptr;
+};
+constexpr size_t MSM_PENDING_WORDS = 64 * 72;       // room for the largest result block (<= 43 windows of G2 words)
+MsmPending msm_enqueue_g1(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta, hipStream_t stream,
+                          MsmStats* stats, u32* pinned_host);
+MsmPending msm_enqueue_g2(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta, hipStream_t stream,
+                          MsmStats* stats, u32* pinned_host);
+G1XYZZ msm_collect_g1(const MsmPending& p);
+G2XYZZ msm_collect_g2(const MsmPending& p);
 
 // sum over the schedule's scalars (local index i) of scalar_i * base[i + delta]; bases is a device array
 // of n_bases packed affine records in device Montgomery form ((0,0) = infinity); entries whose base

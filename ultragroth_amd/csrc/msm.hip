@@ -776,21 +776,32 @@ void MsmWorkspace::release() {
 // ---- driver -------------------------------------------------------------------------------------------------------
 namespace {
 template <class Cfg>
-XYZZ<typename Cfg::F> msm_run(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta,
-                              hipStream_t stream, MsmStats* stats) {
+MsmPending msm_enqueue(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta,
+                       hipStream_t stream, MsmStats* stats, u32* pinned_host) {
     typedef typename Cfg::F F;
     const MsmGeometry& g = s.geo;
-    if (g.n == 0 || n_bases == 0) return xyzz_inf<F>();
+    MsmPending pend;
+    pend.g2 = Cfg::PT_WORDS == G2Cfg::PT_WORDS;
+    pend.c = g.c; pend.bucket_windows = g.bucket_windows(); pend.host = pinned_host;
+    if (g.n == 0 || n_bases == 0) return pend;
+    if ((size_t)pend.bucket_windows * Cfg::PT_WORDS > MSM_PENDING_WORDS) throw std::logic_error("msm: result block too large");
+    pend.empty = false;
     u32 nb = (u32)g.total_buckets();
     u64 nseg = ((u64)s.n_valid + ((u64)1 << s.log_seg) - 1) >> s.log_seg;
     ws.reserve(g, Cfg::PT_WORDS == G2Cfg::PT_WORDS, nseg, s.n_heavy_tasks);
-    if (stats) UG_HIP(hipEventRecord(stats->ev0, stream));
+    int slot = -1;
+    if (stats) {
+        if (stats->pending == MsmStats::SLOTS) throw std::logic_error("msm: too many launches in flight");
+        slot = stats->pending++;
+        stats->slot_entries[slot] = g.n * g.windows;
+        UG_HIP(hipEventRecord(stats->ev0[slot], stream));
+    }
     if (nseg) {
         hipLaunchKernelGGL(segment_accumulate_kernel<Cfg>, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, stream,
                            bases, n_bases, delta, s.keys, s.tkeys, s.tvals, s.n_valid, s.log_seg, ws.bucket_pts, ws.slot_pts);
         UG_KERNEL_CHECK();
     }
-    if (stats) UG_HIP(hipEventRecord(stats->ev1, stream));
+    if (stats) UG_HIP(hipEventRecord(stats->ev1[slot], stream));
     if (nseg > 1) {
         hipLaunchKernelGGL(bucket_fixup_kernel<Cfg>, dim3((unsigned)((nseg + 127) / 128)), dim3(128), 0, stream,
                            s.keys, s.bucket_start, s.bucket_count, s.n_valid, (u32)nseg, s.log_seg, ws.slot_pts, ws.bucket_pts);
@@ -833,23 +844,52 @@ XYZZ<typename Cfg::F> msm_run(const MsmSchedule& s, MsmWorkspace& ws, const u32*
         UG_KERNEL_CHECK();
         std::swap(cur, nxt);
     }
-    std::vector<u32> host((size_t)bw * Cfg::PT_WORDS);
-    UG_HIP(hipMemcpyAsync(host.data(), cur, host.size() * 4, hipMemcpyDeviceToHost, stream));
-    UG_HIP(hipStreamSynchronize(stream));
-    if (stats) {
-        float ms = 0;
-        UG_HIP(hipEventElapsedTime(&ms, stats->ev0, stats->ev1));
-        stats->accumulate_ms += ms; stats->launches++; stats->entries += g.n * g.windows;
-    }
-    // Horner over the windows, top first
+    UG_HIP(hipMemcpyAsync(pinned_host, cur, (size_t)bw * Cfg::PT_WORDS * 4, hipMemcpyDeviceToHost, stream));
+    return pend;
+}
+
+// Horner over the bucket sets, top first (one set with window tables)
+template <class Cfg>
+XYZZ<typename Cfg::F> msm_collect(const MsmPending& p) {
+    typedef typename Cfg::F F;
     XYZZ<F> acc = xyzz_inf<F>();
-    for (int w = bw - 1; w >= 0; w--) {
-        for (int k = 0; k < g.c; k++) acc = xyzz_dbl(acc);
-        acc = xyzz_add(acc, Cfg::from_words(host.data() + (size_t)w * Cfg::PT_WORDS, 1));
+    if (p.empty) return acc;
+    for (int w = p.bucket_windows - 1; w >= 0; w--) {
+        for (int k = 0; k < p.c; k++) acc = xyzz_dbl(acc);
+        acc = xyzz_add(acc, Cfg::from_words(p.host + (size_t)w * Cfg::PT_WORDS, 1));
     }
     return acc;
 }
+
+// the synchronous form: queue, wait, collect (result block in a caller-side buffer, not pinned: the copy then waits)
+template <class Cfg>
+XYZZ<typename Cfg::F> msm_run(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta,
+                              hipStream_t stream, MsmStats* stats) {
+    std::vector<u32> host(MSM_PENDING_WORDS);
+    MsmPending p = msm_enqueue<Cfg>(s, ws, bases, n_bases, delta, stream, stats, host.data());
+    UG_HIP(hipStreamSynchronize(stream));
+    if (stats) stats->collect();
+    return msm_collect<Cfg>(p);
+}
 }  // namespace
+
+void MsmStats::create() { for (int i = 0; i < SLOTS; i++) { UG_HIP(hipEventCreate(&ev0[i])); UG_HIP(hipEventCreate(&ev1[i])); } }
+void MsmStats::destroy() { for (int i = 0; i < SLOTS; i++) { if (ev0[i]) hipEventDestroy(ev0[i]); if (ev1[i]) hipEventDestroy(ev1[i]); ev0[i] = ev1[i] = nullptr; } }
+void MsmStats::collect() {
+    for (int i = 0; i < pending; i++) {
+        float ms = 0;
+        UG_HIP(hipEventElapsedTime(&ms, ev0[i], ev1[i]));
+        accumulate_ms += ms; launches++; entries += slot_entries[i];
+    }
+    pending = 0;
+}
+
+MsmPending msm_enqueue_g1(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta, hipStream_t stream,
+                          MsmStats* stats, u32* pinned_host) { return msm_enqueue<G1Cfg>(s, ws, bases, n_bases, delta, stream, stats, pinned_host); }
+MsmPending msm_enqueue_g2(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta, hipStream_t stream,
+                          MsmStats* stats, u32* pinned_host) { return msm_enqueue<G2Cfg>(s, ws, bases, n_bases, delta, stream, stats, pinned_host); }
+G1XYZZ msm_collect_g1(const MsmPending& p) { return msm_collect<G1Cfg>(p); }
+G2XYZZ msm_collect_g2(const MsmPending& p) { return msm_collect<G2Cfg>(p); }
 
 G1XYZZ msm_g1(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta, hipStream_t stream, MsmStats* stats) {
     return msm_run<G1Cfg>(s, ws, bases, n_bases, delta, stream, stats);

@@ -375,10 +375,11 @@ public:
             uint8_t* out = (lo == wr_.lo) ? partials : part;
             memset(part, 0, sizeof part);
             buildSchedule(d_.sw, d_.w, lo, n, tableW_);
-            ugCheck(ug_msm_g1(d_.ctx, d_.A, d_.sw, 0, out));                                   // S1  :55
-            ugCheck(ug_msm_g1(d_.ctx, d_.B1, d_.sw, 0, out + 64));                             // S2  :58
-            ugCheck(ug_msm_g2(d_.ctx, d_.B2, d_.sw, 0, out + 128));                            // S3  :61
-            ugCheck(ug_msm_g1(d_.ctx, d_.C, d_.sw, (int64_t)hdr_.nPublic + 1, out + 256));     // S4  :64
+            // S1-S4 (src/groth16.cpp:55,58,61,64): A, B1, B2, C over the witness schedule, queued back to back
+            const ug_bases* sets[4] = {d_.A, d_.B1, d_.B2, d_.C};
+            const int64_t shifts[4] = {0, 0, 0, (int64_t)hdr_.nPublic + 1};
+            void* outs[4] = {out, out + 64, out + 128, out + 256};
+            ugCheck(ug_msm_batch(d_.ctx, 4, sets, d_.sw, shifts, outs));
             if (out == part && ug_groth16_partials_add(partials, part) != PROVER_OK) throw std::runtime_error("partial sum failed");
         }
         collectTimings();
@@ -666,9 +667,11 @@ public:
         // (a std::async future joins in its destructor, and r, s, rkw are declared before it: they outlive the threads)
         buildSchedule(d_.sw, d_.w, 0, M, tableW_);
         uint8_t sums[UG_GROTH16_PARTIALS_SIZE];
-        ugCheck(ug_msm_g1(d_.ctx, d_.A, d_.sw, 0, sums));                                   // MSM1 :201
-        ugCheck(ug_msm_g1(d_.ctx, d_.B1, d_.sw, 0, sums + 64));                             // MSM2 :214
-        ugCheck(ug_msm_g2(d_.ctx, d_.B2, d_.sw, 0, sums + 128));                            // MSM3 :227
+        {                                                                                   // MSM1-3 :201,214,227
+            const ug_bases* sets[3] = {d_.A, d_.B1, d_.B2};
+            void* outs[3] = {sums, sums + 64, sums + 128};
+            ugCheck(ug_msm_batch(d_.ctx, 3, sets, d_.sw, nullptr, outs));
+        }
         mark("A, B1, B2 MSMs");
         ugCheck(ug_dvec_gather_index(d_.aux, d_.w, d_.finalIdx));                           // :439-445
         mark("final gather");

@@ -30,6 +30,7 @@ struct ug_ctx {
     double msm_ms = 0, fft_ms = 0;
     NttPlan raw_ntt;                       // cache for ug_fr_ntt
     u32* lookup_last = nullptr; u64 lookup_last_n = 0;   // zeroed scratch of ug_dvec_apply_lookup
+    u32* pinned_results = nullptr;         // MsmStats::SLOTS result blocks of queued MSMs (ug_msm_batch)
     void use() const { UG_HIP(hipSetDevice(device)); }
 };
 struct ug_bases {
@@ -87,7 +88,8 @@ int ug_ctx_create(ug_ctx** out, int device) {
     c->use();
     UG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     UG_HIP(hipEventCreate(&c->t0)); UG_HIP(hipEventCreate(&c->t1));
-    for (int k = 0; k < 2; k++) { UG_HIP(hipEventCreate(&c->stats[k].ev0)); UG_HIP(hipEventCreate(&c->stats[k].ev1)); }
+    for (int k = 0; k < 2; k++) c->stats[k].create();
+    UG_HIP(hipHostMalloc((void**)&c->pinned_results, (size_t)MsmStats::SLOTS * MSM_PENDING_WORDS * 4, hipHostMallocDefault));
     *out = c;
     UG_CATCH
 }
@@ -98,7 +100,8 @@ void ug_ctx_destroy(ug_ctx* c) {
     c->ws_g1.release(); c->ws_g2.release(); c->raw_ntt.release();
     if (c->lookup_last) hipFree(c->lookup_last);
     hipEventDestroy(c->t0); hipEventDestroy(c->t1);
-    for (int k = 0; k < 2; k++) { hipEventDestroy(c->stats[k].ev0); hipEventDestroy(c->stats[k].ev1); }
+    for (int k = 0; k < 2; k++) c->stats[k].destroy();
+    if (c->pinned_results) hipHostFree(c->pinned_results);
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -393,6 +396,37 @@ int ug_msm_g2(ug_ctx* c, const ug_bases* b, const ug_schedule* s, int64_t index_
     G2XYZZ r = msm_g2(s->sched, c->ws_g2, b->pts, b->n, delta, c->stream, &c->stats[1]);
     tm.stop();
     affine_out_g2((uint8_t*)out, r);
+    UG_CATCH
+}
+
+// Several MSMs over one schedule, queued back to back on the stream with ONE host synchronisation at the end: the
+// latency-bound tail of one product (bucket reduction, tree sums, result copy) no longer leaves the device idle while the
+// host converts the previous result (A, B1, B2, C of src/groth16.cpp:55-64 share the witness schedule).
+int ug_msm_batch(ug_ctx* c, int count, const ug_bases* const* bases, const ug_schedule* s, const int64_t* index_shifts,
+                 void* const* outs) {
+    UG_TRY
+    if (!c || !s || (count && (!bases || !outs))) throw std::invalid_argument("null argument");
+    if (count < 0 || count > MsmStats::SLOTS) throw std::invalid_argument("at most 8 products per batch");
+    for (int k = 0; k < count; k++) {
+        if (!bases[k] || !outs[k]) throw std::invalid_argument("null argument");
+        check_tables(bases[k], s);
+    }
+    c->use();
+    ScopedTimer tm(c, &c->msm_ms);
+    MsmPending pend[MsmStats::SLOTS];
+    for (int k = 0; k < count; k++) {
+        const ug_bases* b = bases[k];
+        int64_t delta = (int64_t)s->first - (index_shifts ? index_shifts[k] : 0) - (int64_t)b->global_first;
+        u32* host = c->pinned_results + (size_t)k * MSM_PENDING_WORDS;
+        pend[k] = b->g2 ? msm_enqueue_g2(s->sched, c->ws_g2, b->pts, b->n, delta, c->stream, &c->stats[1], host)
+                        : msm_enqueue_g1(s->sched, c->ws_g1, b->pts, b->n, delta, c->stream, &c->stats[0], host);
+    }
+    tm.stop();                                       // synchronises the stream
+    c->stats[0].collect(); c->stats[1].collect();
+    for (int k = 0; k < count; k++) {
+        if (bases[k]->g2) affine_out_g2((uint8_t*)outs[k], msm_collect_g2(pend[k]));
+        else affine_out_g1((uint8_t*)outs[k], msm_collect_g1(pend[k]));
+    }
     UG_CATCH
 }
 
