@@ -405,3 +405,54 @@ def test_ranges_above_the_schedule_limit_are_proved_in_pieces(device, monkeypatc
         finally:
             ug.set_test_blinding(b"")
     assert got == (exp[0], exp[1])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_irregular_circuits(device, seed):
+    """randomised shapes the fixed generator never produces: rows with no entry, rows only in A or only in B, rows with
+    up to 40 entries, repeated (matrix, row, signal) records, coefficients above r, 0..3 public signals, domains 2^3..2^10;
+    witness values include 0, 1 and r - 1. Proof and public.json equal the oracle's."""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    rng = np.random.Generator(np.random.PCG64(0xC0FFEE + seed))
+    log_domain = int(rng.integers(3, 11))
+    domain, nvars = 1 << log_domain, (1 << log_domain) - 1
+    n_public = int(rng.integers(0, 4))
+    recs = []
+    for row in range(domain):
+        kind = rng.integers(0, 6)
+        if kind == 0:
+            continue                                                   # empty row
+        n_a = 0 if kind == 1 else int(rng.integers(1, 4))
+        n_b = 0 if kind == 2 else int(rng.integers(1, 4))
+        if kind == 5 and row % 17 == 0:
+            n_a = 40                                                   # a long row
+        for m, cnt in ((0, n_a), (1, n_b)):
+            sigs = rng.integers(0, nvars, size=cnt)
+            if cnt > 1 and rng.integers(0, 3) == 0:
+                sigs[1] = sigs[0]                                      # the same record position twice
+            for sg in sigs:
+                recs.append((m, row, int(sg)))
+    dt = np.dtype([("m", "<u4"), ("c", "<u4"), ("s", "<u4"), ("v", "<u8", (4,))], align=False)
+    coefs = np.zeros(len(recs), dtype=dt)
+    if recs:
+        arr = np.array(recs, dtype=np.uint32)
+        coefs["m"], coefs["c"], coefs["s"] = arr[:, 0], arr[:, 1], arr[:, 2]
+        coefs["v"] = rng.integers(0, 1 << 63, size=(len(recs), 4), dtype=np.uint64) * np.uint64(2)   # up to 2^256: above r too
+        coefs = coefs[rng.permutation(len(recs))]
+    zkey, wtns, info = synth.build_circuit(device, log_domain, mix="C", seed=0x5EED0400 + seed, n_public=n_public, coefs=coefs)
+    # sprinkle special witness values
+    w = bytearray(wtns)
+    off = O.section(wtns, "wtns", 2)[0]
+    for i, val in ((3, 0), (4, 1), (5, O.R_MOD - 1)):
+        if i < nvars:
+            w[off + 32 * i:off + 32 * i + 32] = O.to_le(val)
+    wtns = bytes(w)
+    r, s = fixed_rs()
+    exp = O.groth16_prove(zkey, wtns, int.from_bytes(r, "little"), int.from_bytes(s, "little"))
+    ug.set_test_blinding(r + s)
+    try:
+        got = ug.groth16_prover(zkey, wtns)
+    finally:
+        ug.set_test_blinding(b"")
+    assert got == (exp[0], exp[1])

@@ -99,7 +99,7 @@ def _section(sid, payload):
     return struct.pack("<IQ", sid, len(payload)) + payload
 
 
-def build_circuit(dev, log_domain, mix="U", seed=0x5EED0000, n_public=1, g1_only=False):
+def build_circuit(dev, log_domain, mix="U", seed=0x5EED0000, n_public=1, g1_only=False, coefs=None):
     """Returns (zkey, wtns_bytes, info). Sections are laid out as snarkjs does (1..10). The zkey comes back as a
     ctypes char array (buffer protocol, ``len``, accepted wherever the bindings take ``bytes``): every section is
     generated in place, so the peak host footprint is one zkey (9.4 GB at 2^24), not two."""
@@ -113,7 +113,9 @@ def build_circuit(dev, log_domain, mix="U", seed=0x5EED0000, n_public=1, g1_only
     vk_g2 = bytes(synth_points(dev, 3, SEEDS["VK"], g2=True))           # beta2, gamma2, delta2
     header = struct.pack("<I", 32) + q_le + struct.pack("<I", 32) + r_le + struct.pack("<III", nvars, n_public, domain)
     header += vk_g1[0:64] + vk_g1[64:128] + vk_g2[0:128] + vk_g2[128:256] + vk_g1[128:192] + vk_g2[256:384]
-    n_coefs = 4 * domain
+    if coefs is None:
+        coefs = coefficients(domain, nvars, seed + 1)
+    n_coefs = len(coefs)                                                 # (a caller may pass its own record array)
     sizes = [(1, 4), (2, len(header)), (3, 64 * (n_public + 1)), (4, 4 + 44 * n_coefs), (5, 64 * nvars), (6, 64 * nvars),
              (7, 128 * nvars), (8, 64 * n_c), (9, 64 * domain), (10, 0)]
     total = 12 + sum(12 + sz for _, sz in sizes)
@@ -129,8 +131,8 @@ def build_circuit(dev, log_domain, mix="U", seed=0x5EED0000, n_public=1, g1_only
     view[at[2][0]:at[2][1]] = header
     lo, hi = at[4]
     view[lo:lo + 4] = struct.pack("<I", n_coefs)
-    coefs = coefficients(domain, nvars, seed + 1)
-    np.frombuffer(view[lo + 4:hi], dtype=coefs.dtype)[:] = coefs
+    if n_coefs:
+        np.frombuffer(view[lo + 4:hi], dtype=coefs.dtype)[:] = coefs
     del coefs
     synth_points(dev, nvars, SEEDS["A"], out=view[at[5][0]:at[5][1]])
     if not g1_only:
