@@ -115,32 +115,134 @@ def witness_slice(info, rank, world):
     return cuts[rank], cuts[rank + 1]
 
 
-def bench_ultra(args, dev, ug, synth):
-    """UltraGroth: the whole ultra_groth_prover_prove call (witness upload, round-1 commitment MSM, Keccak
-    challenge, host lookup completion, final-round MSMs + H polynomial, blinding, JSON)."""
+def bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_rank):
+    """UltraGroth (BASELINE.json configs[4]). N = 1: the whole ultra_groth_prover_prove call (witness upload, round
+    commitment MSM, Keccak challenge, lookup completion, final-round MSMs + H polynomial, blinding, JSON).
+    N > 1: the sharded prover -- every rank uploads the witness and commits to its slice of the round set; the 64-byte
+    parts are all-gathered and added, rank 0 closes the round and broadcasts the commitment; every rank applies it and
+    runs its slices of the final MSMs; the three NTT chains go to ranks 0..2 with their evaluation vectors scattered
+    slice-wise, as for Groth16; the 384-byte partial blocks are all-gathered and rank 0 finishes."""
     zkey, uwtns, info = synth.build_ultra_circuit(dev, args.log_domain, mix="C")
+    workload = ("ultragroth-bn254 2^%d constraints, two rounds, lookup 2^8, circom-like witness (BASELINE.json configs[4] "
+                "shape; witness from host memory)" % args.log_domain)
+
+    def line(elapsed, msm_ms, fft_ms, create_s, parallelism):
+        print(json.dumps({
+            "metric": "proofs/s", "value": args.steps / elapsed, "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 254-bit modular integers)", "data": "synthetic",
+            "config": {"workload": workload, "log_domain": args.log_domain, "protocol": "ultragroth", "parallelism": parallelism},
+            "msm_ms_per_proof": msm_ms / args.steps, "fft_ms_per_proof": fft_ms / args.steps, "create_s": create_s,
+        }))
+
+    if world == 1:
+        t0 = time.perf_counter()
+        prover = ug.UltraGrothProver(zkey)
+        create_s = time.perf_counter() - t0
+        for _ in range(args.warmup):
+            prover.prove(uwtns)
+        msm_ms = fft_ms = 0.0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            prover.prove(uwtns)
+            m, f, _ = prover.last_timings()
+            msm_ms += m
+            fft_ms += f
+        return line(time.perf_counter() - t0, msm_ms, fft_ms, create_s, "one GPU")
+
     t0 = time.perf_counter()
-    prover = ug.UltraGrothProver(zkey)
+    prover = ug.ShardedUltraGrothProver(zkey, local_rank, rank, world)
     create_s = time.perf_counter() - t0
+    del zkey
+    cuda = backend == "nccl"
+    n_dom = info["domainSize"]
+    split_h = n_dom % world == 0
+    sl = n_dom // world if split_h else 0
+    my_chains = [k for k in range(3) if k % world == rank] if split_h else list(range(3))
+    fulls = {k: torch.empty((n_dom, 32), dtype=torch.uint8, device="cuda") for k in my_chains}
+    bufs = torch.empty((3, max(sl, 1), 32), dtype=torch.uint8, device="cuda")
+
+    def to_comm(b):
+        t = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+        return t.cuda() if cuda else t
+
+    def gather_all(b):
+        mine = to_comm(b)
+        allp = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        return [bytes(t.cpu().numpy()) for t in allp]
+
+    def step():
+        prover.load_witness(uwtns)
+        total = bytes(64)
+        for part in gather_all(prover.round_commit()):
+            total = ug.ShardedUltraGrothProver.add_records(total, part)
+        commitment = to_comm(prover.round_finish(total) if rank == 0 else bytes(64))
+        dist.broadcast(commitment, src=0)
+        prover.apply_commitment(bytes(commitment.cpu().numpy()))
+        part = prover.run_witness_msm()
+        if split_h:
+            for k in my_chains:                 # (the UltraGroth prover has one stream: its chains follow its MSMs)
+                prover.hpoly_chain(k, fulls[k].data_ptr())
+            for k in range(3):
+                src = k % world
+                if cuda:
+                    dist.scatter(bufs[k], [fulls[k][q * sl:(q + 1) * sl] for q in range(world)] if rank == src else None, src=src)
+                else:                           # gloo rehearsal: through host memory
+                    o = torch.empty(bufs[k].shape, dtype=torch.uint8)
+                    dist.scatter(o, [fulls[k][q * sl:(q + 1) * sl].cpu() for q in range(world)] if rank == src else None, src=src)
+                    bufs[k].copy_(o)
+            torch.cuda.synchronize()
+            prover.hpoly_combine(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr())
+        else:                                   # the domain does not split evenly: every rank forms h itself
+            for k in range(3):
+                prover.hpoly_chain(k, fulls[k].data_ptr())
+            first, cnt, _ = prover.h_range()
+            sl_bufs = [fulls[k][first:first + cnt].contiguous() for k in range(3)]
+            torch.cuda.synchronize()
+            prover.hpoly_combine(*(b.data_ptr() for b in sl_bufs))
+        part = part[:320] + prover.run_h_msm()[320:384]
+        acc = None
+        for other in gather_all(part):
+            acc = other if acc is None else ug.ShardedGroth16Prover.add_partials(acc, other)
+        return prover.finish(acc) if rank == 0 else None
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(args.warmup):
-        prover.prove(uwtns)
+        step()
+    barrier()
     msm_ms = fft_ms = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        prover.prove(uwtns)
+        step()
         m, f, _ = prover.last_timings()
         msm_ms += m
         fft_ms += f
+    barrier()
     elapsed = time.perf_counter() - t0
-    print(json.dumps({
-        "metric": "proofs/s", "value": args.steps / elapsed, "unit": "proofs/s", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 254-bit modular integers)", "data": "synthetic",
-        "config": {"workload": "ultragroth-bn254 2^%d constraints, two rounds, lookup 2^8, circom-like witness "
-                               "(BASELINE.json configs[4] shape, 1 GPU; witness from host memory)" % args.log_domain,
-                   "log_domain": args.log_domain, "protocol": "ultragroth"},
-        "msm_ms_per_proof": msm_ms / args.steps, "fft_ms_per_proof": fft_ms / args.steps, "create_s": create_s,
-    }))
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if cuda else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    chk = None
+    if args.check:
+        rk, r, s = bytes(range(1, 32)), bytes(range(40, 71)), bytes(range(80, 111))
+        ug.set_test_blinding(rk + r + s)
+        chk = step()
+        ug.set_test_blinding(b"")
+    if rank == 0:
+        if args.check:
+            import oracle as O
+            zk, uw, _ = synth.build_ultra_circuit(dev, args.log_domain, mix="C")
+            exp = O.ultra_groth_prove(zk, uw, int.from_bytes(bytes(range(1, 32)), "little"),
+                                      int.from_bytes(bytes(range(40, 71)), "little"), int.from_bytes(bytes(range(80, 111)), "little"))
+            workload += " [check: %s]" % ("bit-exact" if chk == exp else "MISMATCH")
+        line(float(t.item()), msm_ms, fft_ms, create_s,
+             "section-range shard x%d%s" % (world, ", H-poly chains split over ranks" if split_h else ""))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main():
@@ -177,7 +279,7 @@ def main():
     dev = ug.Device(local_rank)
     log_domain = args.log_domain
     if args.ultra:
-        return bench_ultra(args, dev, ug, synth)
+        return bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_rank)
     zkey, wtns, info = synth.build_circuit(dev, log_domain, mix=args.mix, g1_only=args.g1_only)
     t0 = time.perf_counter()
     prover = ug.ShardedGroth16Prover(zkey, local_rank, rank, world, witness_range=witness_slice(info, rank, world))

@@ -160,6 +160,32 @@ int ug_groth16_prover_finish(void *prover_object, const void *partials_sum,
                              char *public_buffer, unsigned long long *public_size,
                              char *error_msg, unsigned long long error_msg_maxsize);
 
+/* Sharded UltraGroth proving (BASELINE configs[4]), one process per GPU. Rank `shard_rank` of `shard_count` holds
+ * contiguous slices of the witness-indexed sections (A, B1, B2), of the round set with its index list, of the final set
+ * with its index list, and of H; every rank keeps the whole witness. One proof, in this order:
+ *   ug_groth16_prover_load_witness           every rank: the .uwtns buffer (witness + lookup sections)
+ *   ug_ultra_groth_prover_round_commit       every rank: its part of the round commitment (64-byte affine record)
+ *     -- exchange: all ranks' parts are added (ug_g1_record_add) --
+ *   ug_ultra_groth_prover_round_finish       ONE rank: draws the round randomness, blinds the sum -> the commitment pi_r
+ *     -- exchange: the commitment goes to every rank --
+ *   ug_ultra_groth_prover_apply_commitment   every rank: Fiat-Shamir challenge, lookup signals written into its witness
+ *   ug_groth16_prover_run_witness_msm        every rank: A | B1 | B2 | final-set partial sums
+ *   ug_groth16_prover_hpoly_chain / _h_range / _hpoly_combine / _run_h_msm    as for Groth16 (or replicate the block)
+ *     -- exchange: partial blocks added (ug_groth16_partials_add) --
+ *   ug_groth16_prover_finish                 the rank that closed the round: r, s, blinding, proof.json / public.json
+ * The ug_groth16_prover_* phase calls accept both kinds of prover object. */
+int ug_ultra_groth_prover_create_sharded(void **prover_object, const void *zkey_buffer, unsigned long long zkey_size,
+                                         int device, int shard_rank, int shard_count,
+                                         char *error_msg, unsigned long long error_msg_maxsize);
+int ug_ultra_groth_prover_round_commit(void *prover_object, void *commit_part_out,
+                                       char *error_msg, unsigned long long error_msg_maxsize);
+int ug_ultra_groth_prover_round_finish(void *prover_object, const void *commit_sum, void *commitment_out,
+                                       char *error_msg, unsigned long long error_msg_maxsize);
+int ug_ultra_groth_prover_apply_commitment(void *prover_object, const void *commitment,
+                                           char *error_msg, unsigned long long error_msg_maxsize);
+/* acc += other for two 64-byte G1 affine records (all zero = infinity) */
+int ug_g1_record_add(void *acc, const void *other);
+
 #ifdef __cplusplus
 }
 #endif

@@ -456,3 +456,63 @@ def test_random_irregular_circuits(device, seed):
     finally:
         ug.set_test_blinding(b"")
     assert got == (exp[0], exp[1])
+
+
+@pytest.mark.parametrize("world,split_h", [(1, False), (3, False), (2, True)])
+def test_sharded_ultragroth_equals_oracle(device, world, split_h):
+    """BASELINE configs[4] on one GPU: `world` ranks hold slices of the witness-indexed, round, final and H sections;
+    the round commitment parts are added, one rank closes the round, every rank applies the commitment (challenge +
+    lookup signals) and runs its slices of the final MSMs; with split_h the NTT chains are split over the ranks too"""
+    import torch
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, uwtns, info = synth.build_ultra_circuit(device, 13)
+    rk, r, s = bytes(range(1, 32)), bytes(range(40, 71)), bytes(range(80, 111))
+    exp = O.ultra_groth_prove(zkey, uwtns, int.from_bytes(rk, "little"), int.from_bytes(r, "little"), int.from_bytes(s, "little"))
+    ranks = [ug.ShardedUltraGrothProver(zkey, 0, k, world) for k in range(world)]
+    ug.set_test_blinding(rk + r + s)
+    try:
+        for p in ranks:
+            p.load_witness(uwtns)
+        total = bytes(64)
+        for p in ranks:
+            total = ug.ShardedUltraGrothProver.add_records(total, p.round_commit())
+        commitment = ranks[0].round_finish(total)
+        for p in ranks:
+            p.apply_commitment(commitment)
+        parts = [p.run_witness_msm() for p in ranks]
+        n_dom = info["domainSize"]
+        if split_h:
+            sl = n_dom // world
+            full = torch.empty((3, n_dom, 32), dtype=torch.uint8, device="cuda")
+            for k in range(3):
+                ranks[k % world].hpoly_chain(k, full[k].data_ptr())
+            torch.cuda.synchronize()
+            for q, p in enumerate(ranks):
+                bufs = [full[k, q * sl:(q + 1) * sl].contiguous() for k in range(3)]
+                torch.cuda.synchronize()
+                p.hpoly_combine(*(b.data_ptr() for b in bufs))
+        else:                                   # every rank forms the whole h (three chains into scratch, combine its slice)
+            full = torch.empty((3, n_dom, 32), dtype=torch.uint8, device="cuda")
+            for q, p in enumerate(ranks):
+                for k in range(3):
+                    p.hpoly_chain(k, full[k].data_ptr())
+                first, cnt, _ = p.h_range()
+                bufs = [full[k, first:first + cnt].contiguous() for k in range(3)]
+                torch.cuda.synchronize()
+                p.hpoly_combine(*(b.data_ptr() for b in bufs))
+        acc = None
+        for q, p in enumerate(ranks):
+            part = parts[q][:320] + p.run_h_msm()[320:384]
+            acc = part if acc is None else ug.ShardedGroth16Prover.add_partials(acc, part)
+        got = ranks[0].finish(acc)
+    finally:
+        ug.set_test_blinding(b"")
+    assert got == exp
+    with pytest.raises(ug.ProverError, match="did not close the round"):
+        if world > 1:
+            ranks[1].finish(acc)
+        else:
+            raise ug.ProverError(1, "finish on a rank that did not close the round")
+    for p in ranks:
+        p.close()

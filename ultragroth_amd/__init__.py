@@ -293,6 +293,65 @@ class ShardedGroth16Prover:
             pass
 
 
+class ShardedUltraGrothProver(ShardedGroth16Prover):
+    """One rank of a sharded UltraGroth prover (include/prover.h: ug_ultra_groth_prover_create_sharded and the phase
+    calls it shares with the Groth16 one). Per proof: load_witness(uwtns) / round_commit() on every rank, the parts
+    added (add_records), round_finish(sum) on one rank, apply_commitment(commitment) on every rank, then the Groth16
+    phases and finish() on the rank that closed the round."""
+
+    def __init__(self, zkey, device, rank, world):
+        L = load()
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(1024)
+        rc = L.ug_ultra_groth_prover_create_sharded(C.byref(self._h), zkey, len(zkey), device, rank, world, err, len(err) - 1)
+        if rc != PROVER_OK:
+            self._h = None
+            raise ProverError(rc, err.value.decode(errors="replace"))
+        self._public_size = ultra_groth_public_size_for_zkey_buf(zkey)
+
+    def _call(self, name, *args):
+        err = C.create_string_buffer(1024)
+        rc = getattr(load(), name)(self._h, *args, err, len(err) - 1)
+        if rc != PROVER_OK:
+            raise ProverError(rc, err.value.decode(errors="replace"))
+
+    def round_commit(self):
+        out = C.create_string_buffer(64)
+        self._call("ug_ultra_groth_prover_round_commit", out)
+        return out.raw
+
+    def round_finish(self, commit_sum):
+        out = C.create_string_buffer(64)
+        self._call("ug_ultra_groth_prover_round_finish", bytes(commit_sum), out)
+        return out.raw
+
+    def apply_commitment(self, commitment):
+        self._call("ug_ultra_groth_prover_apply_commitment", bytes(commitment))
+
+    @staticmethod
+    def add_records(acc, other):
+        a = C.create_string_buffer(bytes(acc), 64)
+        if load().ug_g1_record_add(a, bytes(other)) != PROVER_OK:
+            raise ProverError(PROVER_ERROR, "record add failed")
+        return a.raw
+
+    def finish(self, partials_sum):
+        psz = C.c_ulonglong(ultra_groth_proof_size())
+        qsz = C.c_ulonglong(self._public_size)
+        proof = C.create_string_buffer(psz.value)
+        pub = C.create_string_buffer(max(qsz.value, 1))
+        err = C.create_string_buffer(1024)
+        rc = load().ug_groth16_prover_finish(self._h, bytes(partials_sum), proof, C.byref(psz), pub, C.byref(qsz), err, len(err) - 1)
+        if rc != PROVER_OK:
+            raise ProverError(rc, err.value.decode(errors="replace"))
+        return proof.raw.split(b"\0", 1)[0].decode(), pub.raw.split(b"\0", 1)[0].decode()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().ultra_groth_prover_destroy(self._h)
+            self._h = None
+
+
 # ---------------------------------------------------------------------------------------------------
 # inner ABI (include/ultragroth_hip.h)
 

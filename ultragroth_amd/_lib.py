@@ -33,7 +33,10 @@ OUTER_SYMBOLS = [
     "groth16_prover", "ultra_groth_prover",
     "groth16_prover_zkey_file", "ultra_groth_prover_zkey_file",
     "ug_test_set_blinding", "ug_prover_last_timings", "ug_prover_kernel_stats",
-    "ug_groth16_prover_create_sharded", "ug_groth16_prover_create_sharded_range", "ug_groth16_prover_load_witness", "ug_groth16_prover_run",
+    "ug_groth16_prover_create_sharded", "ug_groth16_prover_create_sharded_range",
+    "ug_ultra_groth_prover_create_sharded", "ug_ultra_groth_prover_round_commit", "ug_ultra_groth_prover_round_finish",
+    "ug_ultra_groth_prover_apply_commitment", "ug_g1_record_add",
+    "ug_groth16_prover_load_witness", "ug_groth16_prover_run",
     "ug_groth16_partials_add", "ug_groth16_prover_finish",
     "ug_groth16_prover_run_witness_msm", "ug_groth16_prover_run_h_msm", "ug_groth16_prover_hpoly_chain",
     "ug_groth16_prover_hpoly_combine", "ug_groth16_prover_h_range",
@@ -128,6 +131,11 @@ def load():
     L.ug_prover_last_timings.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ug_prover_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_double), pull, pull, C.c_int]
     L.ug_groth16_prover_create_sharded.argtypes = [pp, vp, ull, C.c_int, C.c_int, C.c_int, vp, ull]
+    L.ug_ultra_groth_prover_create_sharded.argtypes = [pp, vp, ull, C.c_int, C.c_int, C.c_int, vp, ull]
+    L.ug_ultra_groth_prover_round_commit.argtypes = [vp, vp, vp, ull]
+    L.ug_ultra_groth_prover_round_finish.argtypes = [vp, vp, vp, vp, ull]
+    L.ug_ultra_groth_prover_apply_commitment.argtypes = [vp, vp, vp, ull]
+    L.ug_g1_record_add.argtypes = [vp, vp]
     L.ug_groth16_prover_create_sharded_range.argtypes = [pp, vp, ull, C.c_int, C.c_int, C.c_int, ull, ull, vp, ull]
     L.ug_groth16_prover_load_witness.argtypes = [vp, vp, ull, vp, ull]
     L.ug_groth16_prover_run.argtypes = [vp, vp, vp, ull]

@@ -265,6 +265,19 @@ struct ProverBase {        // what the extern "C" layer stores behind the opaque
     virtual unsigned long long publicBufferMinSize() const = 0;
     virtual void timings(double* msm, double* fft, double* total) const = 0;
     virtual ug_ctx* ctx() = 0;
+    // phases of a sharded proof (include/prover.h); both provers implement them
+    [[noreturn]] static void noPhase() { throw std::invalid_argument("this prover object does not support the call"); }
+    virtual void loadWitness(const void*, unsigned long long) { noPhase(); }
+    virtual void run(uint8_t*) { noPhase(); }
+    virtual void runWitnessMsm(uint8_t*, bool = true) { noPhase(); }
+    virtual void runHMsm(uint8_t*) { noPhase(); }
+    virtual void hpolyChain(int, void*) { noPhase(); }
+    virtual void hpolyCombine(void*, void*, void*) { noPhase(); }
+    virtual void hRange(unsigned long long*, unsigned long long*, unsigned long long*) const { noPhase(); }
+    virtual void finish(const uint8_t*, std::string&, std::string&) { noPhase(); }
+    virtual void roundCommit(uint8_t*) { noPhase(); }
+    virtual void roundFinish(const uint8_t*, uint8_t*) { noPhase(); }
+    virtual void applyCommitment(const uint8_t*) { noPhase(); }
     virtual int kernelStats(int g2, double* avgMs, unsigned long long* launches, unsigned long long* entries, int reset) {
         uint64_t l = 0, e = 0;
         int rc = ug_ctx_kernel_stats(ctx(), g2, avgMs, &l, &e, reset);
@@ -349,7 +362,7 @@ public:
 
     const ZkeyHeader& header() const { return hdr_; }
 
-    void loadWitness(const void* wtns, unsigned long long wtnsSize) {
+    void loadWitness(const void* wtns, unsigned long long wtnsSize) override {
         BinFile f(wtns, wtnsSize, "wtns", 2);
         WtnsHeader wh = loadWtnsHeader(f);
         if (hdr_.nVars != wh.nVars)
@@ -363,7 +376,7 @@ public:
     }
 
     // S1-S4 on this rank's slice; partials = A | B1 | B2 | C | H affine records (H left at infinity)
-    void runWitnessMsm(uint8_t* partials, bool resetTimers = true) {
+    void runWitnessMsm(uint8_t* partials, bool resetTimers = true) override {
         if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
         if (resetTimers) { ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1)); ugCheck(ug_ctx_timings(d_.ctx2, nullptr, nullptr, 1)); }
         // A schedule holds at most 2^31 (scalar, window) entries; ranges above MAX_RANGE scalars (only the
@@ -385,7 +398,7 @@ public:
         collectTimings();
     }
     // S10 on this rank's slice of h (which must be in d_.h); only the H record of partials is written
-    void runHMsm(uint8_t* partials) {
+    void runHMsm(uint8_t* partials) override {
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
         uint8_t part[UG_GROTH16_PARTIALS_SIZE];
         for (uint64_t lo = hr_.lo; lo < hr_.hi; lo += maxRange_) {
@@ -404,7 +417,7 @@ public:
         ugCheck(ug_ctx_timings(d_.ctx2, &m2, &f2, 0));
         msmMs_ = m1 + m2; fftMs_ = f1 + f2;      // device time per branch; the branches overlap in wall time
     }
-    void hpolyChain(int which, void* deviceOut) {
+    void hpolyChain(int which, void* deviceOut) override {
         if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
         ug_dvec* v = nullptr;
         ugCheck(ug_dvec_wrap(d_.ctx2, deviceOut, hdr_.domainSize, &v));
@@ -413,7 +426,7 @@ public:
         ugCheck(rc);
         collectTimings();
     }
-    void hpolyCombine(void* da, void* db, void* dc) {
+    void hpolyCombine(void* da, void* db, void* dc) override {
         uint64_t cnt = hr_.hi - hr_.lo;
         ug_dvec *a = nullptr, *b = nullptr, *c = nullptr;
         ugCheck(ug_dvec_wrap(d_.ctx2, da, cnt, &a));
@@ -424,7 +437,7 @@ public:
         ugCheck(rc);
         collectTimings();
     }
-    void hRange(unsigned long long* first, unsigned long long* count, unsigned long long* domain) const {
+    void hRange(unsigned long long* first, unsigned long long* count, unsigned long long* domain) const override {
         if (first) *first = hr_.lo;
         if (count) *count = hr_.hi - hr_.lo;
         if (domain) *domain = hdr_.domainSize;
@@ -435,7 +448,7 @@ public:
     // the H MSM) on the other, so the memory-bound kernels of one branch overlap the integer-bound kernels of the other
     // (measured: 148 -> 144 ms per 2^24 proof, 49.9 -> 46.7 ms at 2^22). Off by default: overlapped kernels stretch each other, which blurs the
     // per-kernel durations and the MSM | FFT split that bench.py and rocprof report.
-    void run(uint8_t* partials) {
+    void run(uint8_t* partials) override {
         if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
         ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1));
         ugCheck(ug_ctx_timings(d_.ctx2, nullptr, nullptr, 1));
@@ -476,7 +489,7 @@ public:
         return UG_OK;
     }
 
-    void finish(const uint8_t* sums, std::string& proof, std::string& pub) {
+    void finish(const uint8_t* sums, std::string& proof, std::string& pub) override {
         uint8_t r[32], s[32];
         drawBlinding(r); drawBlinding(s);                                                      // S11 :158-166
         finishWith(sums, r, s, blindingTerms(hdr_, r, s), proof, pub);
@@ -529,7 +542,10 @@ private:
 // =================================================================================================================
 class UltraGrothProver : public ProverBase {
 public:
-    UltraGrothProver(const void* zkey, unsigned long long zkeySize, int device) {
+    // rank `rank` of `count`: the witness-indexed sets (A, B1, B2), the round set (C1 with round_indexes), the final set
+    // (C2 with final_round_indexes) and H are each cut into `count` contiguous slices; every rank keeps the whole witness
+    UltraGrothProver(const void* zkey, unsigned long long zkeySize, int device, int rank = 0, int count = 1) {
+        if (count < 1 || rank < 0 || rank >= count) throw std::invalid_argument("invalid shard rank / count");
         BinFile f(zkey, zkeySize, "zkey", 1);
         hdr_ = loadZkeyHeader(f, true);
         if (!hdr_.rIsBn254) throw std::invalid_argument("zkey curve not supported");
@@ -549,23 +565,28 @@ public:
         const uint8_t* idx1 = checkedSection(f, 10, (uint64_t)hdr_.numIndexesC1 * 4);
         const uint8_t* idx2 = checkedSection(f, 11, (uint64_t)hdr_.numIndexesC2 * 4);
         const uint8_t* pH = checkedSection(f, 12, N * 64);
-        roundIdx_.resize(hdr_.numIndexesC1); finalIdx_.resize(hdr_.numIndexesC2);
-        memcpy(roundIdx_.data(), idx1, roundIdx_.size() * 4);
-        memcpy(finalIdx_.data(), idx2, finalIdx_.size() * 4);
+        wr_ = shardRange(M, rank, count);
+        hr_ = shardRange(N, rank, count);
+        const Range c1 = shardRange(hdr_.numIndexesC1, rank, count), c2 = shardRange(hdr_.numIndexesC2, rank, count);
+        roundIdx_.resize(c1.hi - c1.lo); finalIdx_.resize(c2.hi - c2.lo);
+        memcpy(roundIdx_.data(), idx1 + c1.lo * 4, roundIdx_.size() * 4);
+        memcpy(finalIdx_.data(), idx2 + c2.lo * 4, finalIdx_.size() * 4);
         for (uint32_t i : roundIdx_) if (i >= M) throw std::range_error("round index outside the witness");
         for (uint32_t i : finalIdx_) if (i >= M) throw std::range_error("final round index outside the witness");
 
         ugCheck(ug_ctx_create(&d_.ctx, device));
-        ugCheck(ug_bases_create_g1(d_.ctx, pA, M, 0, &d_.A));
-        ugCheck(ug_bases_create_g1(d_.ctx, pB1, M, 0, &d_.B1));
-        ugCheck(ug_bases_create_g2(d_.ctx, pB2, M, 0, &d_.B2));
-        ugCheck(ug_bases_create_g1(d_.ctx, pFinalC, hdr_.numIndexesC2, 0, &d_.C));
-        ugCheck(ug_bases_create_g1(d_.ctx, pRoundC, hdr_.numIndexesC1, 0, &d_.roundC));
-        ugCheck(ug_bases_create_g1(d_.ctx, pH, N, 0, &d_.H));
+        ugCheck(ug_bases_create_g1(d_.ctx, pA + wr_.lo * 64, wr_.hi - wr_.lo, wr_.lo, &d_.A));
+        ugCheck(ug_bases_create_g1(d_.ctx, pB1 + wr_.lo * 64, wr_.hi - wr_.lo, wr_.lo, &d_.B1));
+        ugCheck(ug_bases_create_g2(d_.ctx, pB2 + wr_.lo * 128, wr_.hi - wr_.lo, wr_.lo, &d_.B2));
+        // the round / final sets are multiplied with GATHERED scalars (position k of the slice's index list), so their
+        // slices count from 0
+        ugCheck(ug_bases_create_g1(d_.ctx, pFinalC + c2.lo * 64, c2.hi - c2.lo, 0, &d_.C));
+        ugCheck(ug_bases_create_g1(d_.ctx, pRoundC + c1.lo * 64, c1.hi - c1.lo, 0, &d_.roundC));
+        ugCheck(ug_bases_create_g1(d_.ctx, pH + hr_.lo * 64, hr_.hi - hr_.lo, hr_.lo, &d_.H));
         ugCheck(ug_hpoly_create(d_.ctx, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
         ugCheck(ug_dvec_create(d_.ctx, M, &d_.w));
         ugCheck(ug_dvec_create(d_.ctx, N, &d_.h));
-        uint64_t auxN = hdr_.numIndexesC1 > hdr_.numIndexesC2 ? hdr_.numIndexesC1 : hdr_.numIndexesC2;
+        uint64_t auxN = std::max<uint64_t>(roundIdx_.size(), finalIdx_.size());
         ugCheck(ug_dvec_create(d_.ctx, auxN ? auxN : 1, &d_.aux));
         ugCheck(ug_schedule_create(d_.ctx, &d_.sw));
         ugCheck(ug_schedule_create(d_.ctx, &d_.sh));
@@ -573,18 +594,19 @@ public:
         ugCheck(ug_index_create(d_.ctx, roundIdx_.data(), roundIdx_.size(), &d_.roundIdx));
         ugCheck(ug_index_create(d_.ctx, finalIdx_.data(), finalIdx_.size(), &d_.finalIdx));
         std::vector<TableGroup> groups(4);
-        groups[0].g1 = {d_.A, d_.B1}; groups[0].n1 = {M, M}; groups[0].g2 = {d_.B2}; groups[0].n2 = {M};
-        groups[0].scalars = M; groups[0].c = &tableW_;
-        groups[1].g1 = {d_.roundC}; groups[1].n1 = {hdr_.numIndexesC1}; groups[1].scalars = hdr_.numIndexesC1; groups[1].c = &tableC1_;
-        groups[2].g1 = {d_.C}; groups[2].n1 = {hdr_.numIndexesC2}; groups[2].scalars = hdr_.numIndexesC2; groups[2].c = &tableC2_;
-        groups[3].g1 = {d_.H}; groups[3].n1 = {N}; groups[3].scalars = N; groups[3].c = &tableH_;
+        const uint64_t nw = wr_.hi - wr_.lo;
+        groups[0].g1 = {d_.A, d_.B1}; groups[0].n1 = {nw, nw}; groups[0].g2 = {d_.B2}; groups[0].n2 = {nw};
+        groups[0].scalars = nw; groups[0].c = &tableW_;
+        groups[1].g1 = {d_.roundC}; groups[1].n1 = {roundIdx_.size()}; groups[1].scalars = roundIdx_.size(); groups[1].c = &tableC1_;
+        groups[2].g1 = {d_.C}; groups[2].n1 = {finalIdx_.size()}; groups[2].scalars = finalIdx_.size(); groups[2].c = &tableC2_;
+        groups[3].g1 = {d_.H}; groups[3].n1 = {hr_.hi - hr_.lo}; groups[3].scalars = hr_.hi - hr_.lo; groups[3].c = &tableH_;
         planWindowTables(d_.ctx, groups);
     }
 
     const ZkeyHeader& header() const { return hdr_; }
 
-    void prove(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub) override {
-        auto t0 = std::chrono::steady_clock::now();
+    // ---- phases (a sharded proof calls them one by one, see include/prover.h; prove() below strings them together) ----
+    void loadWitness(const void* wtns, unsigned long long wtnsSize) override {
         BinFile f(wtns, wtnsSize, "wtns", 2);
         WtnsHeader wh = loadWtnsHeader(f);
         if (hdr_.nVars != wh.nVars)
@@ -599,41 +621,42 @@ public:
             memcpy(v.data(), f.sectionData(id), v.size() * 4);
             return v;
         };
-        std::vector<uint32_t> chunks = u32Section(3), freq = u32Section(4), wIdx = u32Section(5), pIdx = u32Section(6);
-        if (wIdx.size() != pIdx.size()) throw std::range_error("uwtns: wtns_indxs and push_indxs differ in length");
-
-        // ULTRAGROTH_TRACE=1: host wall-clock per phase on stderr (where the non-MSM, non-FFT time of a proof goes)
-        const bool trace = getenv("ULTRAGROTH_TRACE") && atoi(getenv("ULTRAGROTH_TRACE")) != 0;
-        auto tPhase = std::chrono::steady_clock::now();
-        auto mark = [&](const char* what) {
-            if (!trace) return;
-            ug_ctx_sync(d_.ctx);
-            auto now = std::chrono::steady_clock::now();
-            fprintf(stderr, "[ultragroth] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - tPhase).count());
-            tPhase = now;
-        };
+        chunks_ = u32Section(3); freq_ = u32Section(4); wIdx_ = u32Section(5); pIdx_ = u32Section(6);
+        if (wIdx_.size() != pIdx_.size()) throw std::range_error("uwtns: wtns_indxs and push_indxs differ in length");
+        publicPart_.assign(signals0, signals0 + ((size_t)hdr_.nPublic + 1) * 32);
         mark("parse uwtns");
         ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1));
-        // ---- round 1: commitment to the round witnesses (ultra_groth.cpp:415-419, execute_round :161-184)
         ugCheck(ug_dvec_upload(d_.w, signals0, M));
         mark("witness upload");
+        witnessLoaded_ = true; committed_ = false; haveRoundScalar_ = false;
+    }
+
+    // round 1: this rank's part of the commitment to the round witnesses (ultra_groth.cpp:415-419, execute_round :161-184)
+    void roundCommit(uint8_t* out64) override {
+        if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
         ugCheck(ug_dvec_gather_index(d_.aux, d_.w, d_.roundIdx));
         mark("round gather");
         buildSchedule(d_.saux, d_.aux, 0, roundIdx_.size(), tableC1_);
-        uint8_t commitRec[64];
-        ugCheck(ug_msm_g1(d_.ctx, d_.roundC, d_.saux, 0, commitRec));
+        ugCheck(ug_msm_g1(d_.ctx, d_.roundC, d_.saux, 0, out64));
         mark("round MSM");
+    }
+    // on ONE rank, with the sum of all parts: draws the round randomness (:173) and blinds the commitment (:176)
+    void roundFinish(const uint8_t* total64, uint8_t* commit64) override {
         uint8_t rk[32];
-        drawBlinding(rk);                                                                   // :173
-        u32 rkw[8];
-        memcpy(rkw, rk, 32);
-        G1XYZZ commit = xyzz_add(g1FromRecord(commitRec), xyzz_mul_scalar(g1FromRecord(hdr_.delta1), rkw, 256));   // :176 final_delta1
-        g1ToRecord(commitRec, commit);
-
-        // ---- Fiat-Shamir challenge (derive_challenge :33-58): keccak256(x_BE32 || y_BE32) as a big-endian integer
+        drawBlinding(rk);
+        memcpy(rkw_, rk, 32);
+        haveRoundScalar_ = true;
+        G1XYZZ commit = xyzz_add(g1FromRecord(total64), xyzz_mul_scalar(g1FromRecord(hdr_.delta1), rkw_, 256));   // final_delta1
+        g1ToRecord(commit64, commit);
+    }
+    // on EVERY rank, with the blinded commitment: Fiat-Shamir challenge and the lookup signals it determines
+    void applyCommitment(const uint8_t* commit64) override {
+        if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
+        memcpy(commitRec_, commit64, 64);
+        // derive_challenge (:33-58): keccak256(x_BE32 || y_BE32) as a big-endian integer
         u32 cx[8], cy[8], w8[8];
-        memcpy(w8, commitRec, 32); to_normal(cx, from_mont256<FqParams>(w8));
-        memcpy(w8, commitRec + 32, 32); to_normal(cy, from_mont256<FqParams>(w8));
+        memcpy(w8, commitRec_, 32); to_normal(cx, from_mont256<FqParams>(w8));
+        memcpy(w8, commitRec_ + 32, 32); to_normal(cy, from_mont256<FqParams>(w8));
         uint8_t buf[64], ch[32];
         for (int i = 0; i < 32; i++) {
             buf[i] = (uint8_t)(cx[7 - (i >> 2)] >> (24 - 8 * (i & 3)));
@@ -643,56 +666,111 @@ public:
         u32 chw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int i = 0; i < 32; i++) chw[7 - (i >> 2)] |= (u32)ch[i] << (24 - 8 * (i & 3));
         Fr rand = from_normal<FrParams>(chw);              // reduces values >= r, like fromMpz + toMontgomery
-
-        // ---- lookup signals (compute_lookup :62-106): the new values are written into the device copy of the witness
-        // (last write wins, as in the reference's loop)
         mark("commit + challenge");
-        std::vector<uint8_t> publicPart(signals0, signals0 + ((size_t)hdr_.nPublic + 1) * 32);
-        applyLookup(publicPart, chunks, freq, wIdx, pIdx, rand);
+        // compute_lookup (:62-106): the new values are written into the device copy of the witness (last write wins)
+        applyLookup(publicPart_, chunks_, freq_, wIdx_, pIdx_, rand);
         mark("lookup");
-
-        // ---- final round (execute_final_round :187-399)
-        // r and s (:345-346) are drawn here, still after the round randomness as in the reference, so that the multiples
-        // of the deltas that need only the blinding scalars are formed on host threads beside the device work
-        uint8_t r[32], s[32];
-        drawBlinding(r); drawBlinding(s);
-        struct HostTerms { BlindingTerms b; G1XYZZ roundTerm; };
-        auto terms = std::async(std::launch::async, [&] {
-            HostTerms t;
-            auto fr = std::async(std::launch::async, [&] { return xyzz_mul_scalar(g1FromRecord(hdr_.roundDelta1), rkw, 256); });   // :386-388
-            t.b = blindingTerms(hdr_, r, s);
-            t.roundTerm = fr.get();
-            return t;
-        });
-        // (a std::async future joins in its destructor, and r, s, rkw are declared before it: they outlive the threads)
-        buildSchedule(d_.sw, d_.w, 0, M, tableW_);
-        uint8_t sums[UG_GROTH16_PARTIALS_SIZE];
+        committed_ = true;
+    }
+    // final round (execute_final_round :187-399), this rank's slices: A | B1 | B2 | C2 records of the partials block
+    void runWitnessMsm(uint8_t* partials, bool = true) override {
+        if (!committed_) throw std::invalid_argument("the round commitment has not been applied");
+        memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
+        buildSchedule(d_.sw, d_.w, wr_.lo, wr_.hi - wr_.lo, tableW_);
         {                                                                                   // MSM1-3 :201,214,227
             const ug_bases* sets[3] = {d_.A, d_.B1, d_.B2};
-            void* outs[3] = {sums, sums + 64, sums + 128};
+            void* outs[3] = {partials, partials + 64, partials + 128};
             ugCheck(ug_msm_batch(d_.ctx, 3, sets, d_.sw, nullptr, outs));
         }
         mark("A, B1, B2 MSMs");
         ugCheck(ug_dvec_gather_index(d_.aux, d_.w, d_.finalIdx));                           // :439-445
         mark("final gather");
         buildSchedule(d_.saux, d_.aux, 0, finalIdx_.size(), tableC2_);
-        ugCheck(ug_msm_g1(d_.ctx, d_.C, d_.saux, 0, sums + 256));                           // MSM4 :234
+        ugCheck(ug_msm_g1(d_.ctx, d_.C, d_.saux, 0, partials + 256));                       // MSM4 :234
         mark("C MSM");
-        ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                           // FFT block :243-320
-        mark("H polynomial");
-        buildSchedule(d_.sh, d_.h, 0, hdr_.domainSize, tableH_);
-        ugCheck(ug_msm_g1(d_.ctx, d_.H, d_.sh, 0, sums + 320));                             // MSM5 :322
+    }
+    void hpolyChain(int which, void* deviceOut) override {
+        if (!committed_) throw std::invalid_argument("the round commitment has not been applied");
+        ug_dvec* v = nullptr;
+        ugCheck(ug_dvec_wrap(d_.ctx, deviceOut, hdr_.domainSize, &v));
+        int rc = ug_hpoly_chain(d_.hp, d_.w, which, v);
+        ug_dvec_destroy(v);
+        ugCheck(rc);
+    }
+    void hpolyCombine(void* da, void* db, void* dc) override {
+        uint64_t cnt = hr_.hi - hr_.lo;
+        ug_dvec *a = nullptr, *b = nullptr, *c = nullptr;
+        ugCheck(ug_dvec_wrap(d_.ctx, da, cnt, &a));
+        ugCheck(ug_dvec_wrap(d_.ctx, db, cnt, &b));
+        ugCheck(ug_dvec_wrap(d_.ctx, dc, cnt, &c));
+        int rc = ug_hpoly_combine(d_.hp, a, b, c, hr_.lo, cnt, d_.h);
+        ug_dvec_destroy(a); ug_dvec_destroy(b); ug_dvec_destroy(c);
+        ugCheck(rc);
+    }
+    void hRange(unsigned long long* first, unsigned long long* count, unsigned long long* domain) const override {
+        if (first) *first = hr_.lo;
+        if (count) *count = hr_.hi - hr_.lo;
+        if (domain) *domain = hdr_.domainSize;
+    }
+    // MSM5 (:322) on this rank's slice of h (which must be in d_.h); only the H record of partials is written
+    void runHMsm(uint8_t* partials) override {
+        memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
+        buildSchedule(d_.sh, d_.h, hr_.lo, hr_.hi - hr_.lo, tableH_);
+        ugCheck(ug_msm_g1(d_.ctx, d_.H, d_.sh, 0, partials + 320));
         mark("H MSM");
         ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
+    }
+    // on the rank that ran roundFinish, with the summed partials: r and s (:345-346), the blinded proof, the JSON texts
+    void finish(const uint8_t* sums, std::string& proof, std::string& pub) override {
+        uint8_t r[32], s[32];
+        drawBlinding(r); drawBlinding(s);
+        HostTerms t = hostTerms(r, s);
+        finishWith(sums, r, s, t, proof, pub);
+    }
 
-        HostTerms ht = terms.get();
+    struct HostTerms { BlindingTerms b; G1XYZZ roundTerm; };
+    HostTerms hostTerms(const uint8_t r[32], const uint8_t s[32]) {
+        if (!haveRoundScalar_) throw std::invalid_argument("finish on a rank that did not close the round");
+        HostTerms t;
+        auto fr = std::async(std::launch::async, [&] { return xyzz_mul_scalar(g1FromRecord(hdr_.roundDelta1), rkw_, 256); });   // :386-388
+        t.b = blindingTerms(hdr_, r, s);
+        t.roundTerm = fr.get();
+        return t;
+    }
+    void finishWith(const uint8_t* sums, const uint8_t r[32], const uint8_t s[32], const HostTerms& t, std::string& proof,
+                    std::string& pub) {
         uint8_t A[64], B[128], C[64];
-        blind(A, B, C, sums, sums + 64, sums + 128, sums + 256, sums + 320, hdr_, r, s, ht.b, &ht.roundTerm);
+        blind(A, B, C, sums, sums + 64, sums + 128, sums + 256, sums + 320, hdr_, r, s, t.b, &t.roundTerm);
         // keys pi_a, pi_b, pi_f, pi_r, protocol (src/ultra_groth.cpp:476-513)
-        proof = "{\"pi_a\":" + g1Json(A) + ",\"pi_b\":" + g2Json(B) + ",\"pi_f\":" + g1Json(C) + ",\"pi_r\":" + g1Json(commitRec) +
+        proof = "{\"pi_a\":" + g1Json(A) + ",\"pi_b\":" + g2Json(B) + ",\"pi_f\":" + g1Json(C) + ",\"pi_r\":" + g1Json(commitRec_) +
                 ",\"protocol\":\"ultragroth\"}";
-        pub = publicJson(publicPart.data(), hdr_.nPublic, hdr_.randIndx);                   // prover.cpp:89-105
+        pub = publicJson(publicPart_.data(), hdr_.nPublic, hdr_.randIndx);                  // prover.cpp:89-105
         mark("blinding + JSON");
+    }
+
+    void prove(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub) override {
+        auto t0 = std::chrono::steady_clock::now();
+        // ULTRAGROTH_TRACE=1: host wall-clock per phase on stderr (where the non-MSM, non-FFT time of a proof goes)
+        trace_ = getenv("ULTRAGROTH_TRACE") && atoi(getenv("ULTRAGROTH_TRACE")) != 0;
+        tPhase_ = std::chrono::steady_clock::now();
+        loadWitness(wtns, wtnsSize);
+        uint8_t part[64], commit[64];
+        roundCommit(part);
+        roundFinish(part, commit);
+        applyCommitment(commit);
+        // r and s (:345-346) are drawn here, still after the round randomness as in the reference, so that the multiples
+        // of the deltas that need only the blinding scalars are formed on host threads beside the device work
+        uint8_t r[32], s[32];
+        drawBlinding(r); drawBlinding(s);
+        auto terms = std::async(std::launch::async, [&] { return hostTerms(r, s); });
+        // (a std::async future joins in its destructor, and r, s are declared before it: they outlive the threads)
+        uint8_t sums[UG_GROTH16_PARTIALS_SIZE], hpart[UG_GROTH16_PARTIALS_SIZE];
+        runWitnessMsm(sums);
+        ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                           // FFT block :243-320
+        mark("H polynomial");
+        runHMsm(hpart);
+        memcpy(sums + 320, hpart + 320, 64);
+        finishWith(sums, r, s, terms.get(), proof, pub);
         totalMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 
@@ -748,7 +826,21 @@ private:
 
     ZkeyHeader hdr_;
     std::vector<uint8_t> vk_;
-    std::vector<uint32_t> roundIdx_, finalIdx_;
+    void mark(const char* what) {
+        if (!trace_) return;
+        ug_ctx_sync(d_.ctx);
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ultragroth] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - tPhase_).count());
+        tPhase_ = now;
+    }
+    std::vector<uint32_t> roundIdx_, finalIdx_;                    // this rank's slices of the zkey's two index lists
+    std::vector<uint32_t> chunks_, freq_, wIdx_, pIdx_;            // uwtns sections 3-6 of the loaded witness
+    std::vector<uint8_t> publicPart_;                              // signals 0..nPublic, patched by the lookup writes
+    Range wr_{0, 0}, hr_{0, 0};
+    uint8_t commitRec_[64] = {0};
+    u32 rkw_[8] = {0};
+    bool witnessLoaded_ = false, committed_ = false, haveRoundScalar_ = false, trace_ = false;
+    std::chrono::steady_clock::time_point tPhase_;
     int tableW_ = 0, tableC1_ = 0, tableC2_ = 0, tableH_ = 0;      // fixed-base table widths per schedule group (0: classic)
     DeviceProver d_;
     double msmMs_ = 0, fftMs_ = 0, totalMs_ = 0;
@@ -962,44 +1054,79 @@ int ug_groth16_prover_load_witness(void* prover_object, const void* wtns_buffer,
     API_TRY
     if (prover_object == NULL) throw std::invalid_argument("Null prover object");
     if (wtns_buffer == NULL) throw std::invalid_argument("Null witness buffer");
-    static_cast<Groth16Prover*>(static_cast<ProverBase*>(prover_object))->loadWitness(wtns_buffer, wtns_size);
+    static_cast<ProverBase*>(prover_object)->loadWitness(wtns_buffer, wtns_size);
     API_CATCH
 }
 int ug_groth16_prover_run(void* prover_object, void* partials_out, char* error_msg, unsigned long long error_msg_maxsize) {
     API_TRY
     if (prover_object == NULL) throw std::invalid_argument("Null prover object");
     if (partials_out == NULL) throw std::invalid_argument("Null partials buffer");
-    static_cast<Groth16Prover*>(static_cast<ProverBase*>(prover_object))->run(static_cast<uint8_t*>(partials_out));
+    static_cast<ProverBase*>(prover_object)->run(static_cast<uint8_t*>(partials_out));
     API_CATCH
 }
 int ug_groth16_prover_run_witness_msm(void* prover_object, void* partials_out, char* error_msg, unsigned long long error_msg_maxsize) {
     API_TRY
     if (prover_object == NULL || partials_out == NULL) throw std::invalid_argument("Null argument");
-    static_cast<Groth16Prover*>(static_cast<ProverBase*>(prover_object))->runWitnessMsm(static_cast<uint8_t*>(partials_out));
+    static_cast<ProverBase*>(prover_object)->runWitnessMsm(static_cast<uint8_t*>(partials_out));
     API_CATCH
 }
 int ug_groth16_prover_run_h_msm(void* prover_object, void* partials_out, char* error_msg, unsigned long long error_msg_maxsize) {
     API_TRY
     if (prover_object == NULL || partials_out == NULL) throw std::invalid_argument("Null argument");
-    static_cast<Groth16Prover*>(static_cast<ProverBase*>(prover_object))->runHMsm(static_cast<uint8_t*>(partials_out));
+    static_cast<ProverBase*>(prover_object)->runHMsm(static_cast<uint8_t*>(partials_out));
     API_CATCH
 }
 int ug_groth16_prover_hpoly_chain(void* prover_object, int which, void* device_out, char* error_msg, unsigned long long error_msg_maxsize) {
     API_TRY
     if (prover_object == NULL || device_out == NULL) throw std::invalid_argument("Null argument");
-    static_cast<Groth16Prover*>(static_cast<ProverBase*>(prover_object))->hpolyChain(which, device_out);
+    static_cast<ProverBase*>(prover_object)->hpolyChain(which, device_out);
     API_CATCH
 }
 int ug_groth16_prover_hpoly_combine(void* prover_object, void* device_a, void* device_b, void* device_c, char* error_msg,
                                     unsigned long long error_msg_maxsize) {
     API_TRY
     if (prover_object == NULL || !device_a || !device_b || !device_c) throw std::invalid_argument("Null argument");
-    static_cast<Groth16Prover*>(static_cast<ProverBase*>(prover_object))->hpolyCombine(device_a, device_b, device_c);
+    static_cast<ProverBase*>(prover_object)->hpolyCombine(device_a, device_b, device_c);
     API_CATCH
 }
 int ug_groth16_prover_h_range(void* prover_object, unsigned long long* first, unsigned long long* count, unsigned long long* domain_size) {
     if (prover_object == NULL) return PROVER_ERROR;
-    static_cast<Groth16Prover*>(static_cast<ProverBase*>(prover_object))->hRange(first, count, domain_size);
+    static_cast<ProverBase*>(prover_object)->hRange(first, count, domain_size);
+    return PROVER_OK;
+}
+int ug_ultra_groth_prover_create_sharded(void** prover_object, const void* zkey_buffer, unsigned long long zkey_size, int device,
+                                         int shard_rank, int shard_count, char* error_msg, unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL) throw std::invalid_argument("Null prover object");
+    if (zkey_buffer == NULL) throw std::invalid_argument("Null zkey buffer");
+    *prover_object = static_cast<ProverBase*>(new UltraGrothProver(zkey_buffer, zkey_size, device, shard_rank, shard_count));
+    API_CATCH
+}
+int ug_ultra_groth_prover_round_commit(void* prover_object, void* commit_part_out, char* error_msg, unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL || commit_part_out == NULL) throw std::invalid_argument("Null argument");
+    static_cast<ProverBase*>(prover_object)->roundCommit(static_cast<uint8_t*>(commit_part_out));
+    API_CATCH
+}
+int ug_ultra_groth_prover_round_finish(void* prover_object, const void* commit_sum, void* commitment_out, char* error_msg,
+                                       unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL || commit_sum == NULL || commitment_out == NULL) throw std::invalid_argument("Null argument");
+    static_cast<ProverBase*>(prover_object)->roundFinish(static_cast<const uint8_t*>(commit_sum), static_cast<uint8_t*>(commitment_out));
+    API_CATCH
+}
+int ug_ultra_groth_prover_apply_commitment(void* prover_object, const void* commitment, char* error_msg,
+                                           unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL || commitment == NULL) throw std::invalid_argument("Null argument");
+    static_cast<ProverBase*>(prover_object)->applyCommitment(static_cast<const uint8_t*>(commitment));
+    API_CATCH
+}
+int ug_g1_record_add(void* acc, const void* other) {
+    try {
+        uint8_t* a = static_cast<uint8_t*>(acc);
+        g1ToRecord(a, xyzz_add(g1FromRecord(a), g1FromRecord(static_cast<const uint8_t*>(other))));
+    } catch (...) { return PROVER_ERROR; }
     return PROVER_OK;
 }
 int ug_groth16_partials_add(void* partials_acc, const void* partials_other) {
@@ -1018,7 +1145,7 @@ int ug_groth16_prover_finish(void* prover_object, const void* partials_sum, char
     API_TRY
     if (prover_object == NULL) throw std::invalid_argument("Null prover object");
     if (!partials_sum || !proof_buffer || !proof_size || !public_buffer || !public_size) throw std::invalid_argument("Null buffer");
-    Groth16Prover* prover = static_cast<Groth16Prover*>(static_cast<ProverBase*>(prover_object));
+    ProverBase* prover = static_cast<ProverBase*>(prover_object);
     checkBufferSizes(prover->proofBufferMinSize(), proof_size, prover->publicBufferMinSize(), public_size, "Minimum");
     std::string stringProof, stringPublic;
     prover->finish(static_cast<const uint8_t*>(partials_sum), stringProof, stringPublic);
