@@ -66,6 +66,55 @@ def test_sharded_partials_sum_to_the_unsharded_result(world, zkey, wtns):
     assert total == raw
 
 
+def _commit_worker(rank, world, port, q):
+    """the UltraGroth round-commitment exchange of bench.py --ultra: 64-byte parts all-gathered and added on every rank,
+    the closing rank's record broadcast to the others"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle as O
+    import ultragroth_amd as ug
+    zkey = open(os.path.join(ROOT, "tests", "golden", "circuit_final.zkey"), "rb").read()
+    sec = lambda sid: zkey[O.section(zkey, "zkey", sid)[0]: sum(O.section(zkey, "zkey", sid))]
+    pts = sec(9)
+    n = 64
+    lo, hi = n * rank // world, n * (rank + 1) // world
+    sc = b"".join(O.to_le(1000003 * (i + 1)) for i in range(n))
+    part = O.g1_msm(pts[64 * lo:64 * hi], sc[32 * lo:32 * hi], hi - lo) if hi > lo else bytes(64)
+    mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)
+    allp = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allp, mine)
+    total = bytes(64)
+    for other in allp:
+        total = ug.ShardedUltraGrothProver.add_records(total, bytes(other.numpy()))
+    closing = torch.frombuffer(bytearray(total if rank == 0 else bytes(64)), dtype=torch.uint8)
+    dist.broadcast(closing, src=0)
+    assert bytes(closing.numpy()) == total                      # every rank derived the same sum on its own
+    if rank == world - 1:
+        q.put(total)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_round_commitment_exchange(zkey):
+    import oracle as O
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_commit_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    total = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    pts = zkey[O.section(zkey, "zkey", 9)[0]: sum(O.section(zkey, "zkey", 9))]
+    sc = b"".join(O.to_le(1000003 * (i + 1)) for i in range(64))
+    assert total == O.g1_msm(pts[:64 * 64], sc, 64)
+
+
 def test_bench_witness_slices_tile_the_witness():
     """bench.py gives the ranks that also run an NTT chain smaller witness slices: for every world size the slices are
     contiguous, ordered, cover [0, nVars) exactly, and the chain-carrying ranks get the smaller ones"""
