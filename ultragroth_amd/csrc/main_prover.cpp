@@ -1,56 +1,62 @@
 // main_prover.cpp -- `prover <circuit.zkey> <witness.wtns> <proof.json> <public.json>`
-// Same command line, exit codes and messages as the reference CLIs (src/main_prover.cpp:17-85,
-// src/main_prover_ultra_groth.cpp:17-85), on top of include/prover.h. Built twice:
-// -DUG_ULTRA selects the UltraGroth entry points.
+// Command line, exit status and stderr texts of the reference CLIs (src/main_prover.cpp:17-85 and
+// src/main_prover_ultra_groth.cpp:17-85), on top of include/prover.h. Built twice: -DUG_ULTRA selects the UltraGroth calls.
+#include <cstdio>
 #include <cstdlib>
-#include <fstream>
-#include <iostream>
+#include <cstring>
 #include <stdexcept>
 #include <string>
-#include <vector>
 #include "host_util.hpp"
 #include "../../include/prover.h"
 
+namespace {
+
+struct Api {                         // the three one-shot calls of one protocol
+    int (*publicSize)(const void*, unsigned long long, unsigned long long*, char*, unsigned long long);
+    void (*proofSize)(unsigned long long*);
+    int (*prove)(const void*, unsigned long long, const void*, unsigned long long, char*, unsigned long long*, char*,
+                 unsigned long long*, char*, unsigned long long);
+};
 #ifdef UG_ULTRA
-#define PUBLIC_SIZE ultra_groth_public_size_for_zkey_buf
-#define PROOF_SIZE ultra_groth_proof_size
-#define PROVE ultra_groth_prover
+const Api kApi = {ultra_groth_public_size_for_zkey_buf, ultra_groth_proof_size, ultra_groth_prover};
 #else
-#define PUBLIC_SIZE groth16_public_size_for_zkey_buf
-#define PROOF_SIZE groth16_proof_size
-#define PROVE groth16_prover
+const Api kApi = {groth16_public_size_for_zkey_buf, groth16_proof_size, groth16_prover};
 #endif
 
-// the buffers are NUL-padded by strncpy: the file is the text before the first NUL
-static void truncateAtNul(std::vector<char>& v) {
-    for (size_t i = 0; i < v.size(); i++)
-        if (v[i] == 0) { v.resize(i); break; }
+// the library pads its text buffers with NULs (strncpy): a file gets the text up to the first one
+void writeText(const char* path, const std::string& buffer) {
+    FILE* f = fopen(path, "wb");
+    if (!f) throw std::runtime_error(std::string("cannot write ") + path);
+    fwrite(buffer.data(), 1, strnlen(buffer.data(), buffer.size()), f);
+    fclose(f);
 }
+
+void run(char** argv) {
+    ughost::FileMap zkey(argv[1]), wtns(argv[2]);
+    char message[1024] = {0};
+    unsigned long long publicBytes = 0, proofBytes = 0;
+    if (kApi.publicSize(zkey.data(), zkey.size(), &publicBytes, message, sizeof(message) - 1) != PROVER_OK)
+        throw std::runtime_error(message);
+    kApi.proofSize(&proofBytes);
+    std::string proof(proofBytes, '\0'), pub(publicBytes, '\0');
+    if (kApi.prove(zkey.data(), zkey.size(), wtns.data(), wtns.size(), &proof[0], &proofBytes, &pub[0], &publicBytes, message,
+                   sizeof(message) - 1) != PROVER_OK)
+        throw std::runtime_error(message);
+    writeText(argv[3], proof);
+    writeText(argv[4], pub);
+}
+
+}  // namespace
 
 int main(int argc, char** argv) {
     if (argc != 5) {
-        std::cerr << "Invalid number of parameters" << std::endl;
-        std::cerr << "Usage: prover <circuit.zkey> <witness.wtns> <proof.json> <public.json>" << std::endl;
+        fputs("Invalid number of parameters\nUsage: prover <circuit.zkey> <witness.wtns> <proof.json> <public.json>\n", stderr);
         return EXIT_FAILURE;
     }
     try {
-        ughost::FileMap zkey(argv[1]);
-        ughost::FileMap wtns(argv[2]);
-        unsigned long long publicSize = 0, proofSize = 0;
-        char errorMsg[1024] = {0};
-        if (PUBLIC_SIZE(zkey.data(), zkey.size(), &publicSize, errorMsg, sizeof(errorMsg) - 1) != PROVER_OK)
-            throw std::runtime_error(errorMsg);
-        PROOF_SIZE(&proofSize);
-        std::vector<char> publicBuffer(publicSize), proofBuffer(proofSize);
-        if (PROVE(zkey.data(), zkey.size(), wtns.data(), wtns.size(), proofBuffer.data(), &proofSize, publicBuffer.data(),
-                  &publicSize, errorMsg, sizeof(errorMsg) - 1) != PROVER_OK)
-            throw std::runtime_error(errorMsg);
-        truncateAtNul(proofBuffer);
-        truncateAtNul(publicBuffer);
-        std::ofstream(argv[3]).write(proofBuffer.data(), (std::streamsize)proofBuffer.size());
-        std::ofstream(argv[4]).write(publicBuffer.data(), (std::streamsize)publicBuffer.size());
-    } catch (std::exception& e) {
-        std::cerr << "Error: " << e.what() << std::endl;
+        run(argv);
+    } catch (const std::exception& e) {
+        fprintf(stderr, "Error: %s\n", e.what());
         return EXIT_FAILURE;
     }
     return EXIT_SUCCESS;

@@ -1,49 +1,48 @@
 // main_verifier.cpp -- `verifier <verification_key.json> <inputs.json> <proof.json>`
-// Same command line, messages and exit codes as the reference CLIs (src/main_verifier.cpp:8-60,
+// Command line, stderr messages and exit codes of the reference CLIs (src/main_verifier.cpp:8-60 and
 // src/main_verifier_ultra_groth.cpp), on top of include/verifier.h. Built twice: -DUG_ULTRA selects ultra_groth_verify.
+#include <cstdio>
 #include <cstdlib>
-#include <iostream>
-#include <stdexcept>
+#include <exception>
 #include <string>
 #include "host_util.hpp"
 #include "../../include/verifier.h"
 
+namespace {
+
+typedef int (*VerifyFn)(const char*, const char*, const char*, char*, unsigned long);
 #ifdef UG_ULTRA
-#define VERIFY ultra_groth_verify
+const VerifyFn kVerify = ultra_groth_verify;
 #else
-#define VERIFY groth16_verify
+const VerifyFn kVerify = groth16_verify;
 #endif
 
-static std::string fileAsString(const char* path) {
+std::string slurp(const char* path) {
     ughost::FileMap m(path);
     return std::string(reinterpret_cast<const char*>(m.data()), m.size());
 }
 
+// what the reference prints for each outcome (all on stderr), and the exit status that goes with it
+int report(int outcome, const char* detail) {
+    switch (outcome) {
+        case VERIFIER_VALID_PROOF:   fputs("Result: Valid proof\n", stderr);   return EXIT_SUCCESS;
+        case VERIFIER_INVALID_PROOF: fputs("Result: Invalid proof\n", stderr); return EXIT_FAILURE;
+        default:                     fprintf(stderr, "Error: %s\n", detail);   return EXIT_FAILURE;
+    }
+}
+
+}  // namespace
+
 int main(int argc, char** argv) {
     if (argc != 4) {
-        std::cerr << "Invalid number of parameters:\n";
-        std::cerr << "Usage: verifier <verification_key.json> <inputs.json> <proof.json>\n";
+        fputs("Invalid number of parameters:\nUsage: verifier <verification_key.json> <inputs.json> <proof.json>\n", stderr);
         return EXIT_FAILURE;
     }
+    char detail[256] = {0};
     try {
-        const std::string proof = fileAsString(argv[3]);
-        const std::string inputs = fileAsString(argv[2]);
-        const std::string key = fileAsString(argv[1]);
-        char errorMessage[256] = {0};
-        const int error = VERIFY(proof.c_str(), inputs.c_str(), key.c_str(), errorMessage, sizeof(errorMessage) - 1);
-        if (error == VERIFIER_VALID_PROOF) {
-            std::cerr << "Result: Valid proof" << std::endl;
-            return EXIT_SUCCESS;
-        } else if (error == VERIFIER_INVALID_PROOF) {
-            std::cerr << "Result: Invalid proof" << std::endl;
-            return EXIT_FAILURE;
-        } else {
-            std::cerr << "Error: " << errorMessage << '\n';
-            return EXIT_FAILURE;
-        }
-    } catch (std::exception& e) {
-        std::cerr << "Error: " << e.what() << std::endl;
-        return EXIT_FAILURE;
+        const std::string key = slurp(argv[1]), inputs = slurp(argv[2]), proof = slurp(argv[3]);
+        return report(kVerify(proof.c_str(), inputs.c_str(), key.c_str(), detail, sizeof(detail) - 1), detail);
+    } catch (const std::exception& e) {
+        return report(VERIFIER_ERROR, e.what());
     }
-    return EXIT_FAILURE;
 }
