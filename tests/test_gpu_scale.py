@@ -516,3 +516,27 @@ def test_sharded_ultragroth_equals_oracle(device, world, split_h):
             raise ug.ProverError(1, "finish on a rank that did not close the round")
     for p in ranks:
         p.close()
+
+
+def test_created_prover_at_2_20_bit_exact(device):
+    """the largest size the oracle still proves in seconds: 2^20 constraints through a created prover (window tables of
+    the cost-model width, batched witness MSMs, three-pass NTTs), uniform scalars, twice with different witnesses"""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, wtns, info = synth.build_circuit(device, 20, mix="U", seed=0x5EED0500)
+    r, s = fixed_rs()
+    with ug.Groth16Prover(zkey) as p:
+        for k, w in enumerate((wtns, None)):
+            if w is None:                                           # second witness: the same values rotated by one limb
+                body = np.frombuffer(wtns, dtype=np.uint8).copy()
+                off = O.section(wtns, "wtns", 2)[0]
+                vals = body[off:].reshape(-1, 4, 8)
+                vals[1:, :3] = np.roll(vals[1:, :3], 1, axis=1)     # top limb untouched: values stay below r
+                w = body.tobytes()
+            ug.set_test_blinding(r + s)
+            try:
+                got = p.prove(w)
+            finally:
+                ug.set_test_blinding(b"")
+            exp = O.groth16_prove(zkey, w, int.from_bytes(r, "little"), int.from_bytes(s, "little"))
+            assert got == (exp[0], exp[1]), "witness %d" % k
