@@ -540,3 +540,27 @@ def test_created_prover_at_2_20_bit_exact(device):
                 ug.set_test_blinding(b"")
             exp = O.groth16_prove(zkey, w, int.from_bytes(r, "little"), int.from_bytes(s, "little"))
             assert got == (exp[0], exp[1]), "witness %d" % k
+
+
+def test_overlap_mode_is_bit_exact(device, monkeypatch):
+    """ULTRAGROTH_OVERLAP=1: the H branch (mat-vec, NTT chains, h schedule, H MSM) runs on a second stream from a second
+    host thread beside the witness MSMs; same proof, also with tables forced for a one-shot call (ULTRAGROTH_TABLES=2)"""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, wtns, info = synth.build_circuit(device, 15, mix="U", seed=0x5EED0600)
+    r, s = fixed_rs()
+    exp = O.groth16_prove(zkey, wtns, int.from_bytes(r, "little"), int.from_bytes(s, "little"))
+    monkeypatch.setenv("ULTRAGROTH_OVERLAP", "1")
+    with ug.Groth16Prover(zkey) as p:
+        for _ in range(3):
+            ug.set_test_blinding(r + s)
+            try:
+                assert p.prove(wtns) == (exp[0], exp[1])
+            finally:
+                ug.set_test_blinding(b"")
+    monkeypatch.setenv("ULTRAGROTH_TABLES", "2")
+    ug.set_test_blinding(r + s)
+    try:
+        assert ug.groth16_prover(zkey, wtns) == (exp[0], exp[1])
+    finally:
+        ug.set_test_blinding(b"")
