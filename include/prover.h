@@ -107,8 +107,10 @@ int ultra_groth_prover_zkey_file(const char *zkey_file_path,
 
 /* Test hook: the next draws of blinding randomness (31 bytes each: r then s for Groth16;
  * r_k, r, s for UltraGroth -- src/groth16.cpp:165-166, src/ultra_groth.cpp:173,345-346) are taken from
- * `bytes` instead of the operating system. n = 0 restores OS entropy. Process-wide. */
-void ug_test_set_blinding(const void *bytes, unsigned long long n);
+ * `bytes` (cyclically) instead of the operating system. n = 0 restores OS entropy. Process-wide, and it removes
+ * zero knowledge, so it is honoured only in a process whose environment holds ULTRAGROTH_TEST_HOOKS=1 when the
+ * library first looks (tests, bench.py --check, smoke()); otherwise it changes nothing and returns PROVER_ERROR. */
+int ug_test_set_blinding(const void *bytes, unsigned long long n);
 
 /* Device milliseconds of the last prove on this prover object: MSM part, H-polynomial ("FFT") part, and
  * host wall-clock milliseconds of the whole prove call. */

@@ -61,6 +61,7 @@ def _load():
     L.ugo_keccak256.argtypes = [vp, vp, C.c_uint64]
     L.ugo_derive_challenge.argtypes = [vp, vp]
     L.ugo_fr_dot_walk.argtypes = [vp, vp, C.c_uint64, C.c_uint64]
+    L.ugo_lookup_row.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp]
     return L
 
 
@@ -72,9 +73,13 @@ def _load_ref():
     if not os.path.exists(p):
         return None
     try:
-        return C.CDLL(p)
+        R = C.CDLL(p)
     except OSError:
         return None
+    if hasattr(R, "ref_lookup_row"):
+        R.ref_lookup_row.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
+        R.ref_derive_challenge.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    return R
 
 
 ref = _load_ref()
@@ -214,6 +219,35 @@ def fr_dot_walk(scalars, n, seed):
     buf = scalars if isinstance(scalars, (bytes, bytearray)) else (C.c_char * (n * 32)).from_buffer(scalars)
     lib.ugo_fr_dot_walk(out, buf, n, seed)
     return from_le(out.raw)
+
+
+def lookup_row(i, frequency, rand_mont):
+    """(inv2[i], prod[i]) of compute_lookup's table (src/ultra_groth.cpp:72-79) as plain integers; rand in Montgomery form"""
+    a, b = C.create_string_buffer(32), C.create_string_buffer(32)
+    lib.ugo_lookup_row(a, b, i, frequency, to_le(rand_mont))
+    return from_le(a.raw), from_le(b.raw)
+
+
+def ref_lookup_row(i, frequency, rand_mont):
+    """the same row computed by the reference's own RawFr calls (oracle/ref_shim.cpp)"""
+    a, b = C.create_string_buffer(32), C.create_string_buffer(32)
+    ref.ref_lookup_row(a, b, i, frequency, to_le(rand_mont))
+    return from_le(a.raw), from_le(b.raw)
+
+
+def derive_challenge(commit_record):
+    """derive_challenge (src/ultra_groth.cpp:33-58) of a 64-byte affine G1 record; plain integer < r"""
+    out = C.create_string_buffer(32)
+    lib.ugo_derive_challenge(out, bytes(commit_record))
+    return from_le(out.raw)
+
+
+def ref_derive_challenge(commit_record):
+    """the same through the reference's RawFq::toMpz / FIPS202_KECCAK_256 / RawFr::fromMpz; Montgomery -> plain here"""
+    out = C.create_string_buffer(32)
+    rec = bytes(commit_record)
+    ref.ref_derive_challenge(out, rec[:32], rec[32:64])
+    return mont_decode(out.raw, R_MOD)
 
 
 def keccak256(data):

@@ -672,6 +672,34 @@ void ugo_derive_challenge(uint8_t out_normal[32], const uint8_t commit_aff[64]) 
     derive_challenge(&m, &c); fe_from_mont(&nrm, &m, &UGO_FR); memcpy(out_normal, &nrm, 32);
 }
 
+/* RawFr::set(int) (build/fr.cpp:209-223): the Montgomery form of a C int, negative values taken as value + r. */
+static void fr_set_int(fe *r, int32_t value) {
+    fe m = {{(u64)(value < 0 ? -(int64_t)value : (int64_t)value), 0, 0, 0}};
+    fe_to_mont(&m, &m, &UGO_FR);
+    if (value < 0) fe_neg(&m, &m, &UGO_FR);
+    *r = m;
+}
+/* One row of the lookup table, src/ultra_groth.cpp:72-79:
+ *     sum = field.add(i, rand); inv(inv, sum); prod = field.mul(frequencies[i], inv);
+ * `i` (an int loop variable) and `frequencies[i]` (a uint32_t) both bind to the (int, Element) overloads
+ * (build/fr.hpp:249-251), so each goes through RawFr::set(int): an unsigned frequency >= 2^31 converts to the
+ * negative int freq - 2^32 and enters the product as freq - 2^32 + r. Outputs are normal form (copy_digits :24-31). */
+static void lookup_row(fe *inv2_out, fe *prod_out, uint32_t i, uint32_t frequency, const fe *rand_m) {
+    fe im, sum, inv, fm, pr;
+    fr_set_int(&im, (int32_t)i);
+    r_add(&sum, &im, rand_m);
+    fe_inv(&inv, &sum, &UGO_FR);              /* inverse of 0 is 0 (mpz_invert leaves 0) */
+    fe_from_mont(inv2_out, &inv, &UGO_FR);
+    fr_set_int(&fm, (int32_t)frequency);
+    r_mul(&pr, &fm, &inv);
+    fe_from_mont(prod_out, &pr, &UGO_FR);
+}
+void ugo_lookup_row(uint64_t inv2_out[4], uint64_t prod_out[4], uint32_t i, uint32_t frequency, const uint64_t rand_mont[4]) {
+    fe a, b, rm; memcpy(&rm, rand_mont, 32);
+    lookup_row(&a, &b, i, frequency, &rm);
+    memcpy(inv2_out, &a, 32); memcpy(prod_out, &b, 32);
+}
+
 /* src/ultra_groth.cpp:62-106. signals: nVars normal-form values, modified in place. */
 static void compute_lookup(uint8_t *signals, const uint32_t *chunks, uint32_t chunks_total,
                            const uint32_t *freq, uint32_t lookup_size,
@@ -681,16 +709,7 @@ static void compute_lookup(uint8_t *signals, const uint32_t *chunks, uint32_t ch
     fe *push = (fe *)malloc(total * sizeof(fe));
     fe *inv1 = push + 1, *inv2 = inv1 + chunks_total, *prod = inv2 + lookup_size;
     fe_from_mont(&push[0], rand_m, &UGO_FR);
-    for (uint32_t i = 0; i < lookup_size; i++) {
-        fe im = {{i, 0, 0, 0}}, sum, inv, fm = {{freq[i], 0, 0, 0}}, pr;
-        fe_to_mont(&im, &im, &UGO_FR);
-        r_add(&sum, &im, rand_m);
-        fe_inv(&inv, &sum, &UGO_FR);          /* inverse of 0 is 0 (mpz_invert leaves 0) */
-        fe_from_mont(&inv2[i], &inv, &UGO_FR);
-        fe_to_mont(&fm, &fm, &UGO_FR);
-        r_mul(&pr, &fm, &inv);
-        fe_from_mont(&prod[i], &pr, &UGO_FR);
-    }
+    for (uint32_t i = 0; i < lookup_size; i++) lookup_row(&inv2[i], &prod[i], i, freq[i], rand_m);
     for (uint32_t i = 0; i < chunks_total; i++) inv1[i] = inv2[chunks[i]];
     for (uint32_t i = 0; i < n_idx; i++) memcpy(signals + (size_t)wtns_idx[i] * 32, &push[push_idx[i]], 32);
     free(push);

@@ -52,6 +52,7 @@ int  ugo_ultra_groth_prove(const uint8_t *zkey, uint64_t zkey_size, const uint8_
 
 void ugo_keccak256(uint8_t out[32], const uint8_t *in, uint64_t len);
 void ugo_derive_challenge(uint8_t out_normal[32], const uint8_t commit_aff[64]);
+void ugo_lookup_row(uint64_t inv2_out[4], uint64_t prod_out[4], uint32_t i, uint32_t frequency, const uint64_t rand_mont[4]);
 int  ugo_num_threads(void);
 void ugo_set_num_threads(int n);
 void ugo_fr_dot_walk(uint64_t out[4], const uint8_t *scalars, uint64_t n, uint64_t seed);

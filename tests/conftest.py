@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# deterministic blinding (ug_test_set_blinding) exists only in processes that ask for it before the library loads
+os.environ["ULTRAGROTH_TEST_HOOKS"] = "1"
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

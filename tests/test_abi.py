@@ -87,6 +87,34 @@ def test_error_strings_match_the_reference(lib, zkey, wtns):
     assert msg.raw[:4] == b"Null" and msg.raw[4:] == b"\xff" * 4
 
 
+def test_section_size_cannot_wrap(lib, zkey):
+    """a section size near 2^64 must not wrap the cursor back into the buffer (the reference adds before it checks,
+    src/binfile_utils.cpp:60-66; here the check comes first)"""
+    import struct
+    for huge in ((1 << 64) - 1, (1 << 64) - 12, (1 << 64) - 24 - 10, (1 << 63) + 1):
+        bad = b"zkey" + struct.pack("<II", 1, 2) + struct.pack("<IQ", 1, 4) + struct.pack("<I", 1) + struct.pack("<IQ", 2, huge)
+        bad += bytes(64)
+        with pytest.raises(ug.ProverError) as e:
+            ug.groth16_public_size_for_zkey_buf(bad)
+        assert e.value.message.startswith("Section #1 is invalid")
+    # a size that ends exactly at the end of the buffer is fine
+    ok = b"zkey" + struct.pack("<II", 1, 2) + struct.pack("<IQ", 1, 4) + struct.pack("<I", 1) + struct.pack("<IQ", 2, 64) + bytes(64)
+    assert ug.groth16_public_size_for_zkey_buf(ok) == 4            # (an all-zero header: nPublic = 0)
+
+
+def test_blinding_hook_is_gated():
+    """ug_test_set_blinding changes nothing unless the process was started with ULTRAGROTH_TEST_HOOKS=1"""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys; sys.path.insert(0, %r); import ultragroth_amd as ug; L = ug.load(); "
+            "print(L.ug_test_set_blinding(b'x' * 62, 62), L.ug_test_set_blinding(None, 0))" % ROOT)
+    env = dict(os.environ)
+    env.pop("ULTRAGROTH_TEST_HOOKS", None)
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.split() == ["1", "0"]
+    env["ULTRAGROTH_TEST_HOOKS"] = "1"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.split() == ["0", "0"]
+
+
 def test_no_silent_cpu_fallback(lib, zkey):
     """without a GPU the compute entry points fail loudly"""
     if ug.device_count() > 0:

@@ -123,3 +123,39 @@ def test_ntt_against_direct_dft():
 def test_keccak256_vectors():
     assert O.keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
     assert O.keccak256(b"abc").hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
+
+
+needs_ref = pytest.mark.skipif(O.ref is None or not hasattr(O.ref, "ref_lookup_row"), reason="oracle/_ref (reference field layer) not built")
+
+
+@needs_ref
+def test_lookup_row_against_the_reference_overloads():
+    """compute_lookup's table row (src/ultra_groth.cpp:72-79) against the reference's own RawFr: `frequencies[i]` is a
+    uint32_t that binds to mul(int, Element) (build/fr.hpp:251), so values >= 2^31 enter as freq - 2^32 + r"""
+    rng = random.Random(77)
+    R = 1 << 256
+    for t in range(60):
+        rand = rng.randrange(O.R_MOD)
+        i = rng.choice([0, 1, 2, 255, 65535, rng.randrange(1 << 20)])
+        f = rng.choice([0, 1, 7, (1 << 31) - 1, 1 << 31, (1 << 31) + 5, (1 << 32) - 1, rng.randrange(1 << 32)])
+        got = O.lookup_row(i, f, rand * R % O.R_MOD)
+        assert got == O.ref_lookup_row(i, f, rand * R % O.R_MOD)
+        s = (i + rand) % O.R_MOD
+        inv = pow(s, -1, O.R_MOD) if s else 0
+        signed = f - (1 << 32) if f >= (1 << 31) else f
+        assert got == (inv, signed * inv % O.R_MOD)
+    # i + rand = 0: mpz_invert leaves 0, and so do we
+    assert O.lookup_row(5, 9, (O.R_MOD - 5) * R % O.R_MOD) == O.ref_lookup_row(5, 9, (O.R_MOD - 5) * R % O.R_MOD) == (0, 0)
+
+
+@needs_ref
+def test_derive_challenge_against_the_reference_code(zkey):
+    """derive_challenge (src/ultra_groth.cpp:33-58): big-endian x || y, the reference's Keccak-256, reduction mod r"""
+    a = _sec(zkey, "zkey", 5)
+    for k in range(0, 400, 7):
+        rec = a[64 * k:64 * k + 64]
+        if rec == bytes(64):
+            continue
+        x, y = O.mont_decode(rec[:32]), O.mont_decode(rec[32:])
+        exp = int.from_bytes(O.keccak256(x.to_bytes(32, "big") + y.to_bytes(32, "big")), "big") % O.R_MOD
+        assert O.derive_challenge(rec) == O.ref_derive_challenge(rec) == exp

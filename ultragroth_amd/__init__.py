@@ -49,7 +49,8 @@ def device_count():
 def set_test_blinding(data):
     """Queue bytes for the prover's blinding draws (31 bytes each); b'' restores OS entropy."""
     data = bytes(data)
-    load().ug_test_set_blinding(data if data else None, len(data))
+    if load().ug_test_set_blinding(data if data else None, len(data)) != PROVER_OK:
+        raise ProverError(PROVER_ERROR, "test hooks are off: start the process with ULTRAGROTH_TEST_HOOKS=1")
 
 
 def _buf(b):

@@ -127,7 +127,7 @@ def load():
         getattr(L, n).argtypes = [vp, ull, vp, ull, vp, pull, vp, pull, vp, ull]
     for n in ("groth16_prover_zkey_file", "ultra_groth_prover_zkey_file"):
         getattr(L, n).argtypes = [C.c_char_p, vp, ull, vp, pull, vp, pull, vp, ull]
-    L.ug_test_set_blinding.argtypes = [vp, ull]; L.ug_test_set_blinding.restype = None
+    L.ug_test_set_blinding.argtypes = [vp, ull]; L.ug_test_set_blinding.restype = C.c_int
     L.ug_prover_last_timings.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ug_prover_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_double), pull, pull, C.c_int]
     L.ug_groth16_prover_create_sharded.argtypes = [pp, vp, ull, C.c_int, C.c_int, C.c_int, vp, ull]

@@ -1,5 +1,6 @@
 // host_util.cpp -- see host_util.hpp.
 #include "host_util.hpp"
+#include <cstdlib>
 #include <fcntl.h>
 #include <mutex>
 #include <sys/mman.h>
@@ -38,11 +39,14 @@ BinFile::BinFile(const void* data, uint64_t size, const std::string& type, uint3
         uint32_t sType = rd32(p + pos);
         uint64_t sSize = rd64(p + pos + 4);
         pos += 12;
+        // checked before the add: a crafted size near 2^64 must not wrap `pos` back into the buffer (the reference adds
+        // first, binfile_utils.cpp:60-66, and would accept it)
+        if (sSize > size - pos)
+            throw std::range_error("Section #" + std::to_string(i) + " is invalid.. It ends at pos " +
+                                   (sSize > UINT64_MAX - pos ? "beyond 2^64" : std::to_string(pos + sSize)) +
+                                   " but should end before " + std::to_string(size) + ".");
         sections_[sType].push_back(Section{p + pos, sSize});
         pos += sSize;
-        if (pos > size)
-            throw std::range_error("Section #" + std::to_string(i) + " is invalid.. It ends at pos " + std::to_string(pos) +
-                                   " but should end before " + std::to_string(size) + ".");
     }
 }
 const Section& BinFile::find(uint32_t id, uint32_t pos) const {
@@ -153,10 +157,18 @@ std::vector<uint8_t> g_override;
 size_t g_override_pos = 0;
 }  // namespace
 
-void setRandomOverride(const void* bytes, size_t n) {
+// The override makes r, s and the round randomness deterministic for every prover of the process, i.e. it removes zero
+// knowledge: it only exists in processes started with ULTRAGROTH_TEST_HOOKS=1 (tests, bench.py --check, smoke()).
+bool testHooksEnabled() {
+    static const bool on = [] { const char* e = getenv("ULTRAGROTH_TEST_HOOKS"); return e && e[0] == '1' && !e[1]; }();
+    return on;
+}
+bool setRandomOverride(const void* bytes, size_t n) {
+    if (n && !testHooksEnabled()) return false;               // clearing is always allowed
     std::lock_guard<std::mutex> lock(g_rand_mutex);
     g_override.assign(static_cast<const uint8_t*>(bytes), static_cast<const uint8_t*>(bytes) + n);
     g_override_pos = 0;
+    return true;
 }
 void randomBytes(void* buf, size_t n) {
     {

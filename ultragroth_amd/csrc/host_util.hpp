@@ -62,7 +62,8 @@ std::string toDecimal(const uint8_t le[32]);
 
 // blinding randomness: OS entropy unless a test override is queued (ug_test_set_blinding)
 void randomBytes(void* buf, size_t n);
-void setRandomOverride(const void* bytes, size_t n);
+bool setRandomOverride(const void* bytes, size_t n);      // false (and no effect) unless ULTRAGROTH_TEST_HOOKS=1
+bool testHooksEnabled();
 
 void keccak256(uint8_t out[32], const uint8_t* in, uint64_t len);
 

@@ -159,6 +159,9 @@ Fr fr_root_of_unity(int s) {
 void NttPlan::init(int logn_, hipStream_t stream) {
     release();
     logn = logn_;
+    // per device, and idempotent: set whenever a plan is made on the current device
+    UG_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (1 << NTT_MAX_LOG_TILE) * NL * 4));
     u64 n = (u64)1 << logn;
     // Stage-major twiddle tables: stage s (butterfly span 2^s) reads omega_{2^(s+1)}^j at consecutive j, so the
     // lanes of a wave touch consecutive 32-byte entries at every stage (a single table of omega_n^i indexed with a
@@ -226,12 +229,6 @@ void NttPlan::transform(u32* out, const u32* in, bool inverse, bool gather_bitre
         int npass_left = (rem + 7) / 8;
         int k = (rem + npass_left - 1) / npass_left;
         stages[np] = k; nj[np] = NTT_MAX_LOG_TILE - k; np++; rem -= k;
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-        UG_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (1 << NTT_MAX_LOG_TILE) * NL * 4));
-        attr_set = true;
     }
     // Buffer plan: a scatter pass (last) reads `in`-resident data and writes `out`; otherwise the
     // first pass moves in -> out and the rest run in place on `out`. `in` is clobbered when scattering.

@@ -376,9 +376,9 @@ public:
     }
 
     // S1-S4 on this rank's slice; partials = A | B1 | B2 | C | H affine records (H left at infinity)
-    void runWitnessMsm(uint8_t* partials, bool resetTimers = true) override {
+    void runWitnessMsm(uint8_t* partials, bool standalone = true) override {
         if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
-        if (resetTimers) { ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1)); ugCheck(ug_ctx_timings(d_.ctx2, nullptr, nullptr, 1)); }
+        if (standalone) { ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1)); ugCheck(ug_ctx_timings(d_.ctx2, nullptr, nullptr, 1)); }
         // A schedule holds at most 2^31 (scalar, window) entries; ranges above MAX_RANGE scalars (only the
         // reference's largest legal domain, 2^27, needs it) are proved in pieces whose partial sums are added.
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
@@ -395,10 +395,11 @@ public:
             ugCheck(ug_msm_batch(d_.ctx, 4, sets, d_.sw, shifts, outs));
             if (out == part && ug_groth16_partials_add(partials, part) != PROVER_OK) throw std::runtime_error("partial sum failed");
         }
-        collectTimings();
+        if (standalone) collectTimings();        // (inside run() the two branches may be on two threads: run() collects once)
     }
     // S10 on this rank's slice of h (which must be in d_.h); only the H record of partials is written
-    void runHMsm(uint8_t* partials) override {
+    void runHMsm(uint8_t* partials) override { runHMsmImpl(partials, true); }
+    void runHMsmImpl(uint8_t* partials, bool standalone) {
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
         uint8_t part[UG_GROTH16_PARTIALS_SIZE];
         for (uint64_t lo = hr_.lo; lo < hr_.hi; lo += maxRange_) {
@@ -409,7 +410,7 @@ public:
             ugCheck(ug_msm_g1(d_.ctx2, d_.H, d_.sh, 0, out + 320));                            // S10 :154
             if (out == part && ug_groth16_partials_add(partials, part) != PROVER_OK) throw std::runtime_error("partial sum failed");
         }
-        collectTimings();
+        if (standalone) collectTimings();
     }
     void collectTimings() {
         double m1 = 0, f1 = 0, m2 = 0, f2 = 0;
@@ -456,9 +457,9 @@ public:
         const char* ov = getenv("ULTRAGROTH_OVERLAP");
         const bool overlap = ov && atoi(ov) != 0;
         if (!overlap) {
-            runWitnessMsm(partials, /*resetTimers*/ false);
+            runWitnessMsm(partials, /*standalone*/ false);
             ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                          // S5-S9 :66-148
-            runHMsm(hpart);                                                                    // S10   :154
+            runHMsmImpl(hpart, false);                                                         // S10   :154
             memcpy(partials + 320, hpart + 320, 64);
             collectTimings();
             return;
@@ -467,11 +468,11 @@ public:
         std::thread hBranch([&] {
             try {
                 ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                      // S5-S9 :66-148
-                runHMsm(hpart);                                                                // S10   :154
+                runHMsmImpl(hpart, false);                                                     // S10   :154
             } catch (...) { hErr = std::current_exception(); }
         });
         std::exception_ptr wErr;
-        try { runWitnessMsm(partials, /*resetTimers*/ false); } catch (...) { wErr = std::current_exception(); }
+        try { runWitnessMsm(partials, /*standalone*/ false); } catch (...) { wErr = std::current_exception(); }
         hBranch.join();
         if (wErr) std::rethrow_exception(wErr);
         if (hErr) std::rethrow_exception(hErr);
@@ -785,6 +786,14 @@ public:
 
 private:
     static void putPlain(uint8_t* dst, const Fr& v) { u32 w[8]; to_normal(w, v); memcpy(dst, w, 32); }
+    // RawFr::set(int) (build/fr.cpp:209-223): a C int as a field element, negative values as value + r. compute_lookup
+    // passes its `int i` and its `uint32_t frequencies[i]` to field.add(int, Element) / field.mul(int, Element)
+    // (src/ultra_groth.cpp:72,78; overloads build/fr.hpp:249-251), so a frequency >= 2^31 enters as freq - 2^32 + r.
+    static Fr setInt(int32_t v) {
+        u32 w[8] = {v < 0 ? (u32)(-(int64_t)v) : (u32)v, 0, 0, 0, 0, 0, 0, 0};
+        Fr m = from_normal<FrParams>(w);                       // < 2q, strict
+        return v < 0 ? neg<2>(m) : m;
+    }
     // compute_lookup (src/ultra_groth.cpp:62-106). Host: the 2 L table values inv2[i] = 1 / (i + rand) (0 when the sum
     // is 0) and prod[i] = freq[i] * inv2[i], with one shared inversion. Device: the writes into the witness
     // (ug_dvec_apply_lookup; the reference's push_vector with its per-chunk copies of inv2 is never materialised).
@@ -800,8 +809,7 @@ private:
         std::vector<Fr> sum(L), pre(L);
         Fr acc = fp_one<FrParams>();
         for (size_t i = 0; i < L; i++) {
-            u32 iw[8] = {(u32)i, 0, 0, 0, 0, 0, 0, 0};
-            sum[i] = mul(add(from_normal<FrParams>(iw), rand), fp_one<FrParams>());   // < 2q
+            sum[i] = mul(add(setInt((int32_t)(u32)i), rand), fp_one<FrParams>());     // < 2q
             pre[i] = acc;
             if (!is_zero(sum[i])) acc = mul(acc, sum[i]);
         }
@@ -811,8 +819,7 @@ private:
             if (is_zero(sum[i])) inv_i = fp_zero<FrParams>();
             else { inv_i = mul(inv_acc, pre[i]); inv_acc = mul(inv_acc, sum[i]); }
             putPlain(inv2 + i * 32, inv_i);
-            u32 fw[8] = {freq[i], 0, 0, 0, 0, 0, 0, 0};
-            putPlain(prod + i * 32, mul(from_normal<FrParams>(fw), inv_i));
+            putPlain(prod + i * 32, mul(setInt((int32_t)freq[i]), inv_i));
         }
         ugCheck(ug_dvec_apply_lookup(d_.w, wIdx.data(), pIdx.data(), wIdx.size(), chunks.data(), Cn, table.data(), L));
         // the same writes for the public signals, in order (a later write overwrites an earlier one)
@@ -1017,7 +1024,7 @@ int ultra_groth_prover_zkey_file(const char* zkey_file_path, const void* wtns_bu
 }
 
 // ---- additions ----------------------------------------------------------------------------------------------
-void ug_test_set_blinding(const void* bytes, unsigned long long n) { setRandomOverride(bytes, (size_t)n); }
+int ug_test_set_blinding(const void* bytes, unsigned long long n) { return setRandomOverride(bytes, (size_t)n) ? PROVER_OK : PROVER_ERROR; }
 
 int ug_prover_last_timings(void* prover_object, double* msm_ms, double* fft_ms, double* total_ms) {
     if (!prover_object) return PROVER_ERROR;

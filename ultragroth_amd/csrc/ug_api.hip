@@ -2,6 +2,7 @@
 // Owns device memory, the stream and the reusable workspaces; translates between the reference's byte
 // formats and the device forms; catches every exception at the boundary.
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 #include <exception>
@@ -436,19 +437,22 @@ int ug_hpoly_create(ug_ctx* c, const void* host_coefs, uint64_t n_coefs, uint32_
     if (domain == 0 || (domain & (domain - 1))) throw std::invalid_argument("domain size is not a power of two");
     if (domain > (1u << 27)) throw std::invalid_argument("domain size above 2^27 (Fr has 2-adicity 28)");
     c->use();
-    ug_hpoly* hp = new ug_hpoly();
+    std::unique_ptr<ug_hpoly, void (*)(ug_hpoly*)> hp(new ug_hpoly(), ug_hpoly_destroy);   // frees everything on any throw below
     hp->ctx = c; hp->domain = domain; hp->nvars = n_vars;
     uint8_t* raw = nullptr;
     UG_HIP(hipMalloc(&raw, n_coefs ? (size_t)n_coefs * 44 : 4));
-    if (n_coefs) UG_HIP(hipMemcpyAsync(raw, host_coefs, (size_t)n_coefs * 44, hipMemcpyHostToDevice, c->stream));
-    bool ok = hp->mat.build(raw, n_coefs, domain, n_vars, c->stream);
+    bool ok = false;
+    try {
+        if (n_coefs) UG_HIP(hipMemcpyAsync(raw, host_coefs, (size_t)n_coefs * 44, hipMemcpyHostToDevice, c->stream));
+        ok = hp->mat.build(raw, n_coefs, domain, n_vars, c->stream);
+    } catch (...) { hipFree(raw); throw; }
     hipFree(raw);
-    if (!ok) { delete hp; throw std::invalid_argument("coefficient record out of range (m, row or signal index)"); }
+    if (!ok) throw std::invalid_argument("coefficient record out of range (m, row or signal index)");
     hp->ntt.init(hp->mat.logn, c->stream);
     size_t bytes = (size_t)domain * 32;
     UG_HIP(hipMalloc(&hp->a, bytes)); UG_HIP(hipMalloc(&hp->b, bytes));
     UG_HIP(hipMalloc(&hp->c, bytes)); UG_HIP(hipMalloc(&hp->t, bytes));
-    *out = hp;
+    *out = hp.release();
     UG_CATCH
 }
 
