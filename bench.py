@@ -4,21 +4,27 @@
     python bench.py --gpus N --steps K --warmup W [--log-domain 24] [--mix U|C]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step is one pass of the prover's hot path over one witness of a seeded synthetic circuit
-(ultragroth_amd/synth.py, shapes of SURVEY.md section 8d): the five MSMs and the H-polynomial block on
-the device, then blinding and JSON on the host -- i.e. groth16_prover_prove on a created prover, with the
-witness already resident in HBM when the timed region starts. Default workload: configs[2] of
-BASELINE.json, the 2^24-constraint circuit with full G1+G2 MSMs that the 10x target is quoted on.
+A step is one proof of a seeded synthetic circuit (ultragroth_amd/synth.py, shapes of SURVEY.md section 8d) as SURVEY.md
+section 8(d) defines the metric: the wall time of `groth16_prover_prove` on a CREATED prover with the .wtns in HOST
+memory -- parse, host-to-device copy of the witness, the five MSMs and the H-polynomial block on the device, blinding and
+JSON on the host. `value` is therefore PCIe-inclusive for the witness (512 MiB at 2^24); `witness_upload_ms_per_proof`
+and `resident_ms_per_step` (the same step minus the upload) are extra keys. `create` (zkey upload, conversion, window
+tables) is reported separately as `create_s`. Default workload: configs[2] of BASELINE.json, the 2^24-constraint circuit
+with full G1+G2 MSMs that the 10x target is quoted on.
 
-With N > 1 ranks the base points of every section are sharded by contiguous range (one process per GPU),
-each rank computes partial sums of the five MSMs over its slice, the 384-byte partial records are
+With N > 1 ranks the base points of every section are sharded by contiguous range (one process per GPU), every rank
+uploads the witness, computes partial sums of the five MSMs over its slice, the 384-byte partial records are
 all-gathered over RCCL and added on every rank (an EC addition is not an RCCL reduction operator), and rank 0
 finishes the proof. The three NTT chains of the H polynomial are taken by ranks 0..2 and their evaluation vectors
-scattered slice-wise over RCCL, so each rank forms only its own slice of h. The same proof is produced at every N ("strong" scaling of one proof).
+scattered slice-wise over RCCL, so each rank forms only its own slice of h. The same proof is produced at every N
+("strong" scaling of one proof).
 
-Rank 0 prints ONE JSON line. `roofline` is for the G1 bucket-accumulation kernel, measured with HIP events
-on the launch stream inside the library; `cpu_baseline` times the CPU oracle (oracle/, OpenMP) on a bounded
-sample. The oracle is the checker/baseline only; the timed path never touches it.
+Rank 0 prints ONE JSON line. `roofline` is for the G1 bucket-accumulation kernel (the dominant one), with the G2
+accumulation and the NTT pass kernel beside it under `roofline.kernels`; all three are measured in this run with HIP
+events on the launch stream inside the library. `cpu_baseline` times the CPU oracle (oracle/, OpenMP) on bounded
+samples. The oracle is the checker/baseline only; the timed path never touches it. `--check` proves once more with
+fixed blinding and compares proof.json byte for byte with the expected proof (oracle/closed_form.py: oracle H polynomial
++ MSMs in the exponent, any size); a mismatch makes the exit code 3.
 """
 import argparse
 import json
@@ -42,7 +48,8 @@ def parse():
     ap.add_argument("--mix", default="U", choices=["U", "C"])
     ap.add_argument("--cpu-sample-log", type=int, default=None, help="log2 domain of the CPU-baseline sample circuit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--check", action="store_true", help="also compare the proof with the oracle (small sizes)")
+    ap.add_argument("--check", action="store_true", help="one more proof with fixed blinding, compared byte for byte with the expected proof "
+                                                         "(oracle H polynomial + MSMs in the exponent; any size); exit code 3 on a mismatch")
     ap.add_argument("--g1-only", action="store_true", help="BASELINE.json configs[1]: G1 MSM + NTT only (B1/B2/C sets at infinity)")
     ap.add_argument("--overlap", action="store_true", help="ULTRAGROTH_OVERLAP=1: H branch on a second stream beside the witness MSMs "
                                                            "(faster, but per-kernel times and the MSM | FFT split stretch)")
@@ -67,30 +74,64 @@ def cpu_share():
     return cores
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(dev, args, log_domain):
-    """Oracle (plain C + OpenMP) on a bounded sample: the same generator at 2^sample, scaled linearly in N.
-    The box may show more cores than its share (16 per GPU): the sample is timed with the detected share and, when
-    that is larger, with 16 and 32 threads too, and the FASTEST is reported (the baseline gets every benefit)."""
+    """Oracle (plain C + OpenMP) on bounded samples of the same generator. The proof is timed at two sizes (2^20 and 2^22
+    by default, about 25 s of CPU work together), MSM and FFT parts separately; each part is extrapolated to the
+    benchmarked size with ITS OWN fitted exponent (t ~ N^e: Pippenger is sub-linear, the FFT block N log N), not
+    linearly. A benchmarked size at or below the larger sample is measured directly. The box may show more cores than
+    its share (16 per GPU): the small sample is timed with the detected share and with 16 and 32 threads when those are
+    fewer, and the fastest setting is kept (the baseline gets every benefit)."""
+    import math
     import oracle as O
     from ultragroth_amd import synth
-    sample_log = args.cpu_sample_log if args.cpu_sample_log is not None else min(log_domain, 19)
-    zk, wt, _ = synth.build_circuit(dev, sample_log, mix=args.mix)
+    hi = args.cpu_sample_log if args.cpu_sample_log is not None else min(log_domain, 22)
+    lo = max(min(hi - 2, 20), 10) if hi > 12 else hi
     share = cpu_share()
-    best = None
-    for threads in sorted({share, min(share, 16), min(share, 32)}):
+
+    def timed(log, threads):
+        zk, wt, _ = synth.build_circuit(dev, log, mix=args.mix, g1_only=args.g1_only)
         O.lib.ugo_set_num_threads(threads)
         t0 = time.perf_counter()
         _, _, (msm_s, fft_s) = O.groth16_prove(zk, wt, 12345, 67890, want_timings=True)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[0]:
-            best = (dt, msm_s, fft_s, O.lib.ugo_num_threads())
-    dt, msm_s, fft_s, cores = best
-    scale = float(1 << (log_domain - sample_log))
+        return time.perf_counter() - t0, msm_s, fft_s, O.lib.ugo_num_threads()
+
+    best = None
+    for threads in sorted({share, min(share, 16), min(share, 32)}):
+        t = timed(lo, threads)
+        if best is None or t[0] < best[0]:
+            best = t
+    dt_lo, msm_lo, fft_lo, cores = best
+    if hi > lo:
+        dt_hi, msm_hi, fft_hi, _ = timed(hi, cores)
+    else:
+        dt_hi, msm_hi, fft_hi = dt_lo, msm_lo, fft_lo
+    rest_hi = max(dt_hi - msm_hi - fft_hi, 0.0)                # parsing, blinding, JSON: grows at most linearly
+    if log_domain > hi:
+        e_msm = math.log2(msm_hi / msm_lo) / (hi - lo)
+        e_fft = math.log2(fft_hi / fft_lo) / (hi - lo)
+        k = log_domain - hi
+        est = msm_hi * 2.0 ** (e_msm * k) + fft_hi * 2.0 ** (e_fft * k) + rest_hi * 2.0 ** k
+        how = ("extrapolated to 2^%d with the fitted exponents t ~ N^e: MSM e = %.3f, FFT e = %.3f -> %.1f s per proof"
+               % (log_domain, e_msm, e_fft, est))
+    else:
+        est = dt_hi
+        how = "measured at the benchmarked size"
     return {
-        "value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": cores, "kind": "port",
-        "sample": "oracle (restated rapidsnark-equivalent CPU path, OpenMP, best of 16/32/%d threads) proving the 2^%d "
-                  "circuit of the same generator in %.2f s (MSM %.2f s | FFT %.2f s), scaled x%d linearly in N to 2^%d"
-                  % (share, sample_log, dt, msm_s, fft_s, int(scale), log_domain),
+        "value": 1.0 / est, "unit": "proofs/s", "cores": cores, "kind": "port",
+        "cpu": "%s, nproc %d, share %d" % (cpu_model(), os.cpu_count() or 0, share),
+        "sample": "oracle (restated rapidsnark-equivalent CPU path, plain C + OpenMP, %d threads) proving the 2^%d circuit of the "
+                  "same generator in %.2f s (MSM %.2f | FFT %.2f) and the 2^%d circuit in %.2f s (MSM %.2f | FFT %.2f); %s"
+                  % (cores, lo, dt_lo, msm_lo, fft_lo, hi, dt_hi, msm_hi, fft_hi, how),
     }
 
 
@@ -122,9 +163,15 @@ def bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_r
     parts are all-gathered and added, rank 0 closes the round and broadcasts the commitment; every rank applies it and
     runs its slices of the final MSMs; the three NTT chains go to ranks 0..2 with their evaluation vectors scattered
     slice-wise, as for Groth16; the 384-byte partial blocks are all-gathered and rank 0 finishes."""
-    zkey, uwtns, info = synth.build_ultra_circuit(dev, args.log_domain, mix="C")
-    workload = ("ultragroth-bn254 2^%d constraints, two rounds, lookup 2^8, circom-like witness (BASELINE.json configs[4] "
-                "shape; witness from host memory)" % args.log_domain)
+    LOOKUP_LOG = 16                              # SURVEY.md section 8(d) cfg 5: lookup_size 2^16, chunks M/8
+    zkey, uwtns, info = synth.build_ultra_circuit(dev, args.log_domain, mix="C", lookup_log=LOOKUP_LOG)
+    workload = ("ultragroth-bn254 2^%d constraints, two rounds, lookup 2^%d, circom-like witness (BASELINE.json configs[4] "
+                "shape; step = ultra_groth_prover_prove, .uwtns in host memory)" % (args.log_domain, LOOKUP_LOG))
+    FIXED = (bytes(range(1, 32)), bytes(range(40, 71)), bytes(range(80, 111)))          # r_k, r, s of --check
+
+    def expected():
+        import oracle as O
+        return O.ultra_groth_prove(zkey, uwtns, *(int.from_bytes(b, "little") for b in FIXED))
 
     def line(elapsed, msm_ms, fft_ms, create_s, parallelism):
         print(json.dumps({
@@ -148,12 +195,22 @@ def bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_r
             m, f, _ = prover.last_timings()
             msm_ms += m
             fft_ms += f
-        return line(time.perf_counter() - t0, msm_ms, fft_ms, create_s, "one GPU")
+        elapsed = time.perf_counter() - t0
+        ok = True
+        if args.check:
+            ug.set_test_blinding(b"".join(FIXED))
+            got = prover.prove(uwtns)
+            ug.set_test_blinding(b"")
+            ok = got == expected()
+            workload += " [check: %s]" % ("bit-exact" if ok else "MISMATCH")
+        line(elapsed, msm_ms, fft_ms, create_s, "one GPU")
+        if not ok:
+            sys.exit(3)
+        return
 
     t0 = time.perf_counter()
     prover = ug.ShardedUltraGrothProver(zkey, local_rank, rank, world)
     create_s = time.perf_counter() - t0
-    del zkey
     cuda = backend == "nccl"
     n_dom = info["domainSize"]
     split_h = n_dom % world == 0
@@ -228,21 +285,20 @@ def bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_r
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     chk = None
     if args.check:
-        rk, r, s = bytes(range(1, 32)), bytes(range(40, 71)), bytes(range(80, 111))
-        ug.set_test_blinding(rk + r + s)
+        ug.set_test_blinding(b"".join(FIXED))
         chk = step()
         ug.set_test_blinding(b"")
+    ok = True
     if rank == 0:
         if args.check:
-            import oracle as O
-            zk, uw, _ = synth.build_ultra_circuit(dev, args.log_domain, mix="C")
-            exp = O.ultra_groth_prove(zk, uw, int.from_bytes(bytes(range(1, 32)), "little"),
-                                      int.from_bytes(bytes(range(40, 71)), "little"), int.from_bytes(bytes(range(80, 111)), "little"))
-            workload += " [check: %s]" % ("bit-exact" if chk == exp else "MISMATCH")
+            ok = chk == expected()
+            workload += " [check: %s]" % ("bit-exact" if ok else "MISMATCH")
         line(float(t.item()), msm_ms, fft_ms, create_s,
              "section-range shard x%d%s" % (world, ", H-poly chains split over ranks" if split_h else ""))
     dist.barrier()
     dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
 
 
 def main():
@@ -256,6 +312,8 @@ def main():
         raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
 
+    if args.check:
+        os.environ["ULTRAGROTH_TEST_HOOKS"] = "1"       # fixed blinding for the comparison (only honoured when set before load)
     import torch
     import ultragroth_amd as ug
     from ultragroth_amd import synth
@@ -281,14 +339,15 @@ def main():
     if args.ultra:
         return bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_rank)
     zkey, wtns, info = synth.build_circuit(dev, log_domain, mix=args.mix, g1_only=args.g1_only)
-    t0 = time.perf_counter()
-    prover = ug.ShardedGroth16Prover(zkey, local_rank, rank, world, witness_range=witness_slice(info, rank, world))
-    create_s = time.perf_counter() - t0
     zkey_bytes = len(zkey)
-    del zkey
     t0 = time.perf_counter()
-    prover.load_witness(wtns)
-    upload_s = time.perf_counter() - t0
+    if world == 1:
+        prover = ug.Groth16Prover(zkey)          # groth16_prover_create: the reference's own entry point
+    else:
+        prover = ug.ShardedGroth16Prover(zkey, local_rank, rank, world, witness_range=witness_slice(info, rank, world))
+    create_s = time.perf_counter() - t0
+    if not args.check:
+        del zkey
 
     def barrier():
         torch.cuda.synchronize()
@@ -323,6 +382,9 @@ def main():
             prover.hpoly_chain(k, fulls[k].data_ptr())
 
     def step():
+        if world == 1:
+            return prover.prove(wtns)            # groth16_prover_prove on the .wtns in host memory: THE metric
+        prover.load_witness(wtns)                # every rank brings the witness into its HBM (inside the timed step)
         if split_h:
             th = None
             if my_chains:
@@ -338,25 +400,22 @@ def main():
             part = part[:320] + prover.run_h_msm()[320:384]
         else:
             part = prover.run()
-        if dist is not None:
-            mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)
-            if backend == "nccl":
-                mine = mine.cuda()
-            allp = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(allp, mine)
-            total = bytes(allp[0].cpu().numpy())
-            for other in allp[1:]:
-                total = prover.add_partials(total, bytes(other.cpu().numpy()))
-        else:
-            total = part
+        mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)
+        if backend == "nccl":
+            mine = mine.cuda()
+        allp = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        total = bytes(allp[0].cpu().numpy())
+        for other in allp[1:]:
+            total = prover.add_partials(total, bytes(other.cpu().numpy()))
         return prover.finish(total) if rank == 0 else None
 
     out = None
     for _ in range(args.warmup):
         out = step()
-    prover.kernel_stats(g2=False, reset=True)
-    prover.kernel_stats(g2=True, reset=True)
-    msm_ms = fft_ms = 0.0
+    for which in range(3):
+        prover.kernel_stats(which=which, reset=True)
+    msm_ms = fft_ms = upload_ms = 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -364,6 +423,7 @@ def main():
         m, f, _ = prover.last_timings()
         msm_ms += m
         fft_ms += f
+        upload_ms += prover.last_upload_ms()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -377,60 +437,90 @@ def main():
         chk = step()
         ug.set_test_blinding(b"")
 
+    rc = 0
     if rank == 0:
-        acc_ms, launches, entries = prover.kernel_stats(g2=False)
-        g2_ms, g2_launches, _ = prover.kernel_stats(g2=True)
+        acc_ms, launches, entries = prover.kernel_stats(which=0)
+        g2_ms, g2_launches, g2_entries = prover.kernel_stats(which=1)
+        ntt_ms, ntt_launches, ntt_points = prover.kernel_stats(which=2)
         ws = witness_slice(info, 0, world)
         n_local = (ws[1] - ws[0]) if ws else info["nVars"] // world
-        # G1 bucket accumulation: algorithmic bytes of one G1 MSM launch = 96 B per point of the slice
-        # (64 B affine base + 32 B scalar, each read once)
-        g1_bytes = 96.0 * n_local
-        achieved = g1_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
-        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, corrected as the microarch guide
-        # says), measured separately on this workload and committed under profiles/; null when not measured
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-            k = pmc.get(str(log_domain), {}).get("segment_accumulate_kernel<G1Cfg>")
-            if k and world == 1 and args.mix == "U":
-                traffic = k["fetch"] + k["write"]
-        except Exception:
-            traffic = None
+        # Algorithmic bytes per launch (restated in DESIGN.md): G1 accumulation 96 B per point of
+        # the slice (64 B affine base + 32 B scalar, each read once), G2 160 B per point, one NTT pass 64 B per point
+        g1_bytes, g2_bytes, ntt_bytes = 96.0 * n_local, 160.0 * n_local, 64.0 * info["domainSize"]
+
+        def gbs(nbytes, ms):
+            return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+
+        def mads(per_unit, units, n, ms):
+            return (per_unit * units / max(n, 1) / (ms * 1e-3) / 1e12) if ms > 0 else 0.0
+        achieved = gbs(g1_bytes, acc_ms)
+        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, corrected as the microarch guide says):
+        # NOT measured in this run -- read from the committed summary of the same workload under profiles/ (null if absent)
+        traffic, traffic_source = None, None
+        for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                k = pmc.get(str(log_domain), {}).get("segment_accumulate_kernel<G1Cfg>")
+                if k and world == 1 and args.mix == "U" and not args.g1_only:
+                    traffic = k["fetch"] + k["write"]
+                    traffic_source = "profiles/%s (separate rocprofv3 --pmc passes on this workload; not measured in this run)" % name
+                    break
+            except Exception:
+                pass
+        ms_per_step = 1e3 * elapsed / args.steps
         res = {
             "metric": "proofs/s", "value": args.steps / elapsed, "unit": "proofs/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 254-bit modular integers)",
             "data": "synthetic",
-            "config": {"workload": "groth16-bn254 2^%d constraints, nVars 2^%d-1, nCoefs 4N, full G1+G2 MSM + H-poly FFT, "
-                                   "scalar mix %s (BASELINE.json configs[%d] shape)" % (log_domain, log_domain, args.mix, 1 if args.g1_only else 2),
-                       "log_domain": log_domain, "mix": args.mix, "overlap": bool(os.environ.get("ULTRAGROTH_OVERLAP", "0") not in ("", "0")), "parallelism": "base-range shard x%d%s" % (world, ", H-poly chains split over ranks" if split_h else "")},
+            "config": {"workload": "groth16-bn254 2^%d constraints, nVars 2^%d-1, nCoefs 4N, %s + H-poly FFT, scalar mix %s "
+                                   "(BASELINE.json configs[%d] shape); step = groth16_prover_prove on a created prover, .wtns in host memory"
+                                   % (log_domain, log_domain, "G1 MSMs A and H only" if args.g1_only else "full G1+G2 MSM", args.mix,
+                                      1 if args.g1_only else 2),
+                       "log_domain": log_domain, "mix": args.mix, "overlap": bool(os.environ.get("ULTRAGROTH_OVERLAP", "0") not in ("", "0")),
+                       "parallelism": "one GPU" if world == 1 else "base-range shard x%d%s" % (world, ", H-poly chains split over ranks" if split_h else "")},
             "msm_ms_per_proof": msm_ms / args.steps, "fft_ms_per_proof": fft_ms / args.steps,
-            "create_s": create_s, "witness_upload_s": upload_s, "zkey_bytes": zkey_bytes,
+            "witness_upload_ms_per_proof": upload_ms / args.steps, "resident_ms_per_step": ms_per_step - upload_ms / args.steps,
+            "witness_upload_gbs": (32.0 * info["nVars"] / (upload_ms / args.steps * 1e-3) / 1e9) if upload_ms > 0 else None,
+            "create_s": create_s, "zkey_bytes": zkey_bytes, "zkey_ingest_gbs": zkey_bytes / create_s / 1e9,
             "host_peak_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 2),
             "roofline": {"bound": "hbm", "kernel": "segment_accumulate_kernel<G1Cfg>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": g1_bytes,
                          "avg_launch_ms": acc_ms, "launches": launches,
                          # the bound that actually binds: v_mad_u64_u32 issue (29 T mad/s measured, tools/ubench_int.hip);
-                         # one G1 mixed addition = 1467 mads, entries = (scalar, window) digits
-                         "issue_bound": {"unit": "T mad/s", "peak": 29.0,
-                                         "achieved": (1467.0 * entries / max(launches, 1) / (acc_ms * 1e-3) / 1e12) if acc_ms > 0 else 0.0,
-                                         "frac": (1467.0 * entries / max(launches, 1) / (acc_ms * 1e-3) / 29.0e12) if acc_ms > 0 else 0.0},
-                         "g2_kernel": {"avg_launch_ms": g2_ms, "launches": g2_launches,
-                                       "achieved": (160.0 * n_local / (g2_ms * 1e-3) / 1e9) if g2_ms > 0 else 0.0},
-                         "note": "integer-issue-bound kernel: see DESIGN.md for modmul/s against the v_mad_u64_u32 peak"},
+                         # one G1 mixed addition = 1467 mads, G2 4470, one NTT butterfly 162
+                         "issue_bound": {"unit": "T mad/s", "peak": 29.0, "achieved": mads(1467.0, entries, launches, acc_ms),
+                                         "frac": mads(1467.0, entries, launches, acc_ms) / 29.0},
+                         "kernels": {
+                             "segment_accumulate_kernel<G2Cfg>": {
+                                 "bound": "hbm", "achieved": gbs(g2_bytes, g2_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": gbs(g2_bytes, g2_ms) / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": g2_bytes,
+                                 "avg_launch_ms": g2_ms, "launches": g2_launches,
+                                 "issue_bound_frac": mads(4470.0, g2_entries, g2_launches, g2_ms) / 29.0},
+                             "ntt_pass_kernel": {
+                                 "bound": "hbm", "achieved": gbs(ntt_bytes, ntt_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": gbs(ntt_bytes, ntt_ms) / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ntt_bytes,
+                                 "avg_launch_ms": ntt_ms, "launches": ntt_launches,
+                                 "passes_per_transform": (ntt_launches / (6.0 * args.steps)) if world == 1 else None}},
+                         "note": "integer-issue-bound kernels: see DESIGN.md for modmul/s against the v_mad_u64_u32 peak"},
         }
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(dev, args, log_domain)
         if args.check:
-            import oracle as O
-            zk, wt, _ = synth.build_circuit(dev, log_domain, mix=args.mix)
-            exp = O.groth16_prove(zk, wt, int.from_bytes(bytes(range(1, 32)), "little"), int.from_bytes(bytes(range(31, 62)), "little"))
-            res["check"] = "bit-exact" if (chk[0], chk[1]) == (exp[0], exp[1]) else "MISMATCH"
+            from oracle import closed_form
+            exp = closed_form.groth16_expected(zkey, wtns, synth.SEEDS, synth.g1_generator_record(), synth.g2_generator_record(),
+                                               int.from_bytes(bytes(range(1, 32)), "little"), int.from_bytes(bytes(range(31, 62)), "little"),
+                                               g1_only=args.g1_only)
+            ok = (chk[0], chk[1]) == exp
+            res["check"] = "bit-exact" if ok else "MISMATCH"
+            rc = 0 if ok else 3
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -115,10 +115,13 @@ int ug_test_set_blinding(const void *bytes, unsigned long long n);
 /* Device milliseconds of the last prove on this prover object: MSM part, H-polynomial ("FFT") part, and
  * host wall-clock milliseconds of the whole prove call. */
 int ug_prover_last_timings(void *prover_object, double *msm_ms, double *fft_ms, double *total_ms);
-/* average duration (ms), launch count and (point, window) entries of the G1 (g2 = 0) or G2 (g2 = 1)
- * bucket-accumulation kernel since the prover was created or the counters were last reset */
-int ug_prover_kernel_stats(void *prover_object, int g2, double *accumulate_ms_avg, unsigned long long *launches,
-                           unsigned long long *entries, int reset);
+/* average launch duration (ms), launch count and units processed of the kernels the roofline is reported for, since the
+ * prover was created or the counters were last reset: which = 0 G1 bucket accumulation, 1 G2 bucket accumulation
+ * (units: (point, window) entries), 2 NTT pass kernel (units: points per pass) */
+int ug_prover_kernel_stats(void *prover_object, int which, double *launch_ms_avg, unsigned long long *launches,
+                           unsigned long long *units, int reset);
+/* host wall-clock milliseconds the last prove spent bringing the witness into HBM (parse + host-to-device copy) */
+int ug_prover_last_upload_ms(void *prover_object, double *upload_ms);
 
 /* Sharded Groth16 proving, one process per GPU. Rank `shard_rank` of `shard_count` holds the base points
  * [rank * n / count, (rank + 1) * n / count) of every section and produces partial sums; the partial

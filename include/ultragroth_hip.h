@@ -154,10 +154,10 @@ int  ug_synth_points(ug_ctx* ctx, int g2, const void* generator_record, uint64_t
  * (the MSM | FFT split the reference prints in src/ultra_groth.cpp:199-335) */
 int  ug_ctx_timings(ug_ctx* ctx, double* msm_ms, double* fft_ms, int reset);
 
-/* HIP events (recorded on the launch stream) over the dominant kernel of the hot path, for roofline
- * reporting: average duration in ms of the G1 (g2 = 0) or G2 (g2 = 1) bucket-accumulation launches since
- * the last reset, their count, and the (point, window) entries they processed */
-int  ug_ctx_kernel_stats(ug_ctx* ctx, int g2, double* accumulate_ms_avg, uint64_t* launches, uint64_t* entries, int reset);
+/* HIP events (recorded on the launch stream) around the launches of the kernels the roofline is reported for:
+ * which = 0 the G1 bucket accumulation, 1 the G2 bucket accumulation, 2 the NTT pass kernel. Average launch duration in
+ * ms since the last reset, the launch count, and the units processed ((point, window) entries; NTT points per pass) */
+int  ug_ctx_kernel_stats(ug_ctx* ctx, int which, double* launch_ms_avg, uint64_t* launches, uint64_t* units, int reset);
 
 #ifdef __cplusplus
 }

@@ -44,6 +44,7 @@ def _load():
                                     vp, C.POINTER(C.c_double), vp, C.c_uint64]
     L.ugo_ultra_groth_prove.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp,
                                         C.c_uint64, vp, C.c_uint64]
+    L.ugo_groth16_finish.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64]
     L.ugo_hpoly.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, C.c_uint32, vp]
     L.ugo_fr_ntt.argtypes = [vp, C.c_int, C.c_int]
     L.ugo_fr_root_of_unity.argtypes = [vp, C.c_int]
@@ -143,6 +144,31 @@ def groth16_prove(zkey, wtns, r, s, want_raw=False, want_timings=False):
     if want_timings:
         res.append((tim[0], tim[1]))
     return tuple(res)
+
+
+def groth16_finish(zkey_header_only, sums, public_w, r, s):
+    """Blinding + JSON (S11-S13) from the five MSM results as affine records (A | B1 | B2 | C | H, 384 bytes).
+    zkey_header_only: a zkey holding at least sections 1, 2, 4 (see header_only_zkey); public_w: w[0..nPublic] bytes."""
+    info = zkey_info(zkey_header_only)
+    proof = C.create_string_buffer(1024)
+    pub = C.create_string_buffer(info["nPublic"] * 82 + 16)
+    err = C.create_string_buffer(256)
+    rc = lib.ugo_groth16_finish(zkey_header_only, len(zkey_header_only), bytes(sums), bytes(public_w), to_le(r), to_le(s),
+                                proof, len(proof), pub, len(pub), err, len(err))
+    if rc:
+        raise RuntimeError("oracle finish failed (%d): %s" % (rc, err.value.decode()))
+    return proof.value.decode(), pub.value.decode()
+
+
+def header_only_zkey(zkey):
+    """sections 1 and 2 of a (possibly huge) zkey plus an empty coefficient section, as a small zkey of its own"""
+    import struct
+    view = memoryview(zkey).cast("B")
+    out = b"zkey" + struct.pack("<II", 1, 3)
+    for sid in (1, 2):
+        off, sz = section(zkey, "zkey", sid)
+        out += struct.pack("<IQ", sid, sz) + bytes(view[off:off + sz])
+    return out + struct.pack("<IQ", 4, 4) + bytes(4)
 
 
 def ultra_groth_prove(zkey, wtns, rk, r, s):

@@ -45,6 +45,9 @@ int  ugo_groth16_prove(const uint8_t *zkey, uint64_t zkey_size, const uint8_t *w
                        const uint8_t r[32], const uint8_t s[32],
                        char *proof_out, uint64_t proof_cap, char *public_out, uint64_t public_cap,
                        uint8_t *raw_out, double *timings, char *err, uint64_t errsz);
+int  ugo_groth16_finish(const uint8_t *zkey, uint64_t zkey_size, const uint8_t sums[384], const uint8_t *public_w,
+                        const uint8_t r[32], const uint8_t s[32], char *proof_out, uint64_t proof_cap,
+                        char *public_out, uint64_t public_cap, char *err, uint64_t errsz);
 int  ugo_ultra_groth_prove(const uint8_t *zkey, uint64_t zkey_size, const uint8_t *wtns, uint64_t wtns_size,
                            const uint8_t rk[32], const uint8_t r[32], const uint8_t s[32],
                            char *proof_out, uint64_t proof_cap, char *public_out, uint64_t public_cap,

@@ -150,11 +150,19 @@ class _ProverBase:
         load().ug_prover_last_timings(self._h, C.byref(a), C.byref(b), C.byref(c))
         return a.value, b.value, c.value
 
-    def kernel_stats(self, g2=False, reset=False):
-        """(avg ms, launches, entries) of the G1 / G2 bucket-accumulation kernel since creation / last reset."""
+    def kernel_stats(self, g2=False, reset=False, which=None):
+        """(avg launch ms, launches, units) since creation / last reset of the G1 (which 0) / G2 (1) bucket-accumulation
+        kernel or the NTT pass kernel (2)."""
         a, l, e = C.c_double(), C.c_ulonglong(), C.c_ulonglong()
-        load().ug_prover_kernel_stats(self._h, 1 if g2 else 0, C.byref(a), C.byref(l), C.byref(e), 1 if reset else 0)
+        w = (1 if g2 else 0) if which is None else which
+        load().ug_prover_kernel_stats(self._h, w, C.byref(a), C.byref(l), C.byref(e), 1 if reset else 0)
         return a.value, l.value, e.value
+
+    def last_upload_ms(self):
+        """host wall time the last prove / load_witness spent bringing the witness into HBM"""
+        a = C.c_double()
+        load().ug_prover_last_upload_ms(self._h, C.byref(a))
+        return a.value
 
     def close(self):
         if getattr(self, "_h", None):
@@ -281,6 +289,7 @@ class ShardedGroth16Prover:
 
     last_timings = _ProverBase.last_timings
     kernel_stats = _ProverBase.kernel_stats
+    last_upload_ms = _ProverBase.last_upload_ms
 
     def close(self):
         if getattr(self, "_h", None):
@@ -474,9 +483,10 @@ class Device:
         _check(self._L.ug_ctx_timings(self._h, C.byref(a), C.byref(b), 1 if reset else 0))
         return a.value, b.value
 
-    def kernel_stats(self, g2=False, reset=False):
+    def kernel_stats(self, g2=False, reset=False, which=None):
         a, l, e = C.c_double(), C.c_uint64(), C.c_uint64()
-        _check(self._L.ug_ctx_kernel_stats(self._h, 1 if g2 else 0, C.byref(a), C.byref(l), C.byref(e), 1 if reset else 0))
+        w = (1 if g2 else 0) if which is None else which
+        _check(self._L.ug_ctx_kernel_stats(self._h, w, C.byref(a), C.byref(l), C.byref(e), 1 if reset else 0))
         return a.value, l.value, e.value
 
 

@@ -32,7 +32,7 @@ OUTER_SYMBOLS = [
     "groth16_prover_destroy", "ultra_groth_prover_destroy",
     "groth16_prover", "ultra_groth_prover",
     "groth16_prover_zkey_file", "ultra_groth_prover_zkey_file",
-    "ug_test_set_blinding", "ug_prover_last_timings", "ug_prover_kernel_stats",
+    "ug_test_set_blinding", "ug_prover_last_timings", "ug_prover_kernel_stats", "ug_prover_last_upload_ms",
     "ug_groth16_prover_create_sharded", "ug_groth16_prover_create_sharded_range",
     "ug_ultra_groth_prover_create_sharded", "ug_ultra_groth_prover_round_commit", "ug_ultra_groth_prover_round_finish",
     "ug_ultra_groth_prover_apply_commitment", "ug_g1_record_add",
@@ -130,6 +130,7 @@ def load():
     L.ug_test_set_blinding.argtypes = [vp, ull]; L.ug_test_set_blinding.restype = C.c_int
     L.ug_prover_last_timings.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ug_prover_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_double), pull, pull, C.c_int]
+    L.ug_prover_last_upload_ms.argtypes = [vp, C.POINTER(C.c_double)]
     L.ug_groth16_prover_create_sharded.argtypes = [pp, vp, ull, C.c_int, C.c_int, C.c_int, vp, ull]
     L.ug_ultra_groth_prover_create_sharded.argtypes = [pp, vp, ull, C.c_int, C.c_int, C.c_int, vp, ull]
     L.ug_ultra_groth_prover_round_commit.argtypes = [vp, vp, vp, ull]

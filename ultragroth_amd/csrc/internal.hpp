@@ -22,8 +22,9 @@ struct NttPlan {
     void release();
     // DIT transform; see ntt.hip for the buffer rules. post / post_const are optional multipliers
     // applied in the last pass: out[i] *= post[i], or out[i] *= *post_const.
+    // stats (optional): every pass launch is bracketed with an event pair (KernelStats::collect after a stream sync)
     void transform(u32* out, const u32* in, bool inverse, bool gather_bitrev, bool scatter_bitrev,
-                   const u32* post, const u32* post_const, hipStream_t stream) const;
+                   const u32* post, const u32* post_const, hipStream_t stream, struct MsmStats* stats = nullptr) const;
     ~NttPlan() { release(); }
 };
 
@@ -88,8 +89,9 @@ struct MsmWorkspace {
     ~MsmWorkspace() { release(); }
 };
 
-struct MsmStats {                 // HIP-event timing of the bucket-accumulation launches
-    static constexpr int SLOTS = 8;                 // launches that may be in flight before collect()
+struct MsmStats {                 // HIP-event timing of one kernel's launches (bucket accumulation G1 / G2, NTT passes)
+    static constexpr int SLOTS = 32;                // launches that may be in flight before collect()
+    static constexpr int MAX_BATCH = 8;             // MSMs queued back to back by ug_msm_batch
     hipEvent_t ev0[SLOTS] = {}, ev1[SLOTS] = {};
     u64 slot_entries[SLOTS] = {};
     int pending = 0;
@@ -97,7 +99,10 @@ struct MsmStats {                 // HIP-event timing of the bucket-accumulation
     void create();
     void destroy();
     void collect();                                 // after the stream has been synchronised
+    int begin(hipStream_t stream, u64 units);       // records the start event; returns the slot
+    void end(int slot, hipStream_t stream);
 };
+typedef MsmStats KernelStats;
 
 // An MSM whose kernels and result copy are queued on the stream; the window sums arrive in `host` (pinned memory,
 // bucket_windows * PT_WORDS words) once the stream is synchronised. Several may be queued back to back: the stream

@@ -789,19 +789,13 @@ MsmPending msm_enqueue(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases,
     u32 nb = (u32)g.total_buckets();
     u64 nseg = ((u64)s.n_valid + ((u64)1 << s.log_seg) - 1) >> s.log_seg;
     ws.reserve(g, Cfg::PT_WORDS == G2Cfg::PT_WORDS, nseg, s.n_heavy_tasks);
-    int slot = -1;
-    if (stats) {
-        if (stats->pending == MsmStats::SLOTS) throw std::logic_error("msm: too many launches in flight");
-        slot = stats->pending++;
-        stats->slot_entries[slot] = g.n * g.windows;
-        UG_HIP(hipEventRecord(stats->ev0[slot], stream));
-    }
+    int slot = stats ? stats->begin(stream, g.n * g.windows) : -1;
     if (nseg) {
         hipLaunchKernelGGL(segment_accumulate_kernel<Cfg>, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, stream,
                            bases, n_bases, delta, s.keys, s.tkeys, s.tvals, s.n_valid, s.log_seg, ws.bucket_pts, ws.slot_pts);
         UG_KERNEL_CHECK();
     }
-    if (stats) UG_HIP(hipEventRecord(stats->ev1[slot], stream));
+    if (stats) stats->end(slot, stream);
     if (nseg > 1) {
         hipLaunchKernelGGL(bucket_fixup_kernel<Cfg>, dim3((unsigned)((nseg + 127) / 128)), dim3(128), 0, stream,
                            s.keys, s.bucket_start, s.bucket_count, s.n_valid, (u32)nseg, s.log_seg, ws.slot_pts, ws.bucket_pts);
@@ -875,6 +869,14 @@ XYZZ<typename Cfg::F> msm_run(const MsmSchedule& s, MsmWorkspace& ws, const u32*
 
 void MsmStats::create() { for (int i = 0; i < SLOTS; i++) { UG_HIP(hipEventCreate(&ev0[i])); UG_HIP(hipEventCreate(&ev1[i])); } }
 void MsmStats::destroy() { for (int i = 0; i < SLOTS; i++) { if (ev0[i]) hipEventDestroy(ev0[i]); if (ev1[i]) hipEventDestroy(ev1[i]); ev0[i] = ev1[i] = nullptr; } }
+int MsmStats::begin(hipStream_t stream, u64 units) {
+    if (pending == SLOTS) throw std::logic_error("kernel stats: too many launches in flight");
+    int slot = pending++;
+    slot_entries[slot] = units;
+    UG_HIP(hipEventRecord(ev0[slot], stream));
+    return slot;
+}
+void MsmStats::end(int slot, hipStream_t stream) { UG_HIP(hipEventRecord(ev1[slot], stream)); }
 void MsmStats::collect() {
     for (int i = 0; i < pending; i++) {
         float ms = 0;

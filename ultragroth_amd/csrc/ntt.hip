@@ -213,7 +213,7 @@ void NttPlan::release() {
 // natural order, gathered on the fly); output natural order, or bit-reversed if scatter_bitrev.
 // post (optional) multiplies output element i (natural index) by post[i] in the last pass.
 void NttPlan::transform(u32* out, const u32* in, bool inverse, bool gather_bitrev, bool scatter_bitrev,
-                        const u32* post, const u32* post_const, hipStream_t stream) const {
+                        const u32* post, const u32* post_const, hipStream_t stream, MsmStats* stats) const {
     if (logn == 0) {
         if (out != in) UG_HIP(hipMemcpyAsync(out, in, 32, hipMemcpyDeviceToDevice, stream));
         return;   // size-1 transform is the identity (n^-1 = 1, omega_2^0 = 1)
@@ -249,8 +249,10 @@ void NttPlan::transform(u32* out, const u32* in, bool inverse, bool gather_bitre
         unsigned blocks = (unsigned)(((u64)1 << logn) >> (a.k + a.j));
         int threads = E / 2 > 1024 ? 1024 : (E / 2 < 64 ? 64 : E / 2);
         size_t lds = (size_t)E * NL * 4;
+        int slot = stats ? stats->begin(stream, (u64)1 << logn) : -1;
         hipLaunchKernelGGL(ntt_pass_kernel, dim3(blocks), dim3(threads), lds, stream, a);
         UG_KERNEL_CHECK();
+        if (stats) stats->end(slot, stream);
         s0 += stages[p];
     }
 }

@@ -265,6 +265,7 @@ struct ProverBase {        // what the extern "C" layer stores behind the opaque
     virtual unsigned long long publicBufferMinSize() const = 0;
     virtual void timings(double* msm, double* fft, double* total) const = 0;
     virtual ug_ctx* ctx() = 0;
+    double uploadMs = 0;             // host wall time of the last loadWitness
     // phases of a sharded proof (include/prover.h); both provers implement them
     [[noreturn]] static void noPhase() { throw std::invalid_argument("this prover object does not support the call"); }
     virtual void loadWitness(const void*, unsigned long long) { noPhase(); }
@@ -278,9 +279,9 @@ struct ProverBase {        // what the extern "C" layer stores behind the opaque
     virtual void roundCommit(uint8_t*) { noPhase(); }
     virtual void roundFinish(const uint8_t*, uint8_t*) { noPhase(); }
     virtual void applyCommitment(const uint8_t*) { noPhase(); }
-    virtual int kernelStats(int g2, double* avgMs, unsigned long long* launches, unsigned long long* entries, int reset) {
+    virtual int kernelStats(int which, double* avgMs, unsigned long long* launches, unsigned long long* entries, int reset) {
         uint64_t l = 0, e = 0;
-        int rc = ug_ctx_kernel_stats(ctx(), g2, avgMs, &l, &e, reset);
+        int rc = ug_ctx_kernel_stats(ctx(), which, avgMs, &l, &e, reset);
         if (launches) *launches = l;
         if (entries) *entries = e;
         return rc;
@@ -363,6 +364,7 @@ public:
     const ZkeyHeader& header() const { return hdr_; }
 
     void loadWitness(const void* wtns, unsigned long long wtnsSize) override {
+        auto t0 = std::chrono::steady_clock::now();
         BinFile f(wtns, wtnsSize, "wtns", 2);
         WtnsHeader wh = loadWtnsHeader(f);
         if (hdr_.nVars != wh.nVars)
@@ -373,6 +375,7 @@ public:
         publicPart_.assign(data, data + ((size_t)hdr_.nPublic + 1) * 32);
         ugCheck(ug_dvec_upload(d_.w, data, hdr_.nVars));
         witnessLoaded_ = true;
+        uploadMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 
     // S1-S4 on this rank's slice; partials = A | B1 | B2 | C | H affine records (H left at infinity)
@@ -479,11 +482,11 @@ public:
         memcpy(partials + 320, hpart + 320, 64);
         collectTimings();
     }
-    int kernelStats(int g2, double* avgMs, unsigned long long* launches, unsigned long long* entries, int reset) override {
+    int kernelStats(int which, double* avgMs, unsigned long long* launches, unsigned long long* entries, int reset) override {
         double a1 = 0, a2 = 0;
         uint64_t l1 = 0, l2 = 0, e1 = 0, e2 = 0;
-        if (ug_ctx_kernel_stats(d_.ctx, g2, &a1, &l1, &e1, reset) != UG_OK) return UG_ERROR;
-        if (ug_ctx_kernel_stats(d_.ctx2, g2, &a2, &l2, &e2, reset) != UG_OK) return UG_ERROR;
+        if (ug_ctx_kernel_stats(d_.ctx, which, &a1, &l1, &e1, reset) != UG_OK) return UG_ERROR;
+        if (ug_ctx_kernel_stats(d_.ctx2, which, &a2, &l2, &e2, reset) != UG_OK) return UG_ERROR;
         if (avgMs) *avgMs = (l1 + l2) ? (a1 * (double)l1 + a2 * (double)l2) / (double)(l1 + l2) : 0.0;
         if (launches) *launches = l1 + l2;
         if (entries) *entries = e1 + e2;
@@ -608,6 +611,7 @@ public:
 
     // ---- phases (a sharded proof calls them one by one, see include/prover.h; prove() below strings them together) ----
     void loadWitness(const void* wtns, unsigned long long wtnsSize) override {
+        auto tLoad0 = std::chrono::steady_clock::now();
         BinFile f(wtns, wtnsSize, "wtns", 2);
         WtnsHeader wh = loadWtnsHeader(f);
         if (hdr_.nVars != wh.nVars)
@@ -630,6 +634,7 @@ public:
         ugCheck(ug_dvec_upload(d_.w, signals0, M));
         mark("witness upload");
         witnessLoaded_ = true; committed_ = false; haveRoundScalar_ = false;
+        uploadMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tLoad0).count();
     }
 
     // round 1: this rank's part of the commitment to the round witnesses (ultra_groth.cpp:415-419, execute_round :161-184)
@@ -1031,11 +1036,16 @@ int ug_prover_last_timings(void* prover_object, double* msm_ms, double* fft_ms, 
     static_cast<ProverBase*>(prover_object)->timings(msm_ms, fft_ms, total_ms);
     return PROVER_OK;
 }
-int ug_prover_kernel_stats(void* prover_object, int g2, double* accumulate_ms_avg, unsigned long long* launches,
-                           unsigned long long* entries, int reset) {
+int ug_prover_kernel_stats(void* prover_object, int which, double* launch_ms_avg, unsigned long long* launches,
+                           unsigned long long* units, int reset) {
     if (!prover_object) return PROVER_ERROR;
-    int rc = static_cast<ProverBase*>(prover_object)->kernelStats(g2, accumulate_ms_avg, launches, entries, reset);
+    int rc = static_cast<ProverBase*>(prover_object)->kernelStats(which, launch_ms_avg, launches, units, reset);
     return rc == UG_OK ? PROVER_OK : PROVER_ERROR;
+}
+int ug_prover_last_upload_ms(void* prover_object, double* upload_ms) {
+    if (!prover_object || !upload_ms) return PROVER_ERROR;
+    *upload_ms = static_cast<ProverBase*>(prover_object)->uploadMs;
+    return PROVER_OK;
 }
 
 int ug_groth16_prover_create_sharded(void** prover_object, const void* zkey_buffer, unsigned long long zkey_size, int device,

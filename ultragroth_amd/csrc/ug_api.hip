@@ -1,9 +1,12 @@
 // ug_api.hip -- implementation of the inner C-ABI declared in include/ultragroth_hip.h.
 // Owns device memory, the stream and the reusable workspaces; translates between the reference's byte
 // formats and the device forms; catches every exception at the boundary.
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 #include <exception>
 #include "dev_common.hpp"
@@ -22,11 +25,78 @@ int fail(const std::string& msg) { g_last_error = msg; return UG_ERROR; }
     return UG_OK;
 }  // namespace
 
+// Host -> HBM copies of large caller buffers (the witness of every proof: 512 MiB at 2^24; the zkey sections at create:
+// 9.4 GB). The caller's memory is pageable (the reference's API hands over plain pointers, src/prover.h:127-138; a zkey
+// file is an mmap, src/fileloader.cpp:23-51), and one hipMemcpy from pageable memory runs at about half the PCIe rate
+// (measured 27 GB/s). Here LANES host threads each copy 8 MiB chunks into their own pinned buffers and queue the DMA on
+// their own stream, DEPTH chunks deep, so page-touching memcpy and DMA overlap; `after` (optional) is queued behind each
+// chunk's DMA on the same stream, e.g. the conversion kernel for that chunk's records. Blocking: returns when every
+// chunk and every `after` has completed.
+struct StagedUploader {
+    static constexpr size_t CHUNK = (size_t)8 << 20;
+    static constexpr int MAX_LANES = 8, DEPTH = 2;
+    static constexpr size_t MIN_BYTES = (size_t)32 << 20;      // below this a plain copy is as fast
+    struct Lane { hipStream_t stream = nullptr; uint8_t* buf[DEPTH] = {nullptr, nullptr}; hipEvent_t done[DEPTH] = {nullptr, nullptr}; };
+    Lane lanes[MAX_LANES];
+    int n_lanes = 0;
+    typedef std::function<void(size_t offset, size_t bytes, hipStream_t stream)> After;
+    void init() {
+        if (n_lanes) return;
+        int want = 4;
+        if (const char* e = getenv("ULTRAGROTH_UPLOAD_THREADS")) want = atoi(e);
+        want = want < 1 ? 1 : want > MAX_LANES ? MAX_LANES : want;
+        for (int l = 0; l < want; l++) {
+            UG_HIP(hipStreamCreateWithFlags(&lanes[l].stream, hipStreamNonBlocking));
+            for (int d = 0; d < DEPTH; d++) {
+                UG_HIP(hipHostMalloc((void**)&lanes[l].buf[d], CHUNK, hipHostMallocDefault));
+                UG_HIP(hipEventCreateWithFlags(&lanes[l].done[d], hipEventDisableTiming));
+            }
+            n_lanes = l + 1;
+        }
+    }
+    void upload(int device, void* dst, const void* src, size_t bytes, const After& after = After()) {
+        init();
+        const size_t n_chunks = (bytes + CHUNK - 1) / CHUNK;
+        std::exception_ptr errs[MAX_LANES];
+        auto work = [&](int l) {
+            try {
+                UG_HIP(hipSetDevice(device));
+                Lane& ln = lanes[l];
+                size_t turn = 0;
+                for (size_t c = (size_t)l; c < n_chunks; c += (size_t)n_lanes, turn++) {
+                    const int d = (int)(turn % DEPTH);
+                    if (turn >= DEPTH) UG_HIP(hipEventSynchronize(ln.done[d]));      // the DMA out of this buffer has finished
+                    const size_t off = c * CHUNK, len = bytes - off < CHUNK ? bytes - off : CHUNK;
+                    memcpy(ln.buf[d], static_cast<const uint8_t*>(src) + off, len);
+                    UG_HIP(hipMemcpyAsync(static_cast<uint8_t*>(dst) + off, ln.buf[d], len, hipMemcpyHostToDevice, ln.stream));
+                    UG_HIP(hipEventRecord(ln.done[d], ln.stream));
+                    if (after) after(off, len, ln.stream);
+                }
+                UG_HIP(hipStreamSynchronize(ln.stream));
+            } catch (...) { errs[l] = std::current_exception(); }
+        };
+        std::vector<std::thread> th;
+        for (int l = 1; l < n_lanes; l++) th.emplace_back(work, l);
+        work(0);
+        for (auto& t : th) t.join();
+        for (int l = 0; l < n_lanes; l++) if (errs[l]) std::rethrow_exception(errs[l]);
+    }
+    void release() {
+        for (int l = 0; l < n_lanes; l++) {
+            for (int d = 0; d < DEPTH; d++) { if (lanes[l].buf[d]) hipHostFree(lanes[l].buf[d]); if (lanes[l].done[d]) hipEventDestroy(lanes[l].done[d]); }
+            if (lanes[l].stream) hipStreamDestroy(lanes[l].stream);
+            lanes[l] = Lane();
+        }
+        n_lanes = 0;
+    }
+};
+
 struct ug_ctx {
     int device = 0;
+    StagedUploader uploader;
     hipStream_t stream = nullptr;
     MsmWorkspace ws_g1, ws_g2;
-    MsmStats stats[2];                     // [0] G1, [1] G2 bucket-accumulation launches
+    MsmStats stats[3];                     // [0] G1, [1] G2 bucket-accumulation launches, [2] NTT pass launches
     hipEvent_t t0 = nullptr, t1 = nullptr;
     double msm_ms = 0, fft_ms = 0;
     NttPlan raw_ntt;                       // cache for ug_fr_ntt
@@ -53,6 +123,15 @@ struct ug_hpoly {
 };
 
 namespace {
+// blocking copy of a caller buffer into device memory; `after` as in StagedUploader::upload (called once for a small copy)
+void host_to_device(ug_ctx* c, void* dst, const void* src, size_t bytes, const StagedUploader::After& after = StagedUploader::After()) {
+    if (!bytes) return;
+    UG_HIP(hipStreamSynchronize(c->stream));                   // nothing queued earlier may still read or write dst
+    if (bytes >= StagedUploader::MIN_BYTES) { c->uploader.upload(c->device, dst, src, bytes, after); return; }
+    UG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    if (after) after(0, bytes, c->stream);
+    UG_HIP(hipStreamSynchronize(c->stream));
+}
 struct ScopedTimer {       // accumulates stream time between construction and stop()
     ug_ctx* c; double* acc;
     ScopedTimer(ug_ctx* c_, double* acc_) : c(c_), acc(acc_) { UG_HIP(hipEventRecord(c->t0, c->stream)); }
@@ -89,8 +168,8 @@ int ug_ctx_create(ug_ctx** out, int device) {
     c->use();
     UG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     UG_HIP(hipEventCreate(&c->t0)); UG_HIP(hipEventCreate(&c->t1));
-    for (int k = 0; k < 2; k++) c->stats[k].create();
-    UG_HIP(hipHostMalloc((void**)&c->pinned_results, (size_t)MsmStats::SLOTS * MSM_PENDING_WORDS * 4, hipHostMallocDefault));
+    for (int k = 0; k < 3; k++) c->stats[k].create();
+    UG_HIP(hipHostMalloc((void**)&c->pinned_results, (size_t)MsmStats::MAX_BATCH * MSM_PENDING_WORDS * 4, hipHostMallocDefault));
     *out = c;
     UG_CATCH
 }
@@ -98,10 +177,10 @@ void ug_ctx_destroy(ug_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    c->ws_g1.release(); c->ws_g2.release(); c->raw_ntt.release();
+    c->ws_g1.release(); c->ws_g2.release(); c->raw_ntt.release(); c->uploader.release();
     if (c->lookup_last) hipFree(c->lookup_last);
     hipEventDestroy(c->t0); hipEventDestroy(c->t1);
-    for (int k = 0; k < 2; k++) c->stats[k].destroy();
+    for (int k = 0; k < 3; k++) c->stats[k].destroy();
     if (c->pinned_results) hipHostFree(c->pinned_results);
     hipStreamDestroy(c->stream);
     delete c;
@@ -121,9 +200,15 @@ static int bases_create(ug_ctx* c, const void* host, u64 n, u64 global_first, bo
     size_t bytes = (size_t)n * (g2 ? 128 : 64);
     UG_HIP(hipMalloc(&b->pts, bytes ? bytes : 4));
     if (n) {
-        UG_HIP(hipMemcpyAsync(b->pts, host, bytes, hipMemcpyHostToDevice, c->stream));
-        if (g2) convert_points_g2(b->pts, n, c->stream); else convert_points_g1(b->pts, n, c->stream);
-        UG_HIP(hipStreamSynchronize(c->stream));
+        // each chunk's records are converted to the device form behind its own DMA (chunks are whole records: 8 MiB / 128)
+        const size_t rec = g2 ? 128 : 64;
+        u32* pts = b->pts;
+        try {
+            host_to_device(c, pts, host, bytes, [pts, rec, g2](size_t off, size_t len, hipStream_t st) {
+                u32* p = pts + off / 4;
+                if (g2) convert_points_g2(p, len / rec, st); else convert_points_g1(p, len / rec, st);
+            });
+        } catch (...) { hipFree(b->pts); delete b; throw; }
     }
     *out = b;
     UG_CATCH
@@ -190,8 +275,7 @@ int ug_dvec_upload(ug_dvec* v, const void* host, uint64_t n) {
     if (!v || (!host && n)) throw std::invalid_argument("null argument");
     if (n > v->n) throw std::invalid_argument("upload larger than the vector");
     v->ctx->use();
-    if (n) UG_HIP(hipMemcpyAsync(v->data, host, (size_t)n * 32, hipMemcpyHostToDevice, v->ctx->stream));
-    UG_HIP(hipStreamSynchronize(v->ctx->stream));
+    host_to_device(v->ctx, v->data, host, (size_t)n * 32);
     UG_CATCH
 }
 int ug_dvec_download(const ug_dvec* v, void* host, uint64_t first, uint64_t n) {
@@ -407,14 +491,14 @@ int ug_msm_batch(ug_ctx* c, int count, const ug_bases* const* bases, const ug_sc
                  void* const* outs) {
     UG_TRY
     if (!c || !s || (count && (!bases || !outs))) throw std::invalid_argument("null argument");
-    if (count < 0 || count > MsmStats::SLOTS) throw std::invalid_argument("at most 8 products per batch");
+    if (count < 0 || count > MsmStats::MAX_BATCH) throw std::invalid_argument("at most 8 products per batch");
     for (int k = 0; k < count; k++) {
         if (!bases[k] || !outs[k]) throw std::invalid_argument("null argument");
         check_tables(bases[k], s);
     }
     c->use();
     ScopedTimer tm(c, &c->msm_ms);
-    MsmPending pend[MsmStats::SLOTS];
+    MsmPending pend[MsmStats::MAX_BATCH];
     for (int k = 0; k < count; k++) {
         const ug_bases* b = bases[k];
         int64_t delta = (int64_t)s->first - (index_shifts ? index_shifts[k] : 0) - (int64_t)b->global_first;
@@ -443,7 +527,7 @@ int ug_hpoly_create(ug_ctx* c, const void* host_coefs, uint64_t n_coefs, uint32_
     UG_HIP(hipMalloc(&raw, n_coefs ? (size_t)n_coefs * 44 : 4));
     bool ok = false;
     try {
-        if (n_coefs) UG_HIP(hipMemcpyAsync(raw, host_coefs, (size_t)n_coefs * 44, hipMemcpyHostToDevice, c->stream));
+        host_to_device(c, raw, host_coefs, (size_t)n_coefs * 44);
         ok = hp->mat.build(raw, n_coefs, domain, n_vars, c->stream);
     } catch (...) { hipFree(raw); throw; }
     hipFree(raw);
@@ -473,12 +557,13 @@ int ug_hpoly_run(ug_hpoly* hp, const ug_dvec* w, ug_dvec* h_out) {
     // S8: ifft, twist by omega_2n^i (with 1/n folded in), fft          :110-140
     u32* polys[3] = {hp->a, hp->b, hp->c};
     for (int p = 0; p < 3; p++) {
-        hp->ntt.transform(hp->t, polys[p], /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st);
-        hp->ntt.transform(polys[p], hp->t, /*inverse*/ false, false, false, nullptr, nullptr, st);
+        hp->ntt.transform(hp->t, polys[p], /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, &c->stats[2]);
+        hp->ntt.transform(polys[p], hp->t, /*inverse*/ false, false, false, nullptr, nullptr, st, &c->stats[2]);
     }
     // S9: h = a o b - c, to plain integers                             :142-148
     fr_h_final(h_out->data, hp->a, hp->b, hp->c, n, st);
     tm.stop();
+    c->stats[2].collect();
     UG_CATCH
 }
 
@@ -504,9 +589,10 @@ int ug_hpoly_chain(ug_hpoly* hp, const ug_dvec* w, int which, ug_dvec* out) {
         coef_matvec(hp->a, hp->b, hp->mat, w->data, 1 << which, st);
         src = which ? hp->b : hp->a;
     }
-    hp->ntt.transform(hp->t, src, /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st);
-    hp->ntt.transform(out->data, hp->t, /*inverse*/ false, false, false, nullptr, nullptr, st);
+    hp->ntt.transform(hp->t, src, /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, &c->stats[2]);
+    hp->ntt.transform(out->data, hp->t, /*inverse*/ false, false, false, nullptr, nullptr, st, &c->stats[2]);
     tm.stop();
+    c->stats[2].collect();
     UG_CATCH
 }
 // h[first .. first + count) = plain(a o b - c) from the matching slices of the three coset evaluation vectors
@@ -615,10 +701,11 @@ int ug_ctx_timings(ug_ctx* c, double* msm_ms, double* fft_ms, int reset) {
     if (reset) { c->msm_ms = 0; c->fft_ms = 0; }
     UG_CATCH
 }
-int ug_ctx_kernel_stats(ug_ctx* c, int g2, double* avg_ms, uint64_t* launches, uint64_t* entries, int reset) {
+int ug_ctx_kernel_stats(ug_ctx* c, int which, double* avg_ms, uint64_t* launches, uint64_t* entries, int reset) {
     UG_TRY
     if (!c) throw std::invalid_argument("null argument");
-    MsmStats& st = c->stats[g2 ? 1 : 0];
+    if (which < 0 || which > 2) throw std::invalid_argument("kernel stats: 0 = G1 accumulation, 1 = G2 accumulation, 2 = NTT pass");
+    MsmStats& st = c->stats[which];
     if (avg_ms) *avg_ms = st.launches ? st.accumulate_ms / (double)st.launches : 0.0;
     if (launches) *launches = st.launches;
     if (entries) *entries = st.entries;

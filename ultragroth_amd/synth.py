@@ -142,12 +142,19 @@ def build_circuit(dev, log_domain, mix="U", seed=0x5EED0000, n_public=1, g1_only
         synth_points(dev, n_c, SEEDS["C"], out=view[at[8][0]:at[8][1]])
     synth_points(dev, domain, SEEDS["H"], out=view[at[9][0]:at[9][1]])
     del view
+    wtns = build_witness(log_domain, mix, seed)
+    info = dict(domainSize=domain, nVars=nvars, nPublic=n_public, nCoefs=n_coefs, mix=mix, seed=seed, g1_only=g1_only)
+    return zkey, wtns, info
+
+
+def build_witness(log_domain, mix="U", seed=0x5EED0000):
+    """the .wtns of build_circuit(log_domain, mix, seed) alone (the zkey does not depend on the mix)"""
+    nvars = (1 << log_domain) - 1
+    r_le = R_MOD.to_bytes(32, "little")
     w = scalars(nvars, mix, seed + 2)
     w[0] = (1, 0, 0, 0)
     wtns = b"wtns" + struct.pack("<II", 2, 2) + _section(1, struct.pack("<I", 32) + r_le + struct.pack("<I", nvars))
-    wtns += struct.pack("<IQ", 2, w.nbytes) + w.tobytes()
-    info = dict(domainSize=domain, nVars=nvars, nPublic=n_public, nCoefs=n_coefs, mix=mix, seed=seed, g1_only=g1_only)
-    return zkey, wtns, info
+    return wtns + struct.pack("<IQ", 2, w.nbytes) + w.tobytes()
 
 
 def build_ultra_circuit(dev, log_domain, mix="C", seed=0x5EED0005, lookup_log=8):
