@@ -123,6 +123,31 @@ int ug_prover_kernel_stats(void *prover_object, int which, double *launch_ms_avg
 /* host wall-clock milliseconds the last prove spent bringing the witness into HBM (parse + host-to-device copy) */
 int ug_prover_last_upload_ms(void *prover_object, double *upload_ms);
 
+/* ---- resident multi-circuit prover ---------------------------------------------------------------------
+ * The GPU form of FullProver's map<circuit, Prover> (src/fullprover.cpp:21-63; its HTTP shell and witness calculator
+ * are out of scope): several created provers -- Groth16 and UltraGroth, told apart by the zkey's protocol field --
+ * share one device under an HBM budget (0 = all the memory free at creation). When the budget is short the registry
+ * gives back, least recently used circuit first: fixed-base window tables (a circuit without them proves with the
+ * classic windows, only slower), then per-proof workspaces, then whole circuits; a circuit that was loaded from a file
+ * and evicted comes back by itself on its next ug_registry_prove. Proofs of different circuits take turns on the
+ * device (the reference answers `busy`, src/fullprover.cpp:82-101). Return codes and messages as the prover calls. */
+int ug_registry_create(void **registry, int device, unsigned long long hbm_budget_bytes, char *error_msg,
+                       unsigned long long error_msg_maxsize);
+int ug_registry_load(void *registry, const char *circuit, const void *zkey_buffer, unsigned long long zkey_size,
+                     char *error_msg, unsigned long long error_msg_maxsize);
+/* circuit name = file name without directory and extension (getfilename(), src/fullprover.cpp:14-19) */
+int ug_registry_load_file(void *registry, const char *zkey_file_path, char *error_msg, unsigned long long error_msg_maxsize);
+int ug_registry_prove(void *registry, const char *circuit, const void *wtns_buffer, unsigned long long wtns_size,
+                      char *proof_buffer, unsigned long long *proof_size, char *public_buffer,
+                      unsigned long long *public_size, char *error_msg, unsigned long long error_msg_maxsize);
+int ug_registry_evict(void *registry, const char *circuit, char *error_msg, unsigned long long error_msg_maxsize);
+/* circuit != NULL: its resident bytes, state (0 not loaded, 1 resident without tables, 2 resident with tables,
+ * 3 evicted but reloadable from its file) and proof count. circuit == NULL: device bytes in use by the registry,
+ * number of resident circuits (in *state), proofs made. */
+int ug_registry_info(void *registry, const char *circuit, unsigned long long *resident_bytes, int *state,
+                     unsigned long long *proofs);
+void ug_registry_destroy(void *registry);
+
 /* Sharded Groth16 proving, one process per GPU. Rank `shard_rank` of `shard_count` holds the base points
  * [rank * n / count, (rank + 1) * n / count) of every section and produces partial sums; the partial
  * sums of all ranks are added (ug_groth16_partials_add) and finished on one rank.

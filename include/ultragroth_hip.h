@@ -77,6 +77,9 @@ int  ug_bases_create_g2(ug_ctx* ctx, const void* host_points, uint64_t n, uint64
 int      ug_msm_table_window(uint64_t n);
 uint64_t ug_bases_tables_bytes(uint64_t n, int g2, int c);
 int      ug_bases_precompute(ug_bases* b, int c);
+/* give the tables' memory back (the set keeps its n points; schedules must then be built without tables) */
+int      ug_bases_drop_tables(ug_bases* b);
+int      ug_bases_table_window(const ug_bases* b);          /* width of the tables held, 0 = none */
 int      ug_ctx_mem_info(ug_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 void ug_bases_destroy(ug_bases* b);
 
@@ -108,6 +111,10 @@ void ug_dvec_destroy(ug_dvec* v);
 /* Decompose scalars [first, first + count) of `scalars` (plain 32-byte integers) into signed window
  * digits grouped by bucket. One schedule serves every base set multiplied by the same scalars. */
 int  ug_schedule_create(ug_ctx* ctx, ug_schedule** out);
+/* release the device buffers of a schedule / of a context's MSM workspaces (they are re-allocated by the next build /
+ * product): what a resident multi-circuit prover trims first when HBM is short */
+int  ug_schedule_trim(ug_schedule* s);
+int  ug_ctx_trim(ug_ctx* ctx);
 int  ug_schedule_build(ug_schedule* s, const ug_dvec* scalars, uint64_t first, uint64_t count);
 /* the same for base sets that hold window tables of width c (ug_bases_precompute); count <= 2^27 */
 int  ug_schedule_build_tables(ug_schedule* s, const ug_dvec* scalars, uint64_t first, uint64_t count, int c);

@@ -206,6 +206,64 @@ def ultra_groth_prover(zkey, wtns):
         return p.prove(wtns)
 
 
+class Registry:
+    """ug_registry_* (include/prover.h): several resident circuits on one device under an HBM budget -- the GPU form of
+    the reference's FullProver map<circuit, Prover> (src/fullprover.cpp:21-63)."""
+    NOT_LOADED, RESIDENT, RESIDENT_WITH_TABLES, EVICTED = 0, 1, 2, 3
+
+    def __init__(self, device=0, hbm_budget_bytes=0):
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(1024)
+        rc = load().ug_registry_create(C.byref(self._h), device, hbm_budget_bytes, err, len(err) - 1)
+        if rc != PROVER_OK:
+            self._h = None
+            raise ProverError(rc, err.value.decode(errors="replace"))
+
+    def _call(self, name, *args):
+        err = C.create_string_buffer(1024)
+        rc = getattr(load(), name)(self._h, *args, err, len(err) - 1)
+        if rc != PROVER_OK:
+            raise ProverError(rc, err.value.decode(errors="replace"))
+
+    def load(self, circuit, zkey):
+        self._call("ug_registry_load", circuit.encode(), zkey, len(zkey))
+
+    def load_file(self, path):
+        self._call("ug_registry_load_file", path.encode())
+
+    def prove(self, circuit, wtns, proof_size=1400, public_size=1 << 16):
+        psz, qsz = C.c_ulonglong(proof_size), C.c_ulonglong(public_size)
+        proof, pub = C.create_string_buffer(psz.value), C.create_string_buffer(qsz.value)
+        self._call("ug_registry_prove", circuit.encode(), wtns, len(wtns), proof, C.byref(psz), pub, C.byref(qsz))
+        return proof.raw.split(b"\0", 1)[0].decode(), pub.raw.split(b"\0", 1)[0].decode()
+
+    def evict(self, circuit):
+        self._call("ug_registry_evict", circuit.encode())
+
+    def info(self, circuit=None):
+        """(resident bytes, state, proofs) of a circuit; (bytes in use, resident circuits, proofs) for circuit=None"""
+        b, st, n = C.c_ulonglong(), C.c_int(), C.c_ulonglong()
+        load().ug_registry_info(self._h, circuit.encode() if circuit else None, C.byref(b), C.byref(st), C.byref(n))
+        return b.value, st.value, n.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().ug_registry_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 class ShardedGroth16Prover:
     """One rank of a base-point-sharded Groth16 prover (one process per GPU): see include/prover.h."""
 

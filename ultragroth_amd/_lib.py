@@ -20,6 +20,7 @@ INNER_SYMBOLS = [
     "ug_msm_g1", "ug_msm_g2", "ug_msm_batch",
     "ug_hpoly_create", "ug_hpoly_run", "ug_hpoly_chain", "ug_hpoly_combine", "ug_hpoly_debug_abc", "ug_hpoly_destroy",
     "ug_fr_ntt", "ug_field_op", "ug_synth_points", "ug_ctx_timings", "ug_ctx_kernel_stats",
+    "ug_bases_drop_tables", "ug_bases_table_window", "ug_schedule_trim", "ug_ctx_trim",
 ]
 VERIFIER_SYMBOLS = ["groth16_verify", "ultra_groth_verify"]        # include/verifier.h
 OUTER_SYMBOLS = [
@@ -32,6 +33,8 @@ OUTER_SYMBOLS = [
     "groth16_prover_destroy", "ultra_groth_prover_destroy",
     "groth16_prover", "ultra_groth_prover",
     "groth16_prover_zkey_file", "ultra_groth_prover_zkey_file",
+    "ug_registry_create", "ug_registry_load", "ug_registry_load_file", "ug_registry_prove", "ug_registry_evict", "ug_registry_info",
+    "ug_registry_destroy",
     "ug_test_set_blinding", "ug_prover_last_timings", "ug_prover_kernel_stats", "ug_prover_last_upload_ms",
     "ug_groth16_prover_create_sharded", "ug_groth16_prover_create_sharded_range",
     "ug_ultra_groth_prover_create_sharded", "ug_ultra_groth_prover_round_commit", "ug_ultra_groth_prover_round_finish",
@@ -131,6 +134,13 @@ def load():
     L.ug_prover_last_timings.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ug_prover_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_double), pull, pull, C.c_int]
     L.ug_prover_last_upload_ms.argtypes = [vp, C.POINTER(C.c_double)]
+    L.ug_registry_create.argtypes = [pp, C.c_int, ull, vp, ull]
+    L.ug_registry_load.argtypes = [vp, C.c_char_p, vp, ull, vp, ull]
+    L.ug_registry_load_file.argtypes = [vp, C.c_char_p, vp, ull]
+    L.ug_registry_prove.argtypes = [vp, C.c_char_p, vp, ull, vp, pull, vp, pull, vp, ull]
+    L.ug_registry_evict.argtypes = [vp, C.c_char_p, vp, ull]
+    L.ug_registry_info.argtypes = [vp, C.c_char_p, pull, C.POINTER(C.c_int), pull]
+    L.ug_registry_destroy.argtypes = [vp]; L.ug_registry_destroy.restype = None
     L.ug_groth16_prover_create_sharded.argtypes = [pp, vp, ull, C.c_int, C.c_int, C.c_int, vp, ull]
     L.ug_ultra_groth_prover_create_sharded.argtypes = [pp, vp, ull, C.c_int, C.c_int, C.c_int, vp, ull]
     L.ug_ultra_groth_prover_round_commit.argtypes = [vp, vp, vp, ull]

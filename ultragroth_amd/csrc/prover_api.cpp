@@ -18,6 +18,7 @@
 #include <mutex>
 #include <exception>
 #include <future>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -225,12 +226,12 @@ constexpr uint64_t TABLES_MIN_SCALARS = (uint64_t)1 << 14, TABLES_MAX_SCALARS = 
 
 thread_local bool g_oneShotProver = false;      // create + one prove + destroy (groth16_prover, the CLIs): tables cannot pay
 
-void planWindowTables(ug_ctx* ctx, std::vector<TableGroup>& groups) {
-    for (auto& g : groups) *g.c = 0;
-    const char* e = getenv("ULTRAGROTH_TABLES");
-    if ((e && e[0] == '0') || (g_oneShotProver && !(e && e[0] == '2'))) return;     // "2": tables even for one-shot calls
+thread_local bool g_registryCreate = false;     // the resident multi-circuit prover decides about tables itself, after create
+
+// what the tables of all groups would take (0: no group qualifies) and the schedule workspace they imply
+uint64_t tablesNeed(const std::vector<TableGroup>& groups, std::vector<int>& width, uint64_t* workspaceOut) {
     uint64_t need = 0, workspace = (uint64_t)2 << 30;
-    std::vector<int> width(groups.size(), 0);
+    width.assign(groups.size(), 0);
     for (size_t k = 0; k < groups.size(); k++) {
         const TableGroup& g = groups[k];
         if (g.scalars < TABLES_MIN_SCALARS || g.scalars > TABLES_MAX_SCALARS) continue;
@@ -240,17 +241,39 @@ void planWindowTables(ug_ctx* ctx, std::vector<TableGroup>& groups) {
         for (uint64_t n : g.n2) need += ug_bases_tables_bytes(n, 1, c);
         workspace += 24 * g.scalars * (uint64_t)((255 + c - 1) / c);       // sorted entries + segment slots
     }
-    if (!need) return;
+    if (workspaceOut) *workspaceOut = workspace;
+    return need;
+}
+// builds the tables when the environment allows them and `need + workspace` fits the free device memory and `limit`
+// (bytes the caller is ready to spend, ~0 = no limit of its own); returns the bytes taken (0: classic windows stay)
+uint64_t planWindowTables(ug_ctx* ctx, std::vector<TableGroup>& groups, uint64_t limit = ~(uint64_t)0, bool force = false) {
+    for (auto& g : groups) *g.c = 0;
+    const char* e = getenv("ULTRAGROTH_TABLES");
+    if (e && e[0] == '0') return 0;
+    if (!force && (g_registryCreate || (g_oneShotProver && !(e && e[0] == '2')))) return 0;     // "2": tables even for one-shot calls
+    std::vector<int> width;
+    uint64_t workspace = 0;
+    const uint64_t need = tablesNeed(groups, width, &workspace);
+    if (!need) return 0;
     uint64_t freeB = 0, totalB = 0;
     ugCheck(ug_ctx_mem_info(ctx, &freeB, &totalB));
-    if (need + workspace > freeB) return;
+    if (need + workspace > freeB || need > limit) return 0;
+    uint64_t taken = 0;
     for (size_t k = 0; k < groups.size(); k++) {
         if (!width[k]) continue;
         bool ok = true;
         for (ug_bases* b : groups[k].g1) ok = ok && ug_bases_precompute(b, width[k]) == 0;
         for (ug_bases* b : groups[k].g2) ok = ok && ug_bases_precompute(b, width[k]) == 0;
-        if (ok) *groups[k].c = width[k];       // a group left half built keeps using table 0 of each set
+        if (ok) {
+            *groups[k].c = width[k];
+            for (uint64_t n : groups[k].n1) taken += ug_bases_tables_bytes(n, 0, width[k]);
+            for (uint64_t n : groups[k].n2) taken += ug_bases_tables_bytes(n, 1, width[k]);
+        } else {                               // a group left half built gives its memory back and keeps the classic windows
+            for (ug_bases* b : groups[k].g1) ug_bases_drop_tables(b);
+            for (ug_bases* b : groups[k].g2) ug_bases_drop_tables(b);
+        }
     }
+    return taken;
 }
 void buildSchedule(ug_schedule* s, const ug_dvec* scalars, uint64_t first, uint64_t count, int tableC) {
     if (tableC) ugCheck(ug_schedule_build_tables(s, scalars, first, count, tableC));
@@ -266,6 +289,29 @@ struct ProverBase {        // what the extern "C" layer stores behind the opaque
     virtual void timings(double* msm, double* fft, double* total) const = 0;
     virtual ug_ctx* ctx() = 0;
     double uploadMs = 0;             // host wall time of the last loadWitness
+    // HBM residency control (the resident multi-circuit prover, ug_registry_*): fixed-base tables are optional and the
+    // first thing given back; the per-proof workspaces (schedules, buckets) are re-grown by the next proof
+    uint64_t tableBytes = 0;
+    virtual std::vector<TableGroup> tableGroups() = 0;
+    uint64_t tablesWouldTake() { std::vector<TableGroup> g = tableGroups(); std::vector<int> w; return tablesNeed(g, w, nullptr); }
+    bool buildTables(uint64_t limit) {
+        if (tableBytes) return true;
+        std::lock_guard<std::mutex> turn(proveMutex);
+        std::vector<TableGroup> g = tableGroups();
+        tableBytes = planWindowTables(ctx(), g, limit, /*force*/ true);
+        return tableBytes != 0;
+    }
+    void dropTables() {
+        std::lock_guard<std::mutex> turn(proveMutex);
+        std::vector<TableGroup> g = tableGroups();
+        for (auto& grp : g) {
+            for (ug_bases* b : grp.g1) ug_bases_drop_tables(b);
+            for (ug_bases* b : grp.g2) ug_bases_drop_tables(b);
+            *grp.c = 0;
+        }
+        tableBytes = 0;
+    }
+    virtual void trimWorkspaces() = 0;
     // phases of a sharded proof (include/prover.h); both provers implement them
     [[noreturn]] static void noPhase() { throw std::invalid_argument("this prover object does not support the call"); }
     virtual void loadWitness(const void*, unsigned long long) { noPhase(); }
@@ -350,15 +396,26 @@ public:
             uint64_t v = strtoull(mr, nullptr, 10);
             if (v >= 1 && v < MAX_RANGE) maxRange_ = v;
         }
+        cLo_ = cLo; cHi_ = cHi;
+        std::vector<TableGroup> groups = tableGroups();
+        tableBytes = planWindowTables(d_.ctx, groups);
+    }
+
+    std::vector<TableGroup> tableGroups() override {
         std::vector<TableGroup> groups(2);
-        groups[0].g1 = {d_.A, d_.B1, d_.C}; groups[0].n1 = {wr_.hi - wr_.lo, wr_.hi - wr_.lo, cHi - cLo};
+        groups[0].g1 = {d_.A, d_.B1, d_.C}; groups[0].n1 = {wr_.hi - wr_.lo, wr_.hi - wr_.lo, cHi_ - cLo_};
         groups[0].g2 = {d_.B2}; groups[0].n2 = {wr_.hi - wr_.lo};
         groups[0].scalars = wr_.hi - wr_.lo; groups[0].c = &tableW_;
         if (wr_.hi - wr_.lo > maxRange_) groups[0].scalars = 0;          // proved in pieces: classic windows per piece
         groups[1].g1 = {d_.H}; groups[1].n1 = {hr_.hi - hr_.lo};
         groups[1].scalars = hr_.hi - hr_.lo; groups[1].c = &tableH_;
         if (hr_.hi - hr_.lo > maxRange_) groups[1].scalars = 0;
-        planWindowTables(d_.ctx, groups);
+        return groups;
+    }
+    void trimWorkspaces() override {
+        std::lock_guard<std::mutex> turn(proveMutex);
+        ug_schedule_trim(d_.sw); ug_schedule_trim(d_.sh);
+        ug_ctx_trim(d_.ctx); ug_ctx_trim(d_.ctx2);
     }
 
     const ZkeyHeader& header() const { return hdr_; }
@@ -538,6 +595,7 @@ private:
     ZkeyHeader hdr_;
     std::vector<uint8_t> vk_, publicPart_;
     Range wr_{0, 0}, hr_{0, 0};
+    uint64_t cLo_ = 0, cHi_ = 0;       // this rank's slice of the C section
     DeviceProver d_;
     bool witnessLoaded_ = false;
     double msmMs_ = 0, fftMs_ = 0, totalMs_ = 0;
@@ -597,6 +655,11 @@ public:
         ugCheck(ug_schedule_create(d_.ctx, &d_.saux));
         ugCheck(ug_index_create(d_.ctx, roundIdx_.data(), roundIdx_.size(), &d_.roundIdx));
         ugCheck(ug_index_create(d_.ctx, finalIdx_.data(), finalIdx_.size(), &d_.finalIdx));
+        std::vector<TableGroup> groups = tableGroups();
+        tableBytes = planWindowTables(d_.ctx, groups);
+    }
+
+    std::vector<TableGroup> tableGroups() override {
         std::vector<TableGroup> groups(4);
         const uint64_t nw = wr_.hi - wr_.lo;
         groups[0].g1 = {d_.A, d_.B1}; groups[0].n1 = {nw, nw}; groups[0].g2 = {d_.B2}; groups[0].n2 = {nw};
@@ -604,7 +667,12 @@ public:
         groups[1].g1 = {d_.roundC}; groups[1].n1 = {roundIdx_.size()}; groups[1].scalars = roundIdx_.size(); groups[1].c = &tableC1_;
         groups[2].g1 = {d_.C}; groups[2].n1 = {finalIdx_.size()}; groups[2].scalars = finalIdx_.size(); groups[2].c = &tableC2_;
         groups[3].g1 = {d_.H}; groups[3].n1 = {hr_.hi - hr_.lo}; groups[3].scalars = hr_.hi - hr_.lo; groups[3].c = &tableH_;
-        planWindowTables(d_.ctx, groups);
+        return groups;
+    }
+    void trimWorkspaces() override {
+        std::lock_guard<std::mutex> turn(proveMutex);
+        ug_schedule_trim(d_.sw); ug_schedule_trim(d_.sh); ug_schedule_trim(d_.saux);
+        ug_ctx_trim(d_.ctx);
     }
 
     const ZkeyHeader& header() const { return hdr_; }
@@ -859,6 +927,187 @@ private:
 };
 
 // =================================================================================================================
+// Resident multi-circuit prover: the GPU form of FullProver's map<circuit, Prover> (src/fullprover.cpp:21-63), without
+// its HTTP shell and witness calculator. Several created provers share one device under an HBM budget. What is given
+// back when the budget is short, in this order, always from the least recently used circuit first:
+//   1. fixed-base window tables (optional per circuit: a circuit without them proves with the classic windows),
+//   2. per-proof workspaces (schedules, buckets: re-grown by the circuit's next proof),
+//   3. whole circuits (a circuit loaded from a file comes back on demand; one loaded from a buffer must be loaded again).
+// Residency is measured, not estimated: bytes in use = free device memory at registry creation - free now.
+class Registry {
+public:
+    Registry(int device, uint64_t budget) : device_(device), budget_(budget) {
+        ugCheck(ug_ctx_create(&probe_, device));
+        uint64_t total = 0;
+        ugCheck(ug_ctx_mem_info(probe_, &baselineFree_, &total));
+        if (!budget_ || budget_ > baselineFree_) budget_ = baselineFree_;
+    }
+    ~Registry() {
+        entries_.clear();
+        ug_ctx_destroy(probe_);
+    }
+    static std::string circuitName(const std::string& path) {              // getfilename(), src/fullprover.cpp:14-19
+        std::string f = path.substr(path.find_last_of("/\\") + 1);
+        return f.substr(0, f.find_last_of('.'));
+    }
+    void load(const std::string& name, const void* zkey, uint64_t size, const std::string& path) {
+        std::lock_guard<std::mutex> lock(mutex_);
+        if (name.empty()) throw std::invalid_argument("empty circuit name");
+        entries_.erase(name);
+        // the header tells the protocol (1 = groth16, 1337 = ultragroth, src/zkey_utils.cpp:48-50,129-131)
+        BinFile f(zkey, size, "zkey", 1);
+        if (f.sectionSize(1) < 4) throw std::range_error("Invalid section size");
+        uint32_t protocol;
+        memcpy(&protocol, f.sectionData(1), 4);
+        const uint64_t before = used();
+        std::unique_ptr<Entry> e(new Entry());
+        e->name = name; e->path = path; e->ultra = protocol == 1337;
+        g_registryCreate = true;
+        try {
+            if (e->ultra) e->prover.reset(new UltraGrothProver(zkey, size, device_));
+            else e->prover.reset(new Groth16Prover(zkey, size, device_, 0, 1));
+        } catch (...) { g_registryCreate = false; throw; }
+        g_registryCreate = false;
+        e->coreBytes = used() - before;
+        e->lastUsed = ++tick_;
+        Entry* raw = e.get();
+        entries_[name] = std::move(e);
+        if (!makeRoom(0, raw)) {
+            entries_.erase(name);
+            throw std::runtime_error("circuit " + name + " does not fit the HBM budget");
+        }
+        growTables();
+    }
+    void loadFile(const std::string& path) {
+        FileMap m(path);
+        load(circuitName(path), m.data(), m.size(), path);
+    }
+    void prove(const std::string& name, const void* wtns, uint64_t wtnsSize, std::string& proof, std::string& pub,
+               unsigned long long* proofSize, unsigned long long* publicSize) {
+        Entry* e = nullptr;
+        {
+            std::unique_lock<std::mutex> lock(mutex_);
+            auto it = entries_.find(name);
+            if (it == entries_.end()) {
+                auto ev = evictedPaths_.find(name);
+                if (ev == evictedPaths_.end()) throw std::invalid_argument("circuit not loaded: " + name);
+                const std::string path = ev->second;          // evicted under memory pressure: its file brings it back
+                evictedPaths_.erase(ev);
+                lock.unlock();
+                loadFile(path);
+                lock.lock();
+                it = entries_.find(name);
+                if (it == entries_.end()) throw std::runtime_error("circuit could not be reloaded: " + name);
+            }
+            e = it->second.get();
+            e->lastUsed = ++tick_;
+            checkBufferSizes(e->prover->proofBufferMinSize(), proofSize, e->prover->publicBufferMinSize(), publicSize, "Minimum");
+            // room for the proof's workspaces (known after the circuit's first proof; a guess from its size before)
+            makeRoom(e->workBytes ? 0 : e->coreBytes / 2, e);
+        }
+        {
+            std::lock_guard<std::mutex> device(deviceMutex_);              // one proof on the device at a time, as fullprover's `busy`
+            std::lock_guard<std::mutex> turn(e->prover->proveMutex);
+            const uint64_t before = used();
+            e->prover->prove(wtns, wtnsSize, proof, pub);
+            const uint64_t after = used();
+            if (after > before) e->workBytes += after - before;
+            e->proofs++;
+        }
+        std::lock_guard<std::mutex> lock(mutex_);
+        makeRoom(0, e);
+        growTables();
+    }
+    void evict(const std::string& name) {
+        std::lock_guard<std::mutex> lock(mutex_);
+        if (!entries_.erase(name) && !evictedPaths_.erase(name)) throw std::invalid_argument("circuit not loaded: " + name);
+    }
+    // name empty: totals. state: 0 not loaded, 1 resident without tables, 2 resident with tables, 3 evicted (reloadable)
+    void info(const std::string& name, unsigned long long* bytes, int* state, unsigned long long* proofs) {
+        std::lock_guard<std::mutex> lock(mutex_);
+        if (name.empty()) {
+            if (bytes) *bytes = used();
+            if (state) *state = (int)entries_.size();
+            if (proofs) { *proofs = 0; for (auto& kv : entries_) *proofs += kv.second->proofs; }
+            return;
+        }
+        auto it = entries_.find(name);
+        if (it == entries_.end()) {
+            if (bytes) *bytes = 0;
+            if (proofs) *proofs = 0;
+            if (state) *state = evictedPaths_.count(name) ? 3 : 0;
+            return;
+        }
+        Entry& e = *it->second;
+        if (bytes) *bytes = e.coreBytes + e.prover->tableBytes + e.workBytes;
+        if (state) *state = e.prover->tableBytes ? 2 : 1;
+        if (proofs) *proofs = e.proofs;
+    }
+
+private:
+    struct Entry {
+        std::string name, path;
+        bool ultra = false;
+        std::unique_ptr<ProverBase> prover;
+        uint64_t coreBytes = 0, workBytes = 0, lastUsed = 0, proofs = 0;
+        uint64_t tablesDroppedAt = 0;      // tick at which its tables were taken away (it gets them back only after it was used again)
+    };
+    uint64_t used() {
+        uint64_t freeB = 0, total = 0;
+        ugCheck(ug_ctx_mem_info(probe_, &freeB, &total));
+        return baselineFree_ > freeB ? baselineFree_ - freeB : 0;
+    }
+    Entry* lru(const Entry* keep, bool (*has)(const Entry&)) {
+        Entry* best = nullptr;
+        for (auto& kv : entries_) {
+            Entry* e = kv.second.get();
+            if (e == keep || !has(*e)) continue;
+            if (!best || e->lastUsed < best->lastUsed) best = e;
+        }
+        return best;
+    }
+    // frees memory until used() + extra <= budget; `keep` is never evicted as a whole (its tables and workspaces may go last)
+    bool makeRoom(uint64_t extra, Entry* keep) {
+        while (used() + extra > budget_) {
+            Entry* e = lru(keep, [](const Entry& x) { return x.prover->tableBytes != 0; });
+            if (e) { e->prover->dropTables(); e->tablesDroppedAt = ++tick_; continue; }
+            e = lru(keep, [](const Entry& x) { return x.workBytes != 0; });
+            if (e) { e->prover->trimWorkspaces(); e->workBytes = 0; continue; }
+            e = lru(keep, [](const Entry&) { return true; });
+            if (e) {
+                if (!e->path.empty()) evictedPaths_[e->name] = e->path;
+                entries_.erase(e->name);
+                continue;
+            }
+            if (keep && keep->prover->tableBytes) { keep->prover->dropTables(); keep->tablesDroppedAt = ++tick_; continue; }
+            if (keep && keep->workBytes) { keep->prover->trimWorkspaces(); keep->workBytes = 0; continue; }
+            return false;
+        }
+        return true;
+    }
+    // tables for the most recently used circuits that lack them, while they fit the budget (with room for a proof's workspaces)
+    void growTables() {
+        std::vector<Entry*> order;
+        for (auto& kv : entries_) if (!kv.second->prover->tableBytes) order.push_back(kv.second.get());
+        std::sort(order.begin(), order.end(), [](Entry* a, Entry* b) { return a->lastUsed > b->lastUsed; });
+        for (Entry* e : order) {
+            if (e->tablesDroppedAt && e->lastUsed < e->tablesDroppedAt) continue;      // no thrashing: not before its next use
+            const uint64_t need = e->prover->tablesWouldTake();
+            if (!need) continue;
+            const uint64_t now = used(), reserve = e->workBytes ? 0 : e->coreBytes / 2;
+            if (now + need + reserve > budget_ - budget_ / 10) continue;               // and only into a comfortable margin
+            e->prover->buildTables(budget_ - now - reserve);
+        }
+    }
+    int device_;
+    uint64_t budget_, baselineFree_ = 0, tick_ = 0;
+    ug_ctx* probe_ = nullptr;
+    std::mutex mutex_, deviceMutex_;
+    std::map<std::string, std::unique_ptr<Entry>> entries_;
+    std::map<std::string, std::string> evictedPaths_;
+};
+
+// =================================================================================================================
 // extern "C" surface. Error mapping as in src/prover.cpp:556-576.
 #define API_TRY try {
 #define API_CATCH                                                                                              \
@@ -1030,6 +1279,61 @@ int ultra_groth_prover_zkey_file(const char* zkey_file_path, const void* wtns_bu
 
 // ---- additions ----------------------------------------------------------------------------------------------
 int ug_test_set_blinding(const void* bytes, unsigned long long n) { return setRandomOverride(bytes, (size_t)n) ? PROVER_OK : PROVER_ERROR; }
+
+int ug_registry_create(void** registry, int device, unsigned long long hbm_budget_bytes, char* error_msg, unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (registry == NULL) throw std::invalid_argument("Null registry pointer");
+    *registry = new Registry(device, hbm_budget_bytes);
+    API_CATCH
+}
+int ug_registry_load(void* registry, const char* circuit, const void* zkey_buffer, unsigned long long zkey_size, char* error_msg,
+                     unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (registry == NULL) throw std::invalid_argument("Null registry object");
+    if (circuit == NULL) throw std::invalid_argument("Null circuit name");
+    if (zkey_buffer == NULL) throw std::invalid_argument("Null zkey buffer");
+    static_cast<Registry*>(registry)->load(circuit, zkey_buffer, zkey_size, "");
+    API_CATCH
+}
+int ug_registry_load_file(void* registry, const char* zkey_file_path, char* error_msg, unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (registry == NULL) throw std::invalid_argument("Null registry object");
+    if (zkey_file_path == NULL) throw std::invalid_argument("Null zkey path");
+    static_cast<Registry*>(registry)->loadFile(zkey_file_path);
+    API_CATCH
+}
+int ug_registry_prove(void* registry, const char* circuit, const void* wtns_buffer, unsigned long long wtns_size, char* proof_buffer,
+                      unsigned long long* proof_size, char* public_buffer, unsigned long long* public_size, char* error_msg,
+                      unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (registry == NULL) throw std::invalid_argument("Null registry object");
+    if (circuit == NULL) throw std::invalid_argument("Null circuit name");
+    if (wtns_buffer == NULL) throw std::invalid_argument("Null witness buffer");
+    if (proof_buffer == NULL) throw std::invalid_argument("Null proof buffer");
+    if (proof_size == NULL) throw std::invalid_argument("Null proof size");
+    if (public_buffer == NULL) throw std::invalid_argument("Null public buffer");
+    if (public_size == NULL) throw std::invalid_argument("Null public size");
+    std::string stringProof, stringPublic;
+    static_cast<Registry*>(registry)->prove(circuit, wtns_buffer, wtns_size, stringProof, stringPublic, proof_size, public_size);
+    checkBufferSizes(stringProof.length(), proof_size, stringPublic.length(), public_size, "Required");
+    std::strncpy(proof_buffer, stringProof.c_str(), *proof_size);
+    std::strncpy(public_buffer, stringPublic.c_str(), *public_size);
+    API_CATCH
+}
+int ug_registry_evict(void* registry, const char* circuit, char* error_msg, unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (registry == NULL) throw std::invalid_argument("Null registry object");
+    if (circuit == NULL) throw std::invalid_argument("Null circuit name");
+    static_cast<Registry*>(registry)->evict(circuit);
+    API_CATCH
+}
+int ug_registry_info(void* registry, const char* circuit, unsigned long long* resident_bytes, int* state, unsigned long long* proofs) {
+    if (registry == NULL) return PROVER_ERROR;
+    try { static_cast<Registry*>(registry)->info(circuit ? circuit : "", resident_bytes, state, proofs); }
+    catch (...) { return PROVER_ERROR; }
+    return PROVER_OK;
+}
+void ug_registry_destroy(void* registry) { delete static_cast<Registry*>(registry); }
 
 int ug_prover_last_timings(void* prover_object, double* msm_ms, double* fft_ms, double* total_ms) {
     if (!prover_object) return PROVER_ERROR;

@@ -244,6 +244,40 @@ int ug_bases_precompute(ug_bases* b, int c) {
     b->table_c = c;
     UG_CATCH
 }
+int ug_bases_drop_tables(ug_bases* b) {
+    UG_TRY
+    if (!b) throw std::invalid_argument("null argument");
+    if (!b->table_c) return UG_OK;
+    ug_ctx* ctx = b->ctx;
+    ctx->use();
+    UG_HIP(hipStreamSynchronize(ctx->stream));
+    size_t bytes = (size_t)b->n * (b->g2 ? 128 : 64);
+    u32* small = nullptr;
+    UG_HIP(hipMalloc(&small, bytes ? bytes : 4));
+    if (bytes) UG_HIP(hipMemcpy(small, b->pts, bytes, hipMemcpyDeviceToDevice));
+    hipFree(b->pts);
+    b->pts = small;
+    b->table_c = 0;
+    UG_CATCH
+}
+int ug_bases_table_window(const ug_bases* b) { return b ? b->table_c : 0; }
+int ug_schedule_trim(ug_schedule* s) {
+    UG_TRY
+    if (!s) throw std::invalid_argument("null argument");
+    s->ctx->use();
+    UG_HIP(hipStreamSynchronize(s->ctx->stream));
+    s->sched.release();
+    UG_CATCH
+}
+int ug_ctx_trim(ug_ctx* c) {
+    UG_TRY
+    if (!c) throw std::invalid_argument("null argument");
+    c->use();
+    UG_HIP(hipStreamSynchronize(c->stream));
+    c->ws_g1.release(); c->ws_g2.release(); c->raw_ntt.release();
+    if (c->lookup_last) { hipFree(c->lookup_last); c->lookup_last = nullptr; c->lookup_last_n = 0; }
+    UG_CATCH
+}
 int ug_ctx_mem_info(ug_ctx* c, uint64_t* free_bytes, uint64_t* total_bytes) {
     UG_TRY
     if (!c) throw std::invalid_argument("null argument");
