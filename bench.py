@@ -338,16 +338,31 @@ def main():
     log_domain = args.log_domain
     if args.ultra:
         return bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_rank)
-    zkey, wtns, info = synth.build_circuit(dev, log_domain, mix=args.mix, g1_only=args.g1_only)
-    zkey_bytes = len(zkey)
-    t0 = time.perf_counter()
+    zkey = None
     if world == 1:
+        zkey, wtns, info = synth.build_circuit(dev, log_domain, mix=args.mix, g1_only=args.g1_only)
+        zkey_bytes = len(zkey)
+        t0 = time.perf_counter()
         prover = ug.Groth16Prover(zkey)          # groth16_prover_create: the reference's own entry point
+        create_s = time.perf_counter() - t0
+        if not args.check:
+            del zkey
     else:
-        prover = ug.ShardedGroth16Prover(zkey, local_rank, rank, world, witness_range=witness_slice(info, rank, world))
-    create_s = time.perf_counter() - t0
-    if not args.check:
-        del zkey
+        # every rank makes ONLY its slices of the point sections (same generator walk, entered at the slice); the
+        # coefficient records only on the ranks that run an H-polynomial chain: no rank holds the whole zkey
+        domain = 1 << log_domain
+        info = dict(domainSize=domain, nVars=domain - 1, nPublic=1, nCoefs=4 * domain)
+        wr = witness_slice(info, rank, world)
+        ranges = ug.ShardedGroth16Prover.shard_ranges(info["nVars"], 1, domain, rank, world, wr)
+        runs_chain = domain % world != 0 or any(k % world == rank for k in range(3))
+        header, coefs, slices = synth.build_circuit_slices(dev, log_domain, ranges, with_coefs=runs_chain, g1_only=args.g1_only)
+        wtns = synth.build_witness(log_domain, args.mix)
+        zkey_bytes = len(header) + (len(coefs) if coefs is not None else 0) + sum(len(x) for x in slices)
+        t0 = time.perf_counter()
+        prover = ug.ShardedGroth16Prover.from_slices(header, coefs, info["nCoefs"], slices, local_rank, rank, world,
+                                                     witness_range=wr, public_size=82 + 4)
+        create_s = time.perf_counter() - t0
+        del coefs, slices
 
     def barrier():
         torch.cuda.synchronize()
@@ -377,15 +392,17 @@ def main():
     my_chains = [k for k in range(3) if k % world == rank] if split_h else []
 
     def run_chains():
-        # the H-polynomial branch has its own stream inside the library: it runs beside this rank's witness MSMs
+        # the H-polynomial branch has its own stream inside the library: the rest of the witness (all the mat-vec reads)
+        # is uploaded there, then the chains run, beside this rank's witness MSMs
+        prover.load_witness_part(wtns, 1)
         for k in my_chains:
             prover.hpoly_chain(k, fulls[k].data_ptr())
 
     def step():
         if world == 1:
             return prover.prove(wtns)            # groth16_prover_prove on the .wtns in host memory: THE metric
-        prover.load_witness(wtns)                # every rank brings the witness into its HBM (inside the timed step)
         if split_h:
+            prover.load_witness_part(wtns, 0)    # this rank's slice of the scalars: all its witness MSMs read
             th = None
             if my_chains:
                 th = threading.Thread(target=run_chains)
@@ -398,7 +415,8 @@ def main():
             torch.cuda.synchronize()
             prover.hpoly_combine(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr())
             part = part[:320] + prover.run_h_msm()[320:384]
-        else:
+        else:                                    # the domain does not split evenly: every rank forms h itself
+            prover.load_witness(wtns)
             part = prover.run()
         mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)
         if backend == "nccl":
@@ -509,6 +527,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline(dev, args, log_domain)
         if args.check:
             from oracle import closed_form
+            if zkey is None:                     # N > 1: only now, and only on rank 0, the whole zkey is made (for its coefficient section)
+                zkey = synth.build_circuit(dev, log_domain, mix=args.mix, g1_only=args.g1_only)[0]
             exp = closed_form.groth16_expected(zkey, wtns, synth.SEEDS, synth.g1_generator_record(), synth.g2_generator_record(),
                                                int.from_bytes(bytes(range(1, 32)), "little"), int.from_bytes(bytes(range(31, 62)), "little"),
                                                g1_only=args.g1_only)

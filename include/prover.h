@@ -163,9 +163,29 @@ int ug_groth16_prover_create_sharded_range(void **prover_object, const void *zke
                                            int device, int shard_rank, int shard_count,
                                            unsigned long long witness_first, unsigned long long witness_end,
                                            char *error_msg, unsigned long long error_msg_maxsize);
+/* The same from this rank's SLICES only, so that no rank ever holds the whole zkey in host memory (37.6 GB at 2^26):
+ * zkey_header = the bytes of zkey section 2; coefs = section 4 without its 4-byte count (NULL: this rank will run no
+ * H-polynomial chain and keeps no coefficient matrix); points_* = this rank's slice of sections 5..9, starting at the
+ * first point of the ranges ug_groth16_shard_ranges reports: out[6] = {witness first, end, C first, end, H first, end}
+ * (witness_range: two values as in _create_sharded_range, or NULL for the even split). */
+int ug_groth16_shard_ranges(unsigned long long n_vars, unsigned long long n_public, unsigned long long domain_size,
+                            int shard_rank, int shard_count, const unsigned long long *witness_range,
+                            unsigned long long out[6]);
+int ug_groth16_prover_create_sharded_slices(void **prover_object, const void *zkey_header, unsigned long long zkey_header_size,
+                                            const void *coefs, unsigned long long n_coefs,
+                                            const void *points_a, const void *points_b1, const void *points_b2,
+                                            const void *points_c, const void *points_h,
+                                            int device, int shard_rank, int shard_count,
+                                            const unsigned long long *witness_range,
+                                            char *error_msg, unsigned long long error_msg_maxsize);
 /* upload the witness (wtns file buffer) to the device; returns PROVER_INVALID_WITNESS_LENGTH etc. */
 int ug_groth16_prover_load_witness(void *prover_object, const void *wtns_buffer, unsigned long long wtns_size,
                                    char *error_msg, unsigned long long error_msg_maxsize);
+/* The witness in two parts: part 0 = the scalars of this rank's slice (all that run_witness_msm reads), part 1 = the rest
+ * (read only by hpoly_chain / run: a rank without a chain never uploads it). Part 1 travels on the H branch's stream and
+ * may be called from a second host thread while the MSMs over part 0 run. */
+int ug_groth16_prover_load_witness_part(void *prover_object, const void *wtns_buffer, unsigned long long wtns_size, int part,
+                                        char *error_msg, unsigned long long error_msg_maxsize);
 /* device part of the prove on the resident witness: the five MSMs over this rank's slice + H polynomial */
 int ug_groth16_prover_run(void *prover_object, void *partials_out,
                           char *error_msg, unsigned long long error_msg_maxsize);

@@ -86,6 +86,9 @@ void ug_bases_destroy(ug_bases* b);
 /* device vectors of n 32-byte elements */
 int  ug_dvec_create(ug_ctx* ctx, uint64_t n, ug_dvec** out);
 int  ug_dvec_upload(ug_dvec* v, const void* host, uint64_t n);           /* host -> device, n <= capacity */
+/* the same into elements [first, first + n); `via`: the context whose stream and staging buffers carry the copy (NULL =
+ * the vector's own), so that two host threads can fill disjoint ranges of one vector at the same time */
+int  ug_dvec_upload_range(ug_dvec* v, const void* host, uint64_t first, uint64_t n, ug_ctx* via);
 int  ug_dvec_download(const ug_dvec* v, void* host, uint64_t first, uint64_t n);
 /* out[i] = src[index[i]] for i < n (UltraGroth round / final witness gathers, src/ultra_groth.cpp:415-445) */
 int  ug_dvec_gather(ug_dvec* out, const ug_dvec* src, const uint32_t* host_index, uint64_t n);
@@ -103,6 +106,11 @@ int  ug_dvec_scatter(ug_dvec* dst, const uint32_t* host_index, const void* host_
  * the last. All arrays are host arrays; indices out of range fail with nothing written. */
 int  ug_dvec_apply_lookup(ug_dvec* dst, const uint32_t* w_idx, const uint32_t* p_idx, uint64_t n,
                           const uint32_t* chunks, uint64_t n_chunks, const void* table, uint64_t lookup_size);
+/* The lookup table of compute_lookup (src/ultra_groth.cpp:71-80) for challenge `rand_plain` (32-byte plain integer):
+ * table_out = [rand | inv2[0..L) | prod[0..L)] with inv2[i] = 1 / (i + rand) (0 when i + rand = 0) and
+ * prod[i] = frequencies[i] * inv2[i], plain integers, (1 + 2 L) * 32 bytes of host memory -- the `table` argument of
+ * ug_dvec_apply_lookup. Row index and frequency follow the reference's (int, Element) overloads (>= 2^31: value - 2^32). */
+int  ug_fr_lookup_table(ug_ctx* ctx, const void* rand_plain, const uint32_t* frequencies, uint64_t lookup_size, void* table_out);
 /* non-owning view of n 32-byte elements already in device memory (e.g. a torch / RCCL buffer) */
 int  ug_dvec_wrap(ug_ctx* ctx, void* device_ptr, uint64_t n, ug_dvec** out);
 uint64_t ug_dvec_size(const ug_dvec* v);
@@ -139,7 +147,8 @@ int  ug_hpoly_run(ug_hpoly* hp, const ug_dvec* witness, ug_dvec* h_out);
 /* The same block in two steps, for a prover sharded over GPUs: ug_hpoly_chain computes the coset evaluations of
  * ONE of the three polynomials (which = 0: A.w, 1: B.w, 2: (A.w) o (B.w)) -- ranks take different polynomials and
  * exchange slices -- and ug_hpoly_combine turns matching slices of the three vectors into h[first, first+count).
- * The evaluation vectors are in the library's device form and only meaningful to this library. */
+ * The evaluation vectors are in the library's device form and only meaningful to this library. ug_hpoly_combine needs
+ * no coefficient matrix: hp may be NULL (then the work runs on h_out's context). */
 int  ug_hpoly_chain(ug_hpoly* hp, const ug_dvec* witness, int which, ug_dvec* out_evals);
 int  ug_hpoly_combine(ug_hpoly* hp, const ug_dvec* a, const ug_dvec* b, const ug_dvec* c, uint64_t first, uint64_t count,
                       ug_dvec* h_out);

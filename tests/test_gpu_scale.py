@@ -174,6 +174,78 @@ def test_sharded_prover_with_split_hpoly(device):
         p.close()
 
 
+def test_sharded_prover_from_slices_and_witness_parts(device):
+    """what bench.py does with N > 1 ranks: every rank is created from ITS slices of the point sections only
+    (ug_groth16_prover_create_sharded_slices; the slices are the same generator walk entered at the slice), ranks beyond
+    the three chain ranks hold no coefficient matrix and upload only their slice of the witness; the chain ranks upload
+    the rest of the witness on the H branch's stream. 4 ranks on one GPU, caller-chosen uneven witness ranges."""
+    import torch
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    log_domain, world = 13, 4
+    zkey, wtns, info = synth.build_circuit(device, log_domain, mix="U", seed=0x5EED0000)
+    n_dom, nv = info["domainSize"], info["nVars"]
+    cuts = [0, 1500, 3700, 6000, nv]
+    sl = n_dom // world
+    ranks = []
+    for k in range(world):
+        wr = (cuts[k], cuts[k + 1])
+        rg = ug.ShardedGroth16Prover.shard_ranges(nv, 1, n_dom, k, world, wr)
+        assert rg[0] == wr and rg[2] == (k * sl, (k + 1) * sl)
+        assert rg[1] == (max(wr[0] - 2, 0), max(wr[1] - 2, 0))                 # C follows the witness slice, shifted by nPublic + 1
+        header, coefs, slices = synth.build_circuit_slices(device, log_domain, rg, with_coefs=(k < 3))
+        ranks.append(ug.ShardedGroth16Prover.from_slices(header, coefs, info["nCoefs"], slices, 0, k, world, witness_range=wr,
+                                                         public_size=86))
+    for p in ranks:
+        p.load_witness_part(wtns, 0)
+    parts = [p.run_witness_msm() for p in ranks]
+    with pytest.raises(ug.ProverError, match="whole witness has not been loaded"):
+        ranks[0].hpoly_chain(0, 0x1000)
+    full = torch.empty((3, n_dom, 32), dtype=torch.uint8, device="cuda")
+    for k in range(3):
+        ranks[k].load_witness_part(wtns, 1)
+        ranks[k].hpoly_chain(k, full[k].data_ptr())
+    ranks[3].load_witness_part(wtns, 1)
+    with pytest.raises(ug.ProverError, match="created without the coefficient matrix"):
+        ranks[3].hpoly_chain(0, full[0].data_ptr())
+    torch.cuda.synchronize()
+    total = None
+    for r, p in enumerate(ranks):
+        bufs = [full[k, r * sl:(r + 1) * sl].contiguous() for k in range(3)]
+        torch.cuda.synchronize()
+        p.hpoly_combine(*(b.data_ptr() for b in bufs))
+        part = parts[r][:320] + p.run_h_msm()[320:384]
+        total = part if total is None else ug.ShardedGroth16Prover.add_partials(total, part)
+    r_, s_ = fixed_rs()
+    ug.set_test_blinding(r_ + s_)
+    try:
+        got = ranks[0].finish(total)
+    finally:
+        ug.set_test_blinding(b"")
+    exp = O.groth16_prove(zkey, wtns, int.from_bytes(r_, "little"), int.from_bytes(s_, "little"))
+    assert got == (exp[0], exp[1])
+    for p in ranks:
+        p.close()
+
+
+def test_bench_two_ranks_over_rccl():
+    """the real N = 2 launch line of the driver (one process per GPU, backend nccl = RCCL) with --check; needs two GPUs --
+    on a one-GPU box the same control flow is rehearsed over gloo (tools/run_multi.sh)"""
+    import subprocess
+    import sys
+    import ultragroth_amd as ug
+    if ug.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ([], ["--ultra"]):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", "29631", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                            "--log-domain", "16", "--no-cpu-baseline", "--check"] + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and ("bit-exact" in (line.get("check") or line["config"]["workload"]))
+
+
 def test_api_errors_on_device(zkey, wtns):
     import ultragroth_amd as ug
     with ug.Groth16Prover(zkey) as p:
@@ -217,6 +289,40 @@ def test_ultragroth_matches_oracle(device):
     with pytest.raises(ug.ProverError) as e:
         ug.groth16_prover(zkey, uwtns)
     assert e.value.message == "zkey file is not groth16"
+
+
+def test_lookup_table_rows_follow_the_reference_overloads(device):
+    """ug_fr_lookup_table against the oracle's row (itself pinned to the reference's RawFr calls, tests/test_oracle.py):
+    frequencies >= 2^31 enter as freq - 2^32 (mul(int, Element), build/fr.hpp:251), a zero sum inverts to zero; and a whole
+    UltraGroth proof whose frequencies use the full uint32 range"""
+    import struct
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    rng = random.Random(31)
+    L = 300
+    freq = [rng.choice([0, 1, (1 << 31) - 1, 1 << 31, (1 << 32) - 1, rng.randrange(1 << 32)]) for _ in range(L)]
+    for rand in (rng.randrange(O.R_MOD), O.R_MOD - 7, 0):
+        table = C.create_string_buffer((1 + 2 * L) * 32)
+        arr = (C.c_uint32 * L)(*freq)
+        assert device._L.ug_fr_lookup_table(device._h, O.to_le(rand), arr, L, table) == 0
+        assert O.from_le(table.raw[:32]) == rand
+        for i in range(L):
+            exp = O.lookup_row(i, freq[i], rand * (1 << 256) % O.R_MOD)
+            got = (O.from_le(table.raw[32 * (1 + i):32 * (2 + i)]), O.from_le(table.raw[32 * (1 + L + i):32 * (2 + L + i)]))
+            assert got == exp, (rand, i)
+    zkey, uwtns, info = synth.build_ultra_circuit(device, 11)
+    off, sz = O.section(uwtns, "wtns", 4)
+    big = bytearray(uwtns)
+    for k in range(0, sz // 4, 3):
+        big[off + 4 * k:off + 4 * k + 4] = struct.pack("<I", rng.choice([1 << 31, (1 << 32) - 1, rng.randrange(1 << 31, 1 << 32)]))
+    big = bytes(big)
+    rk, r, s = bytes(range(1, 32)), bytes(range(40, 71)), bytes(range(80, 111))
+    ug.set_test_blinding(rk + r + s)
+    try:
+        got = ug.ultra_groth_prover(zkey, big)
+    finally:
+        ug.set_test_blinding(b"")
+    assert got == O.ultra_groth_prove(zkey, big, *(int.from_bytes(b, "little") for b in (rk, r, s)))
 
 
 # ---- size-independent properties at full size ------------------------------------------------------------------

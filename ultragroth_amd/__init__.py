@@ -283,9 +283,41 @@ class ShardedGroth16Prover:
             raise ProverError(rc, err.value.decode(errors="replace"))
         self._public_size = groth16_public_size_for_zkey_buf(zkey)
 
+    @classmethod
+    def from_slices(cls, header, coefs, n_coefs, slices, device, rank, world, witness_range=None, public_size=None):
+        """ug_groth16_prover_create_sharded_slices: header = zkey section 2, coefs = section 4 records (None: no chain on
+        this rank), slices = (A, B1, B2, C, H) buffers holding this rank's points only (shard_ranges tells which)"""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(1024)
+        wr = (C.c_ulonglong * 2)(*witness_range) if witness_range is not None else None
+        rc = load().ug_groth16_prover_create_sharded_slices(C.byref(self._h), header, len(header), coefs, n_coefs, *slices,
+                                                            device, rank, world, wr, err, len(err) - 1)
+        if rc != PROVER_OK:
+            self._h = None
+            raise ProverError(rc, err.value.decode(errors="replace"))
+        self._public_size = public_size
+        return self
+
+    @staticmethod
+    def shard_ranges(n_vars, n_public, domain, rank, world, witness_range=None):
+        """((witness first, end), (C first, end), (H first, end)) of a rank"""
+        out = (C.c_ulonglong * 6)()
+        wr = (C.c_ulonglong * 2)(*witness_range) if witness_range is not None else None
+        if load().ug_groth16_shard_ranges(n_vars, n_public, domain, rank, world, wr, out) != PROVER_OK:
+            raise ProverError(PROVER_ERROR, "invalid shard rank / count or witness range")
+        return (out[0], out[1]), (out[2], out[3]), (out[4], out[5])
+
     def load_witness(self, wtns):
         err = C.create_string_buffer(1024)
         rc = load().ug_groth16_prover_load_witness(self._h, wtns, len(wtns), err, len(err) - 1)
+        if rc != PROVER_OK:
+            raise ProverError(rc, err.value.decode(errors="replace"))
+
+    def load_witness_part(self, wtns, part):
+        """part 0: the scalars of this rank's MSM slice; part 1: the rest (only ranks that run an H-polynomial chain)"""
+        err = C.create_string_buffer(1024)
+        rc = load().ug_groth16_prover_load_witness_part(self._h, wtns, len(wtns), part, err, len(err) - 1)
         if rc != PROVER_OK:
             raise ProverError(rc, err.value.decode(errors="replace"))
 

@@ -15,7 +15,7 @@ INNER_SYMBOLS = [
     "ug_last_error", "ug_device_count", "ug_ctx_create", "ug_ctx_destroy", "ug_ctx_sync",
     "ug_bases_create_g1", "ug_bases_create_g2", "ug_bases_destroy",
     "ug_msm_table_window", "ug_bases_tables_bytes", "ug_bases_precompute", "ug_ctx_mem_info", "ug_schedule_build_tables",
-    "ug_dvec_create", "ug_dvec_upload", "ug_dvec_download", "ug_dvec_gather", "ug_dvec_scatter", "ug_dvec_apply_lookup", "ug_index_create", "ug_index_destroy", "ug_dvec_gather_index", "ug_dvec_wrap", "ug_dvec_size", "ug_dvec_destroy",
+    "ug_dvec_create", "ug_dvec_upload", "ug_dvec_upload_range", "ug_dvec_download", "ug_dvec_gather", "ug_dvec_scatter", "ug_dvec_apply_lookup", "ug_fr_lookup_table", "ug_index_create", "ug_index_destroy", "ug_dvec_gather_index", "ug_dvec_wrap", "ug_dvec_size", "ug_dvec_destroy",
     "ug_schedule_create", "ug_schedule_build", "ug_schedule_destroy",
     "ug_msm_g1", "ug_msm_g2", "ug_msm_batch",
     "ug_hpoly_create", "ug_hpoly_run", "ug_hpoly_chain", "ug_hpoly_combine", "ug_hpoly_debug_abc", "ug_hpoly_destroy",
@@ -36,7 +36,8 @@ OUTER_SYMBOLS = [
     "ug_registry_create", "ug_registry_load", "ug_registry_load_file", "ug_registry_prove", "ug_registry_evict", "ug_registry_info",
     "ug_registry_destroy",
     "ug_test_set_blinding", "ug_prover_last_timings", "ug_prover_kernel_stats", "ug_prover_last_upload_ms",
-    "ug_groth16_prover_create_sharded", "ug_groth16_prover_create_sharded_range",
+    "ug_groth16_prover_create_sharded", "ug_groth16_prover_create_sharded_range", "ug_groth16_prover_create_sharded_slices",
+    "ug_groth16_shard_ranges", "ug_groth16_prover_load_witness_part",
     "ug_ultra_groth_prover_create_sharded", "ug_ultra_groth_prover_round_commit", "ug_ultra_groth_prover_round_finish",
     "ug_ultra_groth_prover_apply_commitment", "ug_g1_record_add",
     "ug_groth16_prover_load_witness", "ug_groth16_prover_run",
@@ -149,6 +150,11 @@ def load():
     L.ug_g1_record_add.argtypes = [vp, vp]
     L.ug_groth16_prover_create_sharded_range.argtypes = [pp, vp, ull, C.c_int, C.c_int, C.c_int, ull, ull, vp, ull]
     L.ug_groth16_prover_load_witness.argtypes = [vp, vp, ull, vp, ull]
+    L.ug_groth16_prover_load_witness_part.argtypes = [vp, vp, ull, C.c_int, vp, ull]
+    L.ug_groth16_shard_ranges.argtypes = [ull, ull, ull, C.c_int, C.c_int, vp, vp]
+    L.ug_groth16_prover_create_sharded_slices.argtypes = [pp, vp, ull, vp, ull, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, ull]
+    L.ug_dvec_upload_range.argtypes = [vp, vp, u64, u64, vp]
+    L.ug_fr_lookup_table.argtypes = [vp, vp, vp, u64, vp]
     L.ug_groth16_prover_run.argtypes = [vp, vp, vp, ull]
     L.ug_groth16_partials_add.argtypes = [vp, vp]
     L.ug_groth16_prover_run_witness_msm.argtypes = [vp, vp, vp, ull]

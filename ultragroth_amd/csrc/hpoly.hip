@@ -160,6 +160,31 @@ __global__ void lookup_clear_kernel(u32* last, const u32* w_idx, u64 n) {
     if (i < n) last[w_idx[i]] = 0;
 }
 
+// The lookup table itself (src/ultra_groth.cpp:71-80): row i -> inv2[i] = 1 / (i + rand), prod[i] = frequencies[i] * inv2[i],
+// both as plain integers. One lane per row with its own Fermat inversion (2^16 rows: 25 M products, microseconds here;
+// the reference makes one GMP inversion per row on one core). `i` and the uint32 frequency enter through RawFr::set(int)
+// (build/fr.hpp:249-251, build/fr.cpp:209-223): values >= 2^31 mean value - 2^32.
+__device__ __forceinline__ Fr fr_set_int(u32 v) {
+    const bool negative = (v >> 31) != 0;
+    u32 w[8] = {negative ? (u32)(0u - v) : v, 0, 0, 0, 0, 0, 0, 0};
+    Fr m = from_normal<FrParams>(w);                           // < 2q, strict
+    return negative ? neg<2>(m) : m;
+}
+__global__ void lookup_table_kernel(u32* table, const u32* freq, u64 L) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    u32 rw[8];
+    load8(rw, table);                                          // table[0] = rand, plain integer
+    Fr rand = from_normal<FrParams>(rw);
+    Fr sum = cond_sub_q(mul(add(fr_set_int((u32)i), rand), fp_one<FrParams>()));
+    Fr inv_i = limbs_all_zero(sum) ? fp_zero<FrParams>() : inv(sum);      // mpz_invert leaves 0 for 0
+    u32 o[8];
+    to_normal(o, inv_i);
+    store8(table + (1 + i) * 8, o);
+    to_normal(o, mul(fr_set_int(freq[i]), inv_i));
+    store8(table + (1 + L + i) * 8, o);
+}
+
 template <class T> void dev_alloc(T*& p, size_t bytes) { if (p) hipFree(p); p = nullptr; UG_HIP(hipMalloc(&p, bytes ? bytes : 4)); }
 inline unsigned grid_for(u64 n, int block) { return (unsigned)((n + block - 1) / block); }
 
@@ -252,6 +277,11 @@ void apply_lookup(u32* dst, u32* last_scratch, const u32* w_idx, const u32* p_id
     hipLaunchKernelGGL(lookup_write_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, dst, last_scratch, w_idx, p_idx, n, chunks, n_chunks, table);
     UG_KERNEL_CHECK();
     hipLaunchKernelGGL(lookup_clear_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, last_scratch, w_idx, n);
+    UG_KERNEL_CHECK();
+}
+void lookup_table(u32* table_dev, const u32* freq_dev, u64 L, hipStream_t stream) {
+    if (!L) return;
+    hipLaunchKernelGGL(lookup_table_kernel, dim3(grid_for(L, 128)), dim3(128), 0, stream, table_dev, freq_dev, L);
     UG_KERNEL_CHECK();
 }
 void f_op_mont256(int which, int op, u32* out, const u32* a, const u32* b, u64 n, hipStream_t stream) {

@@ -165,6 +165,8 @@ void gather_elements(u32* out, const u32* src, const u32* index_dev, u64 n, u64 
 void scatter_elements(u32* dst, const u32* index_dev, const u32* values_dev, u64 n, u64 dst_n, hipStream_t stream);
 // dst[w_idx[i]] = push[p_idx[i]] for i < n in order (last write wins); push = [table[0] | table[1 + chunks[j]], j < n_chunks |
 // table[1..]]; all pointers on the device, indices already validated; last_scratch: one zeroed u32 per element of dst
+// table_dev: 1 + 2 L elements, [0] = rand (plain) on entry; fills inv2 = 1/(i + rand) and prod = freq[i] * inv2[i] (plain)
+void lookup_table(u32* table_dev, const u32* freq_dev, u64 L, hipStream_t stream);
 void apply_lookup(u32* dst, u32* last_scratch, const u32* w_idx, const u32* p_idx, u64 n, const u32* chunks, u64 n_chunks,
                   const u32* table, hipStream_t stream);
 

@@ -315,6 +315,7 @@ struct ProverBase {        // what the extern "C" layer stores behind the opaque
     // phases of a sharded proof (include/prover.h); both provers implement them
     [[noreturn]] static void noPhase() { throw std::invalid_argument("this prover object does not support the call"); }
     virtual void loadWitness(const void*, unsigned long long) { noPhase(); }
+    virtual void loadWitnessPart(const void*, unsigned long long, int) { noPhase(); }
     virtual void run(uint8_t*) { noPhase(); }
     virtual void runWitnessMsm(uint8_t*, bool = true) { noPhase(); }
     virtual void runHMsm(uint8_t*) { noPhase(); }
@@ -345,6 +346,34 @@ const uint8_t* checkedSection(const BinFile& f, uint32_t id, uint64_t needBytes)
 // =================================================================================================================
 class Groth16Prover : public ProverBase {
 public:
+    // What a prover is made from: the zkey header (section 2), the coefficient records and the five point sections --
+    // whole sections of a zkey buffer, or (sliced) only this rank's slice of each, so that a rank of a many-GPU prover
+    // never holds the whole zkey (37.6 GB at 2^26) in host memory.
+    struct Sources {
+        bool sliced = false;
+        const uint8_t* coefs = nullptr; uint64_t nCoefs = 0; bool haveCoefs = true;     // !haveCoefs: this rank runs no NTT chain
+        const uint8_t *pA = nullptr, *pB1 = nullptr, *pB2 = nullptr, *pC = nullptr, *pH = nullptr;
+    };
+    struct Ranges { Range w, c, h; };
+    // the slices of rank `rank` of `count` (witnessRange: chosen by the caller, else the even split); C follows the witness slice
+    static Ranges shardRanges(uint64_t M, uint64_t nPublic, uint64_t N, int rank, int count, const Range* witnessRange) {
+        if (count < 1 || rank < 0 || rank >= count) throw std::invalid_argument("invalid shard rank / count");
+        if (M < nPublic + 1) throw std::invalid_argument("zkey header: nVars smaller than nPublic + 1");
+        Ranges r;
+        r.w = shardRange(M, rank, count);
+        if (witnessRange) {
+            if (witnessRange->lo > witnessRange->hi || witnessRange->hi > M) throw std::invalid_argument("witness range outside [0, nVars]");
+            r.w = *witnessRange;
+        }
+        r.h = shardRange(N, rank, count);
+        const uint64_t shift = nPublic + 1, nC = M - nPublic - 1;
+        r.c.lo = r.w.lo > shift ? r.w.lo - shift : 0;
+        r.c.hi = r.w.hi > shift ? r.w.hi - shift : 0;
+        if (r.c.hi > nC) r.c.hi = nC;
+        if (r.c.lo > r.c.hi) r.c.lo = r.c.hi;
+        return r;
+    }
+
     // witnessRange: the slice of the witness-indexed sets (A, B1, B2, C) this rank owns, when the caller balances the
     // ranks itself (ug_groth16_prover_create_sharded_range); nullptr = the even split
     Groth16Prover(const void* zkey, unsigned long long zkeySize, int device, int rank, int count, const Range* witnessRange = nullptr)
@@ -354,40 +383,70 @@ public:
         hdr_ = loadZkeyHeader(f, false);
         if (!hdr_.rIsBn254) throw std::invalid_argument("zkey curve not supported");
         if (hdr_.nVars < hdr_.nPublic + 1) throw std::invalid_argument("zkey header: nVars smaller than nPublic + 1");
+        const uint64_t M = hdr_.nVars, N = hdr_.domainSize, nC = M - hdr_.nPublic - 1;
+        Sources src;
+        src.coefs = checkedSection(f, 4, 4 + hdr_.nCoefs * 44) + 4;       // src/groth16.cpp:38
+        src.nCoefs = hdr_.nCoefs;
+        src.pA = checkedSection(f, 5, M * 64);
+        src.pB1 = checkedSection(f, 6, M * 64);
+        src.pB2 = checkedSection(f, 7, M * 128);
+        src.pC = checkedSection(f, 8, nC * 64);
+        src.pH = checkedSection(f, 9, N * 64);
+        init(src, device, witnessRange);
+    }
+    // from the header section and this rank's slices (ug_groth16_prover_create_sharded_slices)
+    Groth16Prover(const void* header, unsigned long long headerSize, const Sources& slices, int device, int rank, int count,
+                  const Range* witnessRange)
+        : rank_(rank), count_(count) {
+        // a header-only container so that the one header parser serves both forms
+        std::vector<uint8_t> mini;
+        auto put32 = [&](uint32_t v) { for (int k = 0; k < 4; k++) mini.push_back((uint8_t)(v >> (8 * k))); };
+        auto put64 = [&](uint64_t v) { for (int k = 0; k < 8; k++) mini.push_back((uint8_t)(v >> (8 * k))); };
+        mini.insert(mini.end(), {'z', 'k', 'e', 'y'});
+        put32(1); put32(3);
+        put32(1); put64(4); put32(1);
+        put32(2); put64(headerSize);
+        mini.insert(mini.end(), static_cast<const uint8_t*>(header), static_cast<const uint8_t*>(header) + headerSize);
+        put32(4); put64(0);
+        BinFile f(mini.data(), mini.size(), "zkey", 1);
+        hdr_ = loadZkeyHeader(f, false);
+        if (!hdr_.rIsBn254) throw std::invalid_argument("zkey curve not supported");
+        hdr_.nCoefs = slices.nCoefs;
+        Sources src = slices;
+        src.sliced = true;
+        init(src, device, witnessRange);       // (copies the verification-key points out of `mini` before it goes away)
+    }
+
+private:
+    void init(const Sources& src, int device, const Range* witnessRange) {
+        const int rank = rank_, count = count_;
         // the prover keeps its own copy of the verification-key points it needs (the reference keeps pointers)
         vk_.assign(hdr_.alpha1, hdr_.alpha1 + 64 + 64 + 128 + 128 + 64 + 128);
         hdr_.alpha1 = vk_.data(); hdr_.beta1 = vk_.data() + 64; hdr_.beta2 = vk_.data() + 128; hdr_.gamma2 = vk_.data() + 256;
         hdr_.delta1 = vk_.data() + 384; hdr_.delta2 = vk_.data() + 448;
 
-        const uint64_t M = hdr_.nVars, N = hdr_.domainSize, nC = M - hdr_.nPublic - 1;
-        const uint8_t* coefs = checkedSection(f, 4, 4 + hdr_.nCoefs * 44) + 4;       // src/groth16.cpp:38
-        const uint8_t* pA = checkedSection(f, 5, M * 64);
-        const uint8_t* pB1 = checkedSection(f, 6, M * 64);
-        const uint8_t* pB2 = checkedSection(f, 7, M * 128);
-        const uint8_t* pC = checkedSection(f, 8, nC * 64);
-        const uint8_t* pH = checkedSection(f, 9, N * 64);
+        const uint64_t M = hdr_.nVars, N = hdr_.domainSize;
+        const uint8_t *coefs = src.coefs, *pA = src.pA, *pB1 = src.pB1, *pB2 = src.pB2, *pC = src.pC, *pH = src.pH;
+        haveHpoly_ = src.haveCoefs;
 
-        wr_ = shardRange(M, rank, count);        // witness scalars (and A/B1/B2 points) of this rank
-        if (witnessRange) {
-            if (witnessRange->lo > witnessRange->hi || witnessRange->hi > M) throw std::invalid_argument("witness range outside [0, nVars]");
-            wr_ = *witnessRange;
+        const Ranges rg = shardRanges(M, hdr_.nPublic, N, rank, count, witnessRange);
+        wr_ = rg.w;                              // witness scalars (and A/B1/B2 points) of this rank
+        hr_ = rg.h;                              // h scalars (and H points) of this rank
+        const uint64_t cLo = rg.c.lo, cHi = rg.c.hi;
+        if (!src.sliced) {                       // whole sections: step to this rank's slice
+            pA += wr_.lo * 64; pB1 += wr_.lo * 64; pB2 += wr_.lo * 128; pC += cLo * 64; pH += hr_.lo * 64;
         }
-        hr_ = shardRange(N, rank, count);        // h scalars (and H points) of this rank
-        const uint64_t shift = (uint64_t)hdr_.nPublic + 1;
-        uint64_t cLo = wr_.lo > shift ? wr_.lo - shift : 0, cHi = wr_.hi > shift ? wr_.hi - shift : 0;
-        if (cHi > nC) cHi = nC;
-        if (cLo > cHi) cLo = cHi;
 
         ugCheck(ug_ctx_create(&d_.ctx, device));
-        ugCheck(ug_bases_create_g1(d_.ctx, pA + wr_.lo * 64, wr_.hi - wr_.lo, wr_.lo, &d_.A));
-        ugCheck(ug_bases_create_g1(d_.ctx, pB1 + wr_.lo * 64, wr_.hi - wr_.lo, wr_.lo, &d_.B1));
-        ugCheck(ug_bases_create_g2(d_.ctx, pB2 + wr_.lo * 128, wr_.hi - wr_.lo, wr_.lo, &d_.B2));
-        ugCheck(ug_bases_create_g1(d_.ctx, pC + cLo * 64, cHi - cLo, cLo, &d_.C));
+        ugCheck(ug_bases_create_g1(d_.ctx, pA, wr_.hi - wr_.lo, wr_.lo, &d_.A));
+        ugCheck(ug_bases_create_g1(d_.ctx, pB1, wr_.hi - wr_.lo, wr_.lo, &d_.B1));
+        ugCheck(ug_bases_create_g2(d_.ctx, pB2, wr_.hi - wr_.lo, wr_.lo, &d_.B2));
+        ugCheck(ug_bases_create_g1(d_.ctx, pC, cHi - cLo, cLo, &d_.C));
         // the H branch (coefficient mat-vec, NTT chains, h schedule, H MSM) gets its own stream so that its
         // memory-bound kernels (sort, transpose, gathers) overlap the integer-bound witness accumulations
         ugCheck(ug_ctx_create(&d_.ctx2, device));
-        ugCheck(ug_bases_create_g1(d_.ctx2, pH + hr_.lo * 64, hr_.hi - hr_.lo, hr_.lo, &d_.H));
-        ugCheck(ug_hpoly_create(d_.ctx2, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
+        ugCheck(ug_bases_create_g1(d_.ctx2, pH, hr_.hi - hr_.lo, hr_.lo, &d_.H));
+        if (haveHpoly_) ugCheck(ug_hpoly_create(d_.ctx2, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
         ugCheck(ug_dvec_create(d_.ctx, M, &d_.w));
         ugCheck(ug_dvec_create(d_.ctx2, N, &d_.h));
         ugCheck(ug_schedule_create(d_.ctx, &d_.sw));
@@ -401,6 +460,7 @@ public:
         tableBytes = planWindowTables(d_.ctx, groups);
     }
 
+public:
     std::vector<TableGroup> tableGroups() override {
         std::vector<TableGroup> groups(2);
         groups[0].g1 = {d_.A, d_.B1, d_.C}; groups[0].n1 = {wr_.hi - wr_.lo, wr_.hi - wr_.lo, cHi_ - cLo_};
@@ -431,8 +491,32 @@ public:
         const uint8_t* data = checkedSection(f, 2, (uint64_t)hdr_.nVars * 32);
         publicPart_.assign(data, data + ((size_t)hdr_.nPublic + 1) * 32);
         ugCheck(ug_dvec_upload(d_.w, data, hdr_.nVars));
-        witnessLoaded_ = true;
+        witnessLoaded_ = true; witnessComplete_ = true;
         uploadMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    // The witness in two parts, for a rank of a sharded prover: part 0 = the scalars of this rank's MSM slice (what
+    // runWitnessMsm reads), part 1 = everything else (only the H-polynomial mat-vec reads it; a rank that runs no
+    // chain never calls it). Part 1 may be uploaded from a second host thread while the MSMs of part 0 run.
+    void loadWitnessPart(const void* wtns, unsigned long long wtnsSize, int part) override {
+        auto t0 = std::chrono::steady_clock::now();
+        BinFile f(wtns, wtnsSize, "wtns", 2);
+        WtnsHeader wh = loadWtnsHeader(f);
+        if (hdr_.nVars != wh.nVars)
+            throw InvalidWitnessLengthException("Invalid witness length. Circuit: " + std::to_string(hdr_.nVars) +
+                                                ", witness: " + std::to_string(wh.nVars));
+        if (!wh.primeIsBn254) throw std::invalid_argument("different wtns curve");
+        const uint8_t* data = checkedSection(f, 2, (uint64_t)hdr_.nVars * 32);
+        if (part == 0) {
+            publicPart_.assign(data, data + ((size_t)hdr_.nPublic + 1) * 32);
+            ugCheck(ug_dvec_upload_range(d_.w, data + wr_.lo * 32, wr_.lo, wr_.hi - wr_.lo, 0));
+            witnessLoaded_ = true; witnessComplete_ = false;
+            uploadMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        } else if (part == 1) {
+            // on the H branch's context: its stream orders the copy before the mat-vec, and the MSM stream is left alone
+            if (wr_.lo) ugCheck(ug_dvec_upload_range(d_.w, data, 0, wr_.lo, d_.ctx2));
+            if (wr_.hi < hdr_.nVars) ugCheck(ug_dvec_upload_range(d_.w, data + wr_.hi * 32, wr_.hi, hdr_.nVars - wr_.hi, d_.ctx2));
+            witnessComplete_ = true;
+        } else throw std::invalid_argument("witness part must be 0 or 1");
     }
 
     // S1-S4 on this rank's slice; partials = A | B1 | B2 | C | H affine records (H left at infinity)
@@ -479,7 +563,8 @@ public:
         msmMs_ = m1 + m2; fftMs_ = f1 + f2;      // device time per branch; the branches overlap in wall time
     }
     void hpolyChain(int which, void* deviceOut) override {
-        if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
+        if (!witnessLoaded_ || !witnessComplete_) throw std::invalid_argument("the whole witness has not been loaded");
+        if (!haveHpoly_) throw std::invalid_argument("this rank was created without the coefficient matrix");
         ug_dvec* v = nullptr;
         ugCheck(ug_dvec_wrap(d_.ctx2, deviceOut, hdr_.domainSize, &v));
         int rc = ug_hpoly_chain(d_.hp, d_.w, which, v);
@@ -510,7 +595,8 @@ public:
     // (measured: 148 -> 144 ms per 2^24 proof, 49.9 -> 46.7 ms at 2^22). Off by default: overlapped kernels stretch each other, which blurs the
     // per-kernel durations and the MSM | FFT split that bench.py and rocprof report.
     void run(uint8_t* partials) override {
-        if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
+        if (!witnessLoaded_ || !witnessComplete_) throw std::invalid_argument("no witness loaded");
+        if (!haveHpoly_) throw std::invalid_argument("this rank was created without the coefficient matrix");
         ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1));
         ugCheck(ug_ctx_timings(d_.ctx2, nullptr, nullptr, 1));
         uint8_t hpart[UG_GROTH16_PARTIALS_SIZE];
@@ -597,7 +683,7 @@ private:
     Range wr_{0, 0}, hr_{0, 0};
     uint64_t cLo_ = 0, cHi_ = 0;       // this rank's slice of the C section
     DeviceProver d_;
-    bool witnessLoaded_ = false;
+    bool witnessLoaded_ = false, witnessComplete_ = false, haveHpoly_ = true;
     double msmMs_ = 0, fftMs_ = 0, totalMs_ = 0;
 };
 
@@ -859,41 +945,18 @@ public:
 
 private:
     static void putPlain(uint8_t* dst, const Fr& v) { u32 w[8]; to_normal(w, v); memcpy(dst, w, 32); }
-    // RawFr::set(int) (build/fr.cpp:209-223): a C int as a field element, negative values as value + r. compute_lookup
-    // passes its `int i` and its `uint32_t frequencies[i]` to field.add(int, Element) / field.mul(int, Element)
-    // (src/ultra_groth.cpp:72,78; overloads build/fr.hpp:249-251), so a frequency >= 2^31 enters as freq - 2^32 + r.
-    static Fr setInt(int32_t v) {
-        u32 w[8] = {v < 0 ? (u32)(-(int64_t)v) : (u32)v, 0, 0, 0, 0, 0, 0, 0};
-        Fr m = from_normal<FrParams>(w);                       // < 2q, strict
-        return v < 0 ? neg<2>(m) : m;
-    }
-    // compute_lookup (src/ultra_groth.cpp:62-106). Host: the 2 L table values inv2[i] = 1 / (i + rand) (0 when the sum
-    // is 0) and prod[i] = freq[i] * inv2[i], with one shared inversion. Device: the writes into the witness
-    // (ug_dvec_apply_lookup; the reference's push_vector with its per-chunk copies of inv2 is never materialised).
+    // compute_lookup (src/ultra_groth.cpp:62-106). The table -- inv2[i] = 1 / (i + rand) (0 when the sum is 0) and
+    // prod[i] = freq[i] * inv2[i], with the reference's (int, Element) overload semantics -- is made on the device
+    // (ug_fr_lookup_table, one lane per row), and so are the writes into the witness (ug_dvec_apply_lookup; the
+    // reference's push_vector with its per-chunk copies of inv2 is never materialised).
     // publicPart receives the writes that land on public signals (they go into public.json).
     void applyLookup(std::vector<uint8_t>& publicPart, const std::vector<uint32_t>& chunks, const std::vector<uint32_t>& freq,
                      const std::vector<uint32_t>& wIdx, const std::vector<uint32_t>& pIdx, const Fr& rand) {
         const size_t L = freq.size(), Cn = chunks.size();
         std::vector<uint8_t> table((2 * L + 1) * 32);                 // [rand | inv2 | prod], plain integers
-        putPlain(table.data(), rand);
-        uint8_t* inv2 = table.data() + 32;
-        uint8_t* prod = inv2 + L * 32;
-        // sums i + rand, then Montgomery's trick: prefix products, one inversion, unwind
-        std::vector<Fr> sum(L), pre(L);
-        Fr acc = fp_one<FrParams>();
-        for (size_t i = 0; i < L; i++) {
-            sum[i] = mul(add(setInt((int32_t)(u32)i), rand), fp_one<FrParams>());     // < 2q
-            pre[i] = acc;
-            if (!is_zero(sum[i])) acc = mul(acc, sum[i]);
-        }
-        Fr inv_acc = inv(acc);
-        for (size_t i = L; i-- > 0;) {
-            Fr inv_i;
-            if (is_zero(sum[i])) inv_i = fp_zero<FrParams>();
-            else { inv_i = mul(inv_acc, pre[i]); inv_acc = mul(inv_acc, sum[i]); }
-            putPlain(inv2 + i * 32, inv_i);
-            putPlain(prod + i * 32, mul(setInt((int32_t)freq[i]), inv_i));
-        }
+        uint8_t randPlain[32];
+        putPlain(randPlain, rand);
+        ugCheck(ug_fr_lookup_table(d_.ctx, randPlain, freq.data(), L, table.data()));     // one lane per row on the device
         ugCheck(ug_dvec_apply_lookup(d_.w, wIdx.data(), pIdx.data(), wIdx.size(), chunks.data(), Cn, table.data(), L));
         // the same writes for the public signals, in order (a later write overwrites an earlier one)
         for (size_t i = 0; i < wIdx.size(); i++) {
@@ -1368,6 +1431,43 @@ int ug_groth16_prover_create_sharded_range(void** prover_object, const void* zke
     if (zkey_buffer == NULL) throw std::invalid_argument("Null zkey buffer");
     Range wr{witness_first, witness_end};
     *prover_object = static_cast<ProverBase*>(new Groth16Prover(zkey_buffer, zkey_size, device, shard_rank, shard_count, &wr));
+    API_CATCH
+}
+int ug_groth16_shard_ranges(unsigned long long n_vars, unsigned long long n_public, unsigned long long domain_size, int shard_rank,
+                            int shard_count, const unsigned long long* witness_range, unsigned long long out[6]) {
+    try {
+        Range wr{0, 0};
+        if (witness_range) { wr.lo = witness_range[0]; wr.hi = witness_range[1]; }
+        Groth16Prover::Ranges r = Groth16Prover::shardRanges(n_vars, n_public, domain_size, shard_rank, shard_count, witness_range ? &wr : nullptr);
+        out[0] = r.w.lo; out[1] = r.w.hi; out[2] = r.c.lo; out[3] = r.c.hi; out[4] = r.h.lo; out[5] = r.h.hi;
+    } catch (...) { return PROVER_ERROR; }
+    return PROVER_OK;
+}
+int ug_groth16_prover_create_sharded_slices(void** prover_object, const void* zkey_header, unsigned long long zkey_header_size,
+                                            const void* coefs, unsigned long long n_coefs, const void* points_a, const void* points_b1,
+                                            const void* points_b2, const void* points_c, const void* points_h, int device, int shard_rank,
+                                            int shard_count, const unsigned long long* witness_range, char* error_msg,
+                                            unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL) throw std::invalid_argument("Null prover object");
+    if (zkey_header == NULL) throw std::invalid_argument("Null zkey buffer");
+    Groth16Prover::Sources src;
+    src.coefs = static_cast<const uint8_t*>(coefs); src.nCoefs = coefs ? n_coefs : 0; src.haveCoefs = coefs != NULL;
+    src.pA = static_cast<const uint8_t*>(points_a); src.pB1 = static_cast<const uint8_t*>(points_b1);
+    src.pB2 = static_cast<const uint8_t*>(points_b2); src.pC = static_cast<const uint8_t*>(points_c);
+    src.pH = static_cast<const uint8_t*>(points_h);
+    Range wr{0, 0};
+    if (witness_range) { wr.lo = witness_range[0]; wr.hi = witness_range[1]; }
+    *prover_object = static_cast<ProverBase*>(new Groth16Prover(zkey_header, zkey_header_size, src, device, shard_rank, shard_count,
+                                                                witness_range ? &wr : nullptr));
+    API_CATCH
+}
+int ug_groth16_prover_load_witness_part(void* prover_object, const void* wtns_buffer, unsigned long long wtns_size, int part,
+                                        char* error_msg, unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL) throw std::invalid_argument("Null prover object");
+    if (wtns_buffer == NULL) throw std::invalid_argument("Null witness buffer");
+    static_cast<ProverBase*>(prover_object)->loadWitnessPart(wtns_buffer, wtns_size, part);
     API_CATCH
 }
 int ug_groth16_prover_load_witness(void* prover_object, const void* wtns_buffer, unsigned long long wtns_size, char* error_msg,

@@ -312,6 +312,16 @@ int ug_dvec_upload(ug_dvec* v, const void* host, uint64_t n) {
     host_to_device(v->ctx, v->data, host, (size_t)n * 32);
     UG_CATCH
 }
+int ug_dvec_upload_range(ug_dvec* v, const void* host, uint64_t first, uint64_t n, ug_ctx* via) {
+    UG_TRY
+    if (!v || (!host && n)) throw std::invalid_argument("null argument");
+    if (first + n > v->n) throw std::invalid_argument("upload outside the vector");
+    ug_ctx* c = via ? via : v->ctx;
+    if (c->device != v->ctx->device) throw std::invalid_argument("upload context on another device");
+    c->use();
+    host_to_device(c, v->data + first * 8, host, (size_t)n * 32);
+    UG_CATCH
+}
 int ug_dvec_download(const ug_dvec* v, void* host, uint64_t first, uint64_t n) {
     UG_TRY
     if (!v || (!host && n)) throw std::invalid_argument("null argument");
@@ -412,6 +422,24 @@ int ug_dvec_apply_lookup(ug_dvec* dst, const uint32_t* w_idx, const uint32_t* p_
     apply_lookup(dst->data, c->lookup_last, d_w, d_p, n, d_c, n_chunks, d_t, c->stream);
     UG_HIP(hipStreamSynchronize(c->stream));
     hipFree(stage);
+    UG_CATCH
+}
+int ug_fr_lookup_table(ug_ctx* c, const void* rand_plain, const uint32_t* frequencies, uint64_t lookup_size, void* table_out) {
+    UG_TRY
+    if (!c || !rand_plain || (!frequencies && lookup_size) || !table_out) throw std::invalid_argument("null argument");
+    c->use();
+    const size_t tbytes = (size_t)(1 + 2 * lookup_size) * 32;
+    u32 *table = nullptr, *freq = nullptr;
+    UG_HIP(hipMalloc(&table, tbytes));
+    UG_HIP(hipMalloc(&freq, lookup_size ? (size_t)lookup_size * 4 : 4));
+    try {
+        UG_HIP(hipMemcpyAsync(table, rand_plain, 32, hipMemcpyHostToDevice, c->stream));
+        if (lookup_size) UG_HIP(hipMemcpyAsync(freq, frequencies, (size_t)lookup_size * 4, hipMemcpyHostToDevice, c->stream));
+        lookup_table(table, freq, lookup_size, c->stream);
+        UG_HIP(hipMemcpyAsync(table_out, table, tbytes, hipMemcpyDeviceToHost, c->stream));
+        UG_HIP(hipStreamSynchronize(c->stream));
+    } catch (...) { hipFree(table); hipFree(freq); throw; }
+    hipFree(table); hipFree(freq);
     UG_CATCH
 }
 uint64_t ug_dvec_size(const ug_dvec* v) { return v ? v->n : 0; }
@@ -633,10 +661,10 @@ int ug_hpoly_chain(ug_hpoly* hp, const ug_dvec* w, int which, ug_dvec* out) {
 int ug_hpoly_combine(ug_hpoly* hp, const ug_dvec* a, const ug_dvec* b, const ug_dvec* cc, uint64_t first, uint64_t count,
                      ug_dvec* h_out) {
     UG_TRY
-    if (!hp || !a || !b || !cc || !h_out) throw std::invalid_argument("null argument");
+    if (!a || !b || !cc || !h_out) throw std::invalid_argument("null argument");
     if (a->n < count || b->n < count || cc->n < count) throw std::invalid_argument("slice vectors shorter than count");
     if (first + count > h_out->n) throw std::invalid_argument("h slice outside the h vector");
-    ug_ctx* c = hp->ctx;
+    ug_ctx* c = hp ? hp->ctx : h_out->ctx;      // (a rank that runs no chain keeps no ug_hpoly: the combine needs none)
     c->use();
     ScopedTimer tm(c, &c->fft_ms);
     fr_h_final(h_out->data + first * 8, a->data, b->data, cc->data, count, c->stream);

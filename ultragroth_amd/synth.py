@@ -78,21 +78,32 @@ def scalars(n, mix, seed):
     return v
 
 
-def coefficients(domain, nvars, seed):
-    """4 * domain packed 44-byte records: rows c = 0..domain-1, two entries in A (m=0) and two in B (m=1)"""
-    rng = np.random.Generator(np.random.PCG64(seed))
+COEF_DTYPE = np.dtype([("m", "<u4"), ("c", "<u4"), ("s", "<u4"), ("v", "<u8", (4,))], align=False)
+COEF_CHUNK_ROWS = 1 << 18
+
+
+def coefficients(domain, nvars, seed, out=None):
+    """4 * domain packed 44-byte records: rows c = 0..domain-1, two entries in A (m=0) and two in B (m=1), generated in
+    chunks of 2^18 rows (each chunk from its own PRNG stream, shuffled within itself: the reference assumes no order --
+    it takes locks), so that the peak host footprint is the output plus one chunk, whatever the domain. Written into
+    `out` (a writable buffer of 4 * domain * 44 bytes) when given."""
+    assert COEF_DTYPE.itemsize == 44
     k = 4 * domain
-    rec = np.zeros(k, dtype=np.dtype([("m", "<u4"), ("c", "<u4"), ("s", "<u4"), ("v", "<u8", (4,))], align=False))
-    assert rec.dtype.itemsize == 44
-    rows = np.repeat(np.arange(domain, dtype=np.uint32), 4)
-    rec["m"] = np.tile(np.array([0, 0, 1, 1], dtype=np.uint32), domain)
-    rec["c"] = rows
-    rec["s"] = rng.integers(0, nvars, size=k, dtype=np.uint32)
-    val = rng.integers(0, 1 << 63, size=(k, 4), dtype=np.uint64)
-    val[:, 3] &= np.uint64((1 << 60) - 1)
-    rec["v"] = val
-    perm = rng.permutation(k)                       # the reference assumes no order (it takes locks)
-    return rec[perm]
+    rec = np.zeros(k, dtype=COEF_DTYPE) if out is None else np.frombuffer(out, dtype=COEF_DTYPE)
+    assert len(rec) == k
+    for ci, r0 in enumerate(range(0, domain, COEF_CHUNK_ROWS)):
+        r1 = min(domain, r0 + COEF_CHUNK_ROWS)
+        n = 4 * (r1 - r0)
+        rng = np.random.Generator(np.random.PCG64([seed, ci]))
+        part = np.zeros(n, dtype=COEF_DTYPE)
+        part["m"] = np.tile(np.array([0, 0, 1, 1], dtype=np.uint32), r1 - r0)
+        part["c"] = np.repeat(np.arange(r0, r1, dtype=np.uint32), 4)
+        part["s"] = rng.integers(0, nvars, size=n, dtype=np.uint32)
+        val = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+        val[:, 3] &= np.uint64((1 << 60) - 1)
+        part["v"] = val
+        rec[4 * r0:4 * r1] = part[rng.permutation(n)]
+    return rec
 
 
 def _section(sid, payload):
@@ -113,9 +124,7 @@ def build_circuit(dev, log_domain, mix="U", seed=0x5EED0000, n_public=1, g1_only
     vk_g2 = bytes(synth_points(dev, 3, SEEDS["VK"], g2=True))           # beta2, gamma2, delta2
     header = struct.pack("<I", 32) + q_le + struct.pack("<I", 32) + r_le + struct.pack("<III", nvars, n_public, domain)
     header += vk_g1[0:64] + vk_g1[64:128] + vk_g2[0:128] + vk_g2[128:256] + vk_g1[128:192] + vk_g2[256:384]
-    if coefs is None:
-        coefs = coefficients(domain, nvars, seed + 1)
-    n_coefs = len(coefs)                                                 # (a caller may pass its own record array)
+    n_coefs = 4 * domain if coefs is None else len(coefs)               # (a caller may pass its own record array)
     sizes = [(1, 4), (2, len(header)), (3, 64 * (n_public + 1)), (4, 4 + 44 * n_coefs), (5, 64 * nvars), (6, 64 * nvars),
              (7, 128 * nvars), (8, 64 * n_c), (9, 64 * domain), (10, 0)]
     total = 12 + sum(12 + sz for _, sz in sizes)
@@ -131,9 +140,12 @@ def build_circuit(dev, log_domain, mix="U", seed=0x5EED0000, n_public=1, g1_only
     view[at[2][0]:at[2][1]] = header
     lo, hi = at[4]
     view[lo:lo + 4] = struct.pack("<I", n_coefs)
-    if n_coefs:
-        np.frombuffer(view[lo + 4:hi], dtype=coefs.dtype)[:] = coefs
-    del coefs
+    if coefs is not None:
+        if n_coefs:
+            np.frombuffer(view[lo + 4:hi], dtype=coefs.dtype)[:] = coefs
+        del coefs
+    else:
+        coefficients(domain, nvars, seed + 1, out=view[lo + 4:hi])       # generated in place, chunk by chunk
     synth_points(dev, nvars, SEEDS["A"], out=view[at[5][0]:at[5][1]])
     if not g1_only:
         # (g1_only = config 2 of BASELINE.json, G1 MSM + NTT only: B1, B2, C stay all-infinity sets of the right size)
@@ -145,6 +157,37 @@ def build_circuit(dev, log_domain, mix="U", seed=0x5EED0000, n_public=1, g1_only
     wtns = build_witness(log_domain, mix, seed)
     info = dict(domainSize=domain, nVars=nvars, nPublic=n_public, nCoefs=n_coefs, mix=mix, seed=seed, g1_only=g1_only)
     return zkey, wtns, info
+
+
+def zkey_header_section(dev, log_domain, n_public=1):
+    """the bytes of zkey section 2 of build_circuit(log_domain)"""
+    domain = 1 << log_domain
+    vk_g1 = bytes(synth_points(dev, 3, SEEDS["VK"]))
+    vk_g2 = bytes(synth_points(dev, 3, SEEDS["VK"], g2=True))
+    header = struct.pack("<I", 32) + Q_MOD.to_bytes(32, "little") + struct.pack("<I", 32) + R_MOD.to_bytes(32, "little")
+    header += struct.pack("<III", domain - 1, n_public, domain)
+    return header + vk_g1[0:64] + vk_g1[64:128] + vk_g2[0:128] + vk_g2[128:256] + vk_g1[128:192] + vk_g2[256:384]
+
+
+def build_circuit_slices(dev, log_domain, ranges, with_coefs=True, seed=0x5EED0000, n_public=1, g1_only=False):
+    """What ONE rank of a sharded prover needs of build_circuit(log_domain, seed=seed), without ever materialising the rest:
+    (header section, coefficient records or None, (A, B1, B2, C, H) slices) for ranges = ((w0, w1), (c0, c1), (h0, h1))
+    as ShardedGroth16Prover.shard_ranges reports them. The points are the same generator walk, entered at the slice."""
+    import ctypes as C
+    domain = 1 << log_domain
+    nvars = domain - 1
+    (w0, w1), (c0, c1), (h0, h1) = ranges
+    coefs = None
+    if with_coefs:
+        coefs = (C.c_char * (4 * domain * 44))()
+        coefficients(domain, nvars, seed + 1, out=coefs)
+
+    def pts(n, name, first, g2=False):
+        if g1_only and name in ("B1", "B2", "C"):
+            return (C.c_char * (n * (128 if g2 else 64)))()
+        return synth_points(dev, n, SEEDS[name] + first, g2=g2)
+    slices = (pts(w1 - w0, "A", w0), pts(w1 - w0, "B1", w0), pts(w1 - w0, "B2", w0, g2=True), pts(c1 - c0, "C", c0), pts(h1 - h0, "H", h0))
+    return zkey_header_section(dev, log_domain, n_public), coefs, slices
 
 
 def build_witness(log_domain, mix="U", seed=0x5EED0000):
