@@ -12,6 +12,13 @@ namespace ug {
 Fr fr_root_of_unity(int s);
 void bitrev_copy(u32* out, const u32* in, int logn, hipStream_t stream);
 
+// Element-wise work folded into the first / last pass of a transform (the H-polynomial block's c = a o b and
+// h = a o b - c, src/groth16.cpp:100-108,142-148) and a separate work buffer so that the inputs stay intact:
+//   in2    first pass: the transform's input element is in[i] * in2[i]
+//   work   intermediate passes run in place here (instead of on `in` / `out`)
+//   fin_a, fin_b   last pass: out[i] = plain integer of fin_a[i] * fin_b[i] - x[i] (32-byte plain, not device form)
+struct NttFusion { const u32* in2 = nullptr; u32* work = nullptr; const u32* fin_a = nullptr; const u32* fin_b = nullptr; };
+
 struct NttPlan {
     int logn = -1;
     u32* tw_fwd = nullptr;    // omega_n^i,   i < n/2
@@ -22,9 +29,11 @@ struct NttPlan {
     void release();
     // DIT transform; see ntt.hip for the buffer rules. post / post_const are optional multipliers
     // applied in the last pass: out[i] *= post[i], or out[i] *= *post_const.
-    // stats (optional): every pass launch is bracketed with an event pair (KernelStats::collect after a stream sync)
+    // stats (optional): every pass launch is bracketed with an event pair (KernelStats::collect after a stream sync).
+    // fuse (optional): see NttFusion.
     void transform(u32* out, const u32* in, bool inverse, bool gather_bitrev, bool scatter_bitrev,
-                   const u32* post, const u32* post_const, hipStream_t stream, struct MsmStats* stats = nullptr) const;
+                   const u32* post, const u32* post_const, hipStream_t stream, struct MsmStats* stats = nullptr,
+                   const struct NttFusion* fuse = nullptr) const;
     ~NttPlan() { release(); }
 };
 

@@ -23,7 +23,8 @@ namespace ug {
 
 namespace {
 
-constexpr int NTT_MAX_LOG_TILE = 11;      // 2^11 elements * 36 B = 72 KiB of LDS, 1024 threads
+constexpr int NTT_MAX_LOG_TILE = 11;      // 2^11 elements * 36 B = 72 KiB of LDS: two workgroups per CU
+constexpr int NTT_THREADS = 512;          // one radix-4 butterfly per lane per step at the full tile
 
 struct PassArgs {
     const u32* in;
@@ -31,6 +32,9 @@ struct PassArgs {
     const u32* tw;        // packed twiddles, stage-major: entry (2^s - 1 + j) = omega_{2^(s+1)}^j, j < 2^s
     const u32* post;      // optional: out[i] *= post[i]   (natural index), nullptr if none
     const u32* post_const;// optional: out[i] *= *post_const
+    const u32* in2;       // optional, first pass: the input element is in[i] * in2[i]
+    const u32* fin_a;     // optional, last pass: out[i] = plain(fin_a[i] * fin_b[i] - x[i]) instead of x[i]
+    const u32* fin_b;
     int logn;
     int s0;               // first stage of this pass
     int k;                // stages in this pass
@@ -39,13 +43,34 @@ struct PassArgs {
     int scatter_bitrev;   // last pass only: write element idx to out[bitrev(idx)]
 };
 
-__global__ __launch_bounds__(1024) void ntt_pass_kernel(PassArgs a) {
+// Raw limb-wise sum / difference WITHOUT the carry pass (limbs may exceed 29 bits): the radix-4 step below feeds them
+// straight into a product or into the next sum. sub adds the 2q table padded by 2 * 2^29 per limb (ff.hpp: sub<K>), so no
+// limb goes negative for a subtrahend with strict limbs.
+__device__ __forceinline__ void raw_add(u32* r, const u32* a, const Fr& b) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) r[i] = a[i] + b.l[i];
+}
+__device__ __forceinline__ void raw_sub2q(u32* r, const u32* a, const Fr& b) {
+    const u32* kq = kq_padded<FrParams, 2>();
+#pragma unroll
+    for (int i = 0; i < NL; i++) r[i] = a[i] + kq[i] - b.l[i];
+}
+__device__ __forceinline__ Fr as_fr(const u32* x) { return fp_from<FrParams>(x); }
+
+// One pass = k consecutive DIT stages on a tile staged in LDS (9 limb planes, conflict-free 4-byte accesses). Stages are
+// taken two at a time as radix-4 steps held in registers: 4 elements and 3 twiddles in, 4 products, 4 elements out per
+// lane -- half the LDS round trips and address arithmetic of radix-2 steps, and only ONE carry pass per element per two
+// stages: the first stage's sums stay un-normalised (limbs < 2^31 + 16, which the column sums of a product with a strict
+// twiddle still hold: 9 * 2^60 + 9 * 2^58 < 2^64). An odd k starts with one radix-2 step. Bounds in units of q: every
+// stage adds a product (< 2q) or its negation (+ 2q), so a pass of 12 stages takes a packed input (< 2^256 < 5.3 q) to
+// below 30 q; the last loop contracts to < 2.01 q for packing.
+__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
     extern __shared__ u32 lds[];
     const int E = 1 << (a.k + a.j);               // elements per workgroup
     const int tid = threadIdx.x, nth = blockDim.x;
     const u32 bid = blockIdx.x;
     const int k = a.k, j = a.j, s0 = a.s0;
-    const u32 emask = (1u << k) - 1, tmask = (1u << j) - 1;
+    const u32 tmask = (1u << j) - 1;
 
     // global index of local element `pos`
     u32 hi = 0, lo0 = 0, base = 0;
@@ -56,55 +81,97 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(PassArgs a) {
         u32 t = pos & tmask, e = pos >> j;
         return (hi << (s0 + k)) | (e << s0) | (lo0 + t);
     };
+    // local position of stage index e in tile t, and the twiddle-table entry of (stage s0 + d, local exponent elow)
+    auto lpos = [&](u32 e, u32 t) -> u32 { return s0 == 0 ? (t << k) | e : (e << j) | t; };
+    auto twidx = [&](int d, u32 elow, u32 t) -> u32 {
+        return s0 == 0 ? ((1u << d) - 1) + elow : ((1u << (s0 + d)) - 1) + ((elow << s0) | (lo0 + t));
+    };
+    // (a bank swizzle of the positions was measured: the early steps' 2- to 4-way conflicts cost nothing visible, the
+    // kernel is bound by vector issue -- 162 multiply-adds and ~190 other vector instructions per butterfly)
+    auto ld = [&](u32* x, u32 pos) {
+#pragma unroll
+        for (int l = 0; l < NL; l++) x[l] = lds[l * E + pos];
+    };
+    auto st = [&](u32 pos, const Fr& y) {
+#pragma unroll
+        for (int l = 0; l < NL; l++) lds[l * E + pos] = y.l[l];
+    };
 
     for (u32 pos = tid; pos < (u32)E; pos += nth) {
         u32 g = gidx(pos);
         u32 src = a.gather_bitrev ? bit_reverse(g, a.logn) : g;
         Fr x = ld_packed<FrParams>(a.in + (size_t)src * 8);
-#pragma unroll
-        for (int l = 0; l < NL; l++) lds[l * E + pos] = x.l[l];
+        if (a.in2) x = mul(x, ld_packed<FrParams>(a.in2 + (size_t)src * 8));      // fused c = a o b (first pass of chain c)
+        st(pos, x);
     }
     __syncthreads();
 
-    for (int d = 0; d < k; d++) {
+    int d = 0;
+    if (k & 1) {                                  // odd stage count: one radix-2 step first
         for (u32 bf = tid; bf < (u32)(E >> 1); bf += nth) {
-            u32 pos0, pos1, twi;
-            if (s0 == 0) {
-                u32 t = bf >> (k - 1), p = bf & ((1u << (k - 1)) - 1);
-                u32 elow = p & ((1u << d) - 1);
-                u32 e0 = ((p >> d) << (d + 1)) | elow;
-                pos0 = (t << k) | e0; pos1 = pos0 + (1u << d);
-                twi = ((1u << d) - 1) + elow;
-            } else {
-                u32 t = bf & tmask, p = bf >> j;
-                u32 elow = p & ((1u << d) - 1);
-                u32 e0 = ((p >> d) << (d + 1)) | elow;
-                pos0 = (e0 << j) | t; pos1 = pos0 + (1u << (d + j));
-                twi = ((1u << (s0 + d)) - 1) + ((elow << s0) | (lo0 + t));
-            }
-            Fr x0, x1;
-#pragma unroll
-            for (int l = 0; l < NL; l++) { x0.l[l] = lds[l * E + pos0]; x1.l[l] = lds[l * E + pos1]; }
-            Fr w = ld_packed<FrParams>(a.tw + (size_t)twi * 8);
-            Fr t = mul(x1, w);                       // < 2q for x1 < 169 q
-            Fr y0 = add(x0, t);                      // grows by < 2q per stage
-            Fr y1 = sub<2>(x0, t);
-#pragma unroll
-            for (int l = 0; l < NL; l++) { lds[l * E + pos0] = y0.l[l]; lds[l * E + pos1] = y1.l[l]; }
+            u32 t, p;
+            if (s0 == 0) { t = bf >> (k - 1); p = bf & ((1u << (k - 1)) - 1); } else { t = bf & tmask; p = bf >> j; }
+            const u32 e0 = p << 1;                // d = 0: elow = 0
+            const u32 pos0 = lpos(e0, t), pos1 = lpos(e0 + 1, t);
+            u32 x0[NL], x1[NL], y[NL];
+            ld(x0, pos0); ld(x1, pos1);
+            Fr w = ld_packed<FrParams>(a.tw + (size_t)twidx(0, 0, t) * 8);
+            Fr tt = mul(as_fr(x1), w);
+            raw_add(y, x0, tt); st(pos0, norm_weak<FrParams>(y));
+            raw_sub2q(y, x0, tt); st(pos1, norm_weak<FrParams>(y));
+        }
+        __syncthreads();
+        d = 1;
+    }
+    for (; d < k; d += 2) {
+        const u32 D = 1u << d;
+        for (u32 bf = tid; bf < (u32)(E >> 2); bf += nth) {
+            u32 t, p;
+            if (s0 == 0) { t = bf >> (k - 2); p = bf & ((1u << (k - 2)) - 1); } else { t = bf & tmask; p = bf >> j; }
+            const u32 elow = p & (D - 1);
+            const u32 e0 = ((p >> d) << (d + 2)) | elow;
+            const u32 p0 = lpos(e0, t), p1 = lpos(e0 + D, t), p2 = lpos(e0 + 2 * D, t), p3 = lpos(e0 + 3 * D, t);
+            // twiddles first: their latency (L2 / HBM) hides behind the LDS reads
+            Fr wa = ld_packed<FrParams>(a.tw + (size_t)twidx(d, elow, t) * 8);
+            Fr wb0 = ld_packed<FrParams>(a.tw + (size_t)twidx(d + 1, elow, t) * 8);
+            Fr wb1 = ld_packed<FrParams>(a.tw + (size_t)twidx(d + 1, elow + D, t) * 8);
+            u32 x0[NL], x1[NL], x2[NL], x3[NL];
+            ld(x0, p0); ld(x1, p1); ld(x2, p2); ld(x3, p3);
+            // stage d: (x0, x1) and (x2, x3), both with wa; sums left raw
+            Fr t1 = mul(as_fr(x1), wa);
+            Fr t3 = mul(as_fr(x3), wa);
+            u32 a0[NL], a1[NL], a2[NL], a3[NL];
+            raw_add(a0, x0, t1); raw_sub2q(a1, x0, t1);
+            raw_add(a2, x2, t3); raw_sub2q(a3, x2, t3);
+            // stage d + 1: (a0, a2) with wb0, (a1, a3) with wb1 = wb0 * omega_4
+            Fr u2 = mul(as_fr(a2), wb0);
+            Fr u3 = mul(as_fr(a3), wb1);
+            u32 y[NL];
+            raw_add(y, a0, u2); st(p0, norm_weak<FrParams>(y));
+            raw_sub2q(y, a0, u2); st(p2, norm_weak<FrParams>(y));
+            raw_add(y, a1, u3); st(p1, norm_weak<FrParams>(y));
+            raw_sub2q(y, a1, u3); st(p3, norm_weak<FrParams>(y));
         }
         __syncthreads();
     }
 
     for (u32 pos = tid; pos < (u32)E; pos += nth) {
         Fr x;
-#pragma unroll
-        for (int l = 0; l < NL; l++) x.l[l] = lds[l * E + pos];
+        ld(x.l, pos);
         u32 g = gidx(pos);
         if (a.post) x = mul(x, ld_packed<FrParams>(a.post + (size_t)g * 8));   // strict, < 2q
         else if (a.post_const) x = mul(x, ld_packed<FrParams>(a.post_const));
         else x = contract(x);                                                   // < 2.01 q, strict
         u32 dst = a.scatter_bitrev ? bit_reverse(g, a.logn) : g;
-        st_packed(a.out + (size_t)dst * 8, x);
+        if (a.fin_a) {
+            // fused h = a o b - c, plain integers (last pass of the third chain; S9, src/groth16.cpp:142-148)
+            Fr tt = mul(ld_packed<FrParams>(a.fin_a + (size_t)dst * 8), ld_packed<FrParams>(a.fin_b + (size_t)dst * 8));   // < 2q
+            u32 w[8];
+            to_normal(w, sub<6>(tt, x));                                        // x < 2.01 q here
+            store8(a.out + (size_t)dst * 8, w);
+        } else {
+            st_packed(a.out + (size_t)dst * 8, x);
+        }
     }
 }
 
@@ -213,14 +280,17 @@ void NttPlan::release() {
 // natural order, gathered on the fly); output natural order, or bit-reversed if scatter_bitrev.
 // post (optional) multiplies output element i (natural index) by post[i] in the last pass.
 void NttPlan::transform(u32* out, const u32* in, bool inverse, bool gather_bitrev, bool scatter_bitrev,
-                        const u32* post, const u32* post_const, hipStream_t stream, MsmStats* stats) const {
+                        const u32* post, const u32* post_const, hipStream_t stream, MsmStats* stats, const NttFusion* fuse) const {
+    const u32* in2 = fuse ? fuse->in2 : nullptr;
+    u32* work = fuse ? fuse->work : nullptr;
     if (logn == 0) {
+        if (in2 || (fuse && fuse->fin_a)) throw std::invalid_argument("ntt: fused forms need at least two points");
         if (out != in) UG_HIP(hipMemcpyAsync(out, in, 32, hipMemcpyDeviceToDevice, stream));
         return;   // size-1 transform is the identity (n^-1 = 1, omega_2^0 = 1)
     }
     if (gather_bitrev && scatter_bitrev) throw std::invalid_argument("ntt: gather and scatter together not supported");
     if ((gather_bitrev || scatter_bitrev) && out == in) throw std::invalid_argument("ntt: permuting transform must be out of place");
-    // split the stages: first pass contiguous (up to 11 stages), then strided passes with 2^j tiles
+    // split the stages: first pass contiguous (up to 11 stages), then strided passes with 2^j adjacent elements per row
     int stages[8], nj[8], np = 0, rem = logn;
     int first = rem < NTT_MAX_LOG_TILE ? rem : NTT_MAX_LOG_TILE;
     stages[np] = first; nj[np] = 0; np++; rem -= first;
@@ -230,14 +300,18 @@ void NttPlan::transform(u32* out, const u32* in, bool inverse, bool gather_bitre
         int k = (rem + npass_left - 1) / npass_left;
         stages[np] = k; nj[np] = NTT_MAX_LOG_TILE - k; np++; rem -= k;
     }
-    // Buffer plan: a scatter pass (last) reads `in`-resident data and writes `out`; otherwise the
-    // first pass moves in -> out and the rest run in place on `out`. `in` is clobbered when scattering.
+    // Buffer plan. Intermediate passes run in place on a work buffer: `work` when given (then `in`, and `in2`, are only
+    // read), else `in` itself for a scattering transform (which is clobbered) and `out` otherwise. The last pass writes `out`.
+    u32* mid = work ? work : (scatter_bitrev ? const_cast<u32*>(in) : out);
     int s0 = 0;
     for (int p = 0; p < np; p++) {
         PassArgs a;
         bool last = (p == np - 1);
-        if (scatter_bitrev) { a.in = in; a.out = last ? out : const_cast<u32*>(in); }
-        else { a.in = (p == 0) ? in : out; a.out = out; }
+        a.in = (p == 0) ? in : mid;
+        a.out = last ? out : mid;
+        a.in2 = (p == 0) ? in2 : nullptr;
+        a.fin_a = (last && fuse) ? fuse->fin_a : nullptr;
+        a.fin_b = (last && fuse) ? fuse->fin_b : nullptr;
         a.tw = inverse ? tw_inv : tw_fwd; a.logn = logn; a.s0 = s0; a.k = stages[p];
         a.j = nj[p];
         if (s0 > 0 && a.j > s0) a.j = s0;
@@ -247,7 +321,7 @@ void NttPlan::transform(u32* out, const u32* in, bool inverse, bool gather_bitre
         a.post_const = last ? post_const : nullptr;
         int E = 1 << (a.k + a.j);
         unsigned blocks = (unsigned)(((u64)1 << logn) >> (a.k + a.j));
-        int threads = E / 2 > 1024 ? 1024 : (E / 2 < 64 ? 64 : E / 2);
+        int threads = E / 4 > NTT_THREADS ? NTT_THREADS : (E / 4 < 64 ? 64 : E / 4);
         size_t lds = (size_t)E * NL * 4;
         int slot = stats ? stats->begin(stream, (u64)1 << logn) : -1;
         hipLaunchKernelGGL(ntt_pass_kernel, dim3(blocks), dim3(threads), lds, stream, a);

@@ -119,7 +119,7 @@ struct ug_schedule {
 };
 struct ug_hpoly {
     ug_ctx* ctx; CoefMatrix mat; NttPlan ntt; u32 domain = 0, nvars = 0;
-    u32 *a = nullptr, *b = nullptr, *c = nullptr, *t = nullptr;     // domain elements each
+    u32 *a = nullptr, *b = nullptr, *c = nullptr, *t = nullptr, *t2 = nullptr;     // domain elements each
 };
 
 namespace {
@@ -597,7 +597,7 @@ int ug_hpoly_create(ug_ctx* c, const void* host_coefs, uint64_t n_coefs, uint32_
     hp->ntt.init(hp->mat.logn, c->stream);
     size_t bytes = (size_t)domain * 32;
     UG_HIP(hipMalloc(&hp->a, bytes)); UG_HIP(hipMalloc(&hp->b, bytes));
-    UG_HIP(hipMalloc(&hp->c, bytes)); UG_HIP(hipMalloc(&hp->t, bytes));
+    UG_HIP(hipMalloc(&hp->c, bytes)); UG_HIP(hipMalloc(&hp->t, bytes)); UG_HIP(hipMalloc(&hp->t2, bytes));
     *out = hp.release();
     UG_CATCH
 }
@@ -614,16 +614,26 @@ int ug_hpoly_run(ug_hpoly* hp, const ug_dvec* w, ug_dvec* h_out) {
     u64 n = hp->domain;
     // S5-S6: a = A.w, b = B.w   (rows stored bit-reversed)            src/groth16.cpp:66-99
     coef_matvec(hp->a, hp->b, hp->mat, w->data, 3, st);
-    // S7: c = a o b                                                    :100-108
-    fr_mul_pointwise(hp->c, hp->a, hp->b, n, st);
+    if (hp->mat.logn == 0) {
+        // one-point domain: every transform is the identity (n^-1 = 1, omega_2^0 = 1), nothing to fold into
+        fr_mul_pointwise(hp->c, hp->a, hp->b, n, st);
+        fr_h_final(h_out->data, hp->a, hp->b, hp->c, n, st);
+        tm.stop();
+        return UG_OK;
+    }
+    // S7 + the inverse half of the third chain: c = a o b is formed inside the first pass of its ifft (:100-108), whose
+    // passes run on hp->c so that a and b stay intact; the twisted coefficients wait in hp->t2
+    NttFusion cinv; cinv.in2 = hp->b; cinv.work = hp->c;
+    hp->ntt.transform(hp->t2, hp->a, /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, &c->stats[2], &cinv);
     // S8: ifft, twist by omega_2n^i (with 1/n folded in), fft          :110-140
-    u32* polys[3] = {hp->a, hp->b, hp->c};
-    for (int p = 0; p < 3; p++) {
+    u32* polys[2] = {hp->a, hp->b};
+    for (int p = 0; p < 2; p++) {
         hp->ntt.transform(hp->t, polys[p], /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, &c->stats[2]);
         hp->ntt.transform(polys[p], hp->t, /*inverse*/ false, false, false, nullptr, nullptr, st, &c->stats[2]);
     }
-    // S9: h = a o b - c, to plain integers                             :142-148
-    fr_h_final(h_out->data, hp->a, hp->b, hp->c, n, st);
+    // the forward half of the third chain, with S9 (h = a o b - c, to plain integers, :142-148) inside its last pass
+    NttFusion cfwd; cfwd.work = hp->c; cfwd.fin_a = hp->a; cfwd.fin_b = hp->b;
+    hp->ntt.transform(h_out->data, hp->t2, /*inverse*/ false, false, false, nullptr, nullptr, st, &c->stats[2], &cfwd);
     tm.stop();
     c->stats[2].collect();
     UG_CATCH
@@ -642,16 +652,21 @@ int ug_hpoly_chain(ug_hpoly* hp, const ug_dvec* w, int which, ug_dvec* out) {
     ScopedTimer tm(c, &c->fft_ms);
     hipStream_t st = c->stream;
     u64 n = hp->domain;
-    u32* src;
+    if (which == 2 && hp->mat.logn == 0) {
+        coef_matvec(hp->a, hp->b, hp->mat, w->data, 3, st);
+        fr_mul_pointwise(out->data, hp->a, hp->b, n, st);                // one-point domain: the chain is the identity
+        tm.stop();
+        return UG_OK;
+    }
     if (which == 2) {
         coef_matvec(hp->a, hp->b, hp->mat, w->data, 3, st);
-        fr_mul_pointwise(hp->c, hp->a, hp->b, n, st);
-        src = hp->c;
+        NttFusion cinv; cinv.in2 = hp->b; cinv.work = hp->c;             // c = a o b inside the first pass
+        hp->ntt.transform(hp->t, hp->a, /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, &c->stats[2], &cinv);
     } else {
         coef_matvec(hp->a, hp->b, hp->mat, w->data, 1 << which, st);
-        src = which ? hp->b : hp->a;
+        u32* src = which ? hp->b : hp->a;
+        hp->ntt.transform(hp->t, src, /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, &c->stats[2]);
     }
-    hp->ntt.transform(hp->t, src, /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, &c->stats[2]);
     hp->ntt.transform(out->data, hp->t, /*inverse*/ false, false, false, nullptr, nullptr, st, &c->stats[2]);
     tm.stop();
     c->stats[2].collect();
@@ -679,6 +694,8 @@ int ug_hpoly_debug_abc(ug_hpoly* hp, void* ha, void* hb, void* hc) {
     c->use();
     void* host[3] = {ha, hb, hc};
     u32* dev[3] = {hp->a, hp->b, hp->c};
+    // ug_hpoly_run folds the third chain's last pass into h; its coset evaluations are re-made from the twisted coefficients
+    if (hc) hp->ntt.transform(hp->c, hp->t2, /*inverse*/ false, false, false, nullptr, nullptr, c->stream);
     for (int p = 0; p < 3; p++) {
         if (!host[p]) continue;
         fr_to_mont256(hp->t, dev[p], hp->domain, c->stream);
@@ -691,7 +708,7 @@ int ug_hpoly_debug_abc(ug_hpoly* hp, void* ha, void* hb, void* hc) {
 void ug_hpoly_destroy(ug_hpoly* hp) {
     if (!hp) return;
     hipSetDevice(hp->ctx->device);
-    hipFree(hp->a); hipFree(hp->b); hipFree(hp->c); hipFree(hp->t);
+    hipFree(hp->a); hipFree(hp->b); hipFree(hp->c); hipFree(hp->t); hipFree(hp->t2);
     hp->mat.release(); hp->ntt.release();
     delete hp;
 }
