@@ -137,6 +137,15 @@ int  ug_msm_g2(ug_ctx* ctx, const ug_bases* bases, const ug_schedule* s, int64_t
  * a single host synchronisation: outs[k] receives what ug_msm_g1 / ug_msm_g2 would write for bases[k]. */
 int  ug_msm_batch(ug_ctx* ctx, int count, const ug_bases* const* bases, const ug_schedule* s, const int64_t* index_shifts,
                   void* const* outs_affine);
+/* The same in two halves, so that a whole proof needs ONE host wait: ug_msm_batch_enqueue queues the products (up to 8
+ * per context may be pending; `outs` must stay valid) and returns at once; ug_ctx_collect waits for everything queued on
+ * the context, then finishes the queued results on the host (Horner, affine conversion) into their `outs`. Schedules
+ * (ug_schedule_build*) and ug_hpoly_run queue their work without a host wait as well. ug_ctx_wait orders two contexts on
+ * the device: what is queued on `waiter` afterwards starts when what was queued on `signal` before has finished. */
+int  ug_msm_batch_enqueue(ug_ctx* ctx, int count, const ug_bases* const* bases, const ug_schedule* schedule,
+                          const int64_t* index_shifts, void* const* outs);
+int  ug_ctx_collect(ug_ctx* ctx);
+int  ug_ctx_wait(ug_ctx* waiter, ug_ctx* signal);
 
 /* coefs: n_coefs packed 44-byte records {u32 m, u32 c, u32 s, Fr coef} (zkey section 4 past its 4-byte
  * count, src/groth16.cpp:38). Builds the row-sorted matrix and the NTT tables for domain_size. */

@@ -17,7 +17,7 @@ INNER_SYMBOLS = [
     "ug_msm_table_window", "ug_bases_tables_bytes", "ug_bases_precompute", "ug_ctx_mem_info", "ug_schedule_build_tables",
     "ug_dvec_create", "ug_dvec_upload", "ug_dvec_upload_range", "ug_dvec_download", "ug_dvec_gather", "ug_dvec_scatter", "ug_dvec_apply_lookup", "ug_fr_lookup_table", "ug_index_create", "ug_index_destroy", "ug_dvec_gather_index", "ug_dvec_wrap", "ug_dvec_size", "ug_dvec_destroy",
     "ug_schedule_create", "ug_schedule_build", "ug_schedule_destroy",
-    "ug_msm_g1", "ug_msm_g2", "ug_msm_batch",
+    "ug_msm_g1", "ug_msm_g2", "ug_msm_batch", "ug_msm_batch_enqueue", "ug_ctx_collect", "ug_ctx_wait",
     "ug_hpoly_create", "ug_hpoly_run", "ug_hpoly_chain", "ug_hpoly_combine", "ug_hpoly_debug_abc", "ug_hpoly_destroy",
     "ug_fr_ntt", "ug_field_op", "ug_synth_points", "ug_ctx_timings", "ug_ctx_kernel_stats",
     "ug_bases_drop_tables", "ug_bases_table_window", "ug_schedule_trim", "ug_ctx_trim",

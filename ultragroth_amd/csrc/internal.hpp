@@ -66,16 +66,12 @@ struct MsmSchedule {
     const u32* tvals = nullptr;
     u32* bucket_start = nullptr;  // per bucket: first entry
     u32* bucket_count = nullptr;  // per bucket: number of entries
-    u32 n_valid = 0;              // entries with a non-zero digit
     int log_seg = 0;              // entries per lane of the segmented accumulation = 2^log_seg
-    u32 n_heavy = 0;              // buckets cut into more than FIX_MAX pieces
     u32* heavy_list = nullptr;    // device: HeavyBucket[heavy_cap]
     u32 heavy_cap = 0;
     u32* medium_list = nullptr;   // device: HeavyBucket[heavy_cap] for buckets of FIX_MAX < pieces <= MEDIUM_MAX
-    u32 n_medium = 0;
     u32* heavy_offsets = nullptr; // device: first task of each heavy bucket (n_heavy + 1 entries)
-    u32 n_heavy_tasks = 0;
-    u32* meta = nullptr;          // device: [n_heavy, n_valid, n_heavy_tasks, n_medium]
+    u32* meta = nullptr;          // device: [n_heavy, n_valid, n_heavy_tasks, n_medium] -- read by the kernels, never by the host
     // workspace
     u32 *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
@@ -99,7 +95,7 @@ struct MsmWorkspace {
 };
 
 struct MsmStats {                 // HIP-event timing of one kernel's launches (bucket accumulation G1 / G2, NTT passes)
-    static constexpr int SLOTS = 32;                // launches that may be in flight before collect()
+    static constexpr int SLOTS = 64;                // launches that may be in flight before collect()
     static constexpr int MAX_BATCH = 8;             // MSMs queued back to back by ug_msm_batch
     hipEvent_t ev0[SLOTS] = {}, ev1[SLOTS] = {};
     u64 slot_entries[SLOTS] = {};

@@ -228,13 +228,15 @@ __host__ __device__ __forceinline__ u64 transposed_index(u64 seg, u32 k, int log
 // one workgroup per tile of 64 segments: coalesced reads of the tile's 64 * 2^log_seg consecutive entries,
 // transposition through LDS (row stride padded by one word), coalesced writes
 __global__ __launch_bounds__(1024) void transpose_entries_kernel(const u32* __restrict__ keys, const u32* __restrict__ vals,
-                                                                u32 n_valid, u32 sentinel, int log_seg,
+                                                                const u32* __restrict__ meta, u32 sentinel, int log_seg,
                                                                 u32* __restrict__ tkeys, u32* __restrict__ tvals) {
     extern __shared__ u32 tile[];                                   // 2 arrays of 64 * (S + 1) words
     const u32 S = 1u << log_seg, row = S + 1;
     u32* tk = tile;
     u32* tv = tile + 64 * row;
+    const u32 n_valid = meta[1];                                    // (the grid covers every entry: the host never reads the count)
     const u64 base = (u64)blockIdx.x << (log_seg + 6);
+    if (base >= n_valid) return;
     for (u32 i = threadIdx.x; i < (64u << log_seg); i += blockDim.x) {
         u64 src = base + i;
         bool in = src < n_valid;
@@ -253,9 +255,10 @@ __global__ __launch_bounds__(1024) void transpose_entries_kernel(const u32* __re
 template <class Cfg>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Cfg::ACC_WAVES, Cfg::ACC_WAVES))) void segment_accumulate_kernel(const u32* __restrict__ bases, u64 n_bases, int64_t delta,
                                                                  const u32* __restrict__ keys, const u32* __restrict__ tkeys,
-                                                                 const u32* __restrict__ tvals, u32 n_valid, int log_seg,
+                                                                 const u32* __restrict__ tvals, const u32* __restrict__ meta, int log_seg,
                                                                  u32* __restrict__ bucket_pts, u32* __restrict__ slot_pts) {
     typedef typename Cfg::F F;
+    const u32 n_valid = meta[1];
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     u64 lo = (u64)t << log_seg;
     if (lo >= n_valid) return;
@@ -332,8 +335,10 @@ __device__ __forceinline__ XYZZ<typename Cfg::F> load_piece(const u32* slot_pts,
 // when most buckets lie inside one segment). Buckets with more than FIX_MAX pieces go to the wave / workgroup paths.
 template <class Cfg>
 __global__ __launch_bounds__(128) void bucket_fixup_kernel(const u32* __restrict__ keys, const u32* __restrict__ start,
-                                                           const u32* __restrict__ count, u32 n_valid, u32 nseg, int log_seg,
+                                                           const u32* __restrict__ count, const u32* __restrict__ meta, int log_seg,
                                                            const u32* __restrict__ slot_pts, u32* __restrict__ bucket_pts) {
+    const u32 n_valid = meta[1];
+    const u32 nseg = (u32)(((u64)n_valid + ((u64)1 << log_seg) - 1) >> log_seg);
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t + 1 >= nseg) return;
     typedef typename Cfg::F F;
@@ -368,9 +373,10 @@ __device__ __forceinline__ XYZZ<typename Cfg::F> block_reduce(XYZZ<typename Cfg:
 // Medium buckets (FIX_MAX < pieces <= MEDIUM_MAX; the short top window of uniform scalars makes thousands of
 // them): one wave per bucket, lanes stride over the pieces, then a 6-step cross-lane butterfly of full additions.
 template <class Cfg>
-__global__ __launch_bounds__(256) void medium_bucket_kernel(const HeavyBucket* mb, u32 n_medium, const u32* slot_pts, u32* bucket_pts) {
+__global__ __launch_bounds__(256) void medium_bucket_kernel(const HeavyBucket* mb, const u32* meta, u32 cap, const u32* slot_pts, u32* bucket_pts) {
     typedef typename Cfg::F F;
     const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const u32 n_medium = meta[3] < cap ? meta[3] : cap;
     if (wave >= n_medium) return;
     HeavyBucket h = mb[wave];
     u32 pieces = h.last_seg - h.first_seg + 1;
@@ -415,11 +421,13 @@ __global__ __launch_bounds__(1024) void heavy_plan_kernel(const HeavyBucket* hb,
 }
 
 template <class Cfg>
-__global__ __launch_bounds__(Cfg::BLOCK) void heavy_partial_kernel(const HeavyBucket* hb, const u32* offsets, u32 n_heavy,
+__global__ __launch_bounds__(Cfg::BLOCK) void heavy_partial_kernel(const HeavyBucket* hb, const u32* offsets, const u32* meta, u32 cap,
                                                                    const u32* slot_pts, u32* task_pts) {
     __shared__ u32 lds[Cfg::PT_WORDS * Cfg::BLOCK / 2];
     typedef typename Cfg::F F;
     const u32 task = blockIdx.x;
+    const u32 n_heavy = meta[0] < cap ? meta[0] : cap;
+    if (task >= meta[2]) return;                       // (uniform per workgroup: the grid is an upper bound)
     u32 lo = 0, hi = n_heavy;                          // last heavy bucket whose first task is <= task
     while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (offsets[mid] <= task) lo = mid; else hi = mid; }
     HeavyBucket h = hb[lo];
@@ -432,10 +440,11 @@ __global__ __launch_bounds__(Cfg::BLOCK) void heavy_partial_kernel(const HeavyBu
 }
 
 template <class Cfg>
-__global__ __launch_bounds__(Cfg::BLOCK) void heavy_final_kernel(const HeavyBucket* hb, const u32* offsets, const u32* task_pts,
-                                                                 u32* bucket_pts) {
+__global__ __launch_bounds__(Cfg::BLOCK) void heavy_final_kernel(const HeavyBucket* hb, const u32* offsets, const u32* meta, u32 cap,
+                                                                 const u32* task_pts, u32* bucket_pts) {
     __shared__ u32 lds[Cfg::PT_WORDS * Cfg::BLOCK / 2];
     typedef typename Cfg::F F;
+    if (blockIdx.x >= (meta[0] < cap ? meta[0] : cap)) return;
     HeavyBucket h = hb[blockIdx.x];
     u32 t0 = offsets[blockIdx.x], t1 = offsets[blockIdx.x + 1];
     XYZZ<F> acc = xyzz_inf<F>();
@@ -698,7 +707,6 @@ void MsmSchedule::reserve(const MsmGeometry& g) {
 void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_t stream) {
     geo = g;
     reserve(g);
-    n_heavy = 0; n_medium = 0; n_heavy_tasks = 0; n_valid = 0;
     log_seg = segment_log(g.n * g.windows);
     if (g.n == 0) return;
     u64 total = g.n * g.windows;
@@ -727,23 +735,17 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
     UG_KERNEL_CHECK();
     hipLaunchKernelGGL(heavy_plan_kernel, dim3(1), dim3(1024), 0, stream, (const HeavyBucket*)heavy_list, heavy_cap, meta, heavy_offsets);
     UG_KERNEL_CHECK();
-    u32 m[4] = {0, 0, 0, 0};
-    UG_HIP(hipMemcpyAsync(m, meta, 16, hipMemcpyDeviceToHost, stream));
-    UG_HIP(hipStreamSynchronize(stream));
-    if (m[0] > heavy_cap || m[3] > heavy_cap) throw std::runtime_error("msm: heavy-bucket list overflow");
-    n_medium = m[3];
-    n_heavy = m[0];
-    n_valid = m[1];
-    n_heavy_tasks = m[2];
+    // No read-back of the counts: every later launch is sized by an upper bound derived from n * windows and reads the
+    // true counts (meta) on the device, so a schedule costs the host no synchronisation.
     // lane-transposed copy of the valid entries into the sort's spare buffers
     u64 tile = (u64)64 << log_seg;
-    u64 n_padded = ((u64)n_valid + tile - 1) / tile * tile;
+    u64 n_tiles = (total + tile - 1) / tile;
     u32* tk = (keys == keys_a) ? keys_b : keys_a;
     u32* tv = (vals == vals_a) ? vals_b : vals_a;
-    if (n_padded) {
+    {
         size_t lds = (size_t)2 * 64 * (((size_t)1 << log_seg) + 1) * 4;
-        hipLaunchKernelGGL(transpose_entries_kernel, dim3((unsigned)(n_padded / tile)), dim3(1024), lds, stream,
-                           keys, vals, n_valid, sentinel, log_seg, tk, tv);
+        hipLaunchKernelGGL(transpose_entries_kernel, dim3((unsigned)n_tiles), dim3(1024), lds, stream,
+                           keys, vals, meta, sentinel, log_seg, tk, tv);
         UG_KERNEL_CHECK();
     }
     tkeys = tk; tvals = tv;
@@ -786,33 +788,38 @@ MsmPending msm_enqueue(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases,
     if (g.n == 0 || n_bases == 0) return pend;
     if ((size_t)pend.bucket_windows * Cfg::PT_WORDS > MSM_PENDING_WORDS) throw std::logic_error("msm: result block too large");
     pend.empty = false;
-    u32 nb = (u32)g.total_buckets();
-    u64 nseg = ((u64)s.n_valid + ((u64)1 << s.log_seg) - 1) >> s.log_seg;
-    ws.reserve(g, Cfg::PT_WORDS == G2Cfg::PT_WORDS, nseg, s.n_heavy_tasks);
+    // upper bounds of what the schedule holds (the true counts stay on the device, MsmSchedule::meta):
+    // segments; heavy buckets (each spans more than MEDIUM_MAX segments); their 1024-piece tasks; medium buckets
+    const u64 total = g.n * g.windows;
+    const u64 nseg = (total + ((u64)1 << s.log_seg) - 1) >> s.log_seg;
+    const u32 heavy_max = (u32)std::min<u64>(s.heavy_cap, nseg / MEDIUM_MAX + 1);
+    const u32 tasks_max = (u32)((nseg + heavy_max) / HEAVY_TASK + heavy_max + 1);
+    const u32 medium_max = (u32)std::min<u64>(s.heavy_cap, nseg / (FIX_MAX - 1) + 1);
+    ws.reserve(g, Cfg::PT_WORDS == G2Cfg::PT_WORDS, nseg, tasks_max);
     int slot = stats ? stats->begin(stream, g.n * g.windows) : -1;
     if (nseg) {
         hipLaunchKernelGGL(segment_accumulate_kernel<Cfg>, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, stream,
-                           bases, n_bases, delta, s.keys, s.tkeys, s.tvals, s.n_valid, s.log_seg, ws.bucket_pts, ws.slot_pts);
+                           bases, n_bases, delta, s.keys, s.tkeys, s.tvals, s.meta, s.log_seg, ws.bucket_pts, ws.slot_pts);
         UG_KERNEL_CHECK();
     }
     if (stats) stats->end(slot, stream);
     if (nseg > 1) {
         hipLaunchKernelGGL(bucket_fixup_kernel<Cfg>, dim3((unsigned)((nseg + 127) / 128)), dim3(128), 0, stream,
-                           s.keys, s.bucket_start, s.bucket_count, s.n_valid, (u32)nseg, s.log_seg, ws.slot_pts, ws.bucket_pts);
+                           s.keys, s.bucket_start, s.bucket_count, s.meta, s.log_seg, ws.slot_pts, ws.bucket_pts);
         UG_KERNEL_CHECK();
-    }
-    if (s.n_medium) {
-        hipLaunchKernelGGL(medium_bucket_kernel<Cfg>, dim3((s.n_medium + 3) / 4), dim3(256), 0, stream,
-                           (const HeavyBucket*)s.medium_list, s.n_medium, ws.slot_pts, ws.bucket_pts);
-        UG_KERNEL_CHECK();
-    }
-    if (s.n_heavy) {
-        hipLaunchKernelGGL(heavy_partial_kernel<Cfg>, dim3(s.n_heavy_tasks), dim3(Cfg::BLOCK), 0, stream,
-                           (const HeavyBucket*)s.heavy_list, s.heavy_offsets, s.n_heavy, ws.slot_pts, ws.task_pts);
-        UG_KERNEL_CHECK();
-        hipLaunchKernelGGL(heavy_final_kernel<Cfg>, dim3(s.n_heavy), dim3(Cfg::BLOCK), 0, stream,
-                           (const HeavyBucket*)s.heavy_list, s.heavy_offsets, ws.task_pts, ws.bucket_pts);
-        UG_KERNEL_CHECK();
+        if (nseg > FIX_MAX) {
+            hipLaunchKernelGGL(medium_bucket_kernel<Cfg>, dim3((medium_max + 3) / 4), dim3(256), 0, stream,
+                               (const HeavyBucket*)s.medium_list, s.meta, medium_max, ws.slot_pts, ws.bucket_pts);
+            UG_KERNEL_CHECK();
+        }
+        if (nseg > MEDIUM_MAX) {
+            hipLaunchKernelGGL(heavy_partial_kernel<Cfg>, dim3(tasks_max), dim3(Cfg::BLOCK), 0, stream,
+                               (const HeavyBucket*)s.heavy_list, s.heavy_offsets, s.meta, heavy_max, ws.slot_pts, ws.task_pts);
+            UG_KERNEL_CHECK();
+            hipLaunchKernelGGL(heavy_final_kernel<Cfg>, dim3(heavy_max), dim3(Cfg::BLOCK), 0, stream,
+                               (const HeavyBucket*)s.heavy_list, s.heavy_offsets, s.meta, heavy_max, ws.task_pts, ws.bucket_pts);
+            UG_KERNEL_CHECK();
+        }
     }
     int chunk = reduce_chunk(g);
     const int bw = g.bucket_windows();                 // bucket sets: one per window, or one in all with window tables

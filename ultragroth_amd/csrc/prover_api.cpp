@@ -490,6 +490,7 @@ public:
         if (!wh.primeIsBn254) throw std::invalid_argument("different wtns curve");
         const uint8_t* data = checkedSection(f, 2, (uint64_t)hdr_.nVars * 32);
         publicPart_.assign(data, data + ((size_t)hdr_.nPublic + 1) * 32);
+        resetTimings();
         ugCheck(ug_dvec_upload(d_.w, data, hdr_.nVars));
         witnessLoaded_ = true; witnessComplete_ = true;
         uploadMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -507,6 +508,7 @@ public:
         if (!wh.primeIsBn254) throw std::invalid_argument("different wtns curve");
         const uint8_t* data = checkedSection(f, 2, (uint64_t)hdr_.nVars * 32);
         if (part == 0) {
+            resetTimings();
             publicPart_.assign(data, data + ((size_t)hdr_.nPublic + 1) * 32);
             ugCheck(ug_dvec_upload_range(d_.w, data + wr_.lo * 32, wr_.lo, wr_.hi - wr_.lo, 0));
             witnessLoaded_ = true; witnessComplete_ = false;
@@ -522,7 +524,6 @@ public:
     // S1-S4 on this rank's slice; partials = A | B1 | B2 | C | H affine records (H left at infinity)
     void runWitnessMsm(uint8_t* partials, bool standalone = true) override {
         if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
-        if (standalone) { ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1)); ugCheck(ug_ctx_timings(d_.ctx2, nullptr, nullptr, 1)); }
         // A schedule holds at most 2^31 (scalar, window) entries; ranges above MAX_RANGE scalars (only the
         // reference's largest legal domain, 2^27, needs it) are proved in pieces whose partial sums are added.
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
@@ -539,7 +540,7 @@ public:
             ugCheck(ug_msm_batch(d_.ctx, 4, sets, d_.sw, shifts, outs));
             if (out == part && ug_groth16_partials_add(partials, part) != PROVER_OK) throw std::runtime_error("partial sum failed");
         }
-        if (standalone) collectTimings();        // (inside run() the two branches may be on two threads: run() collects once)
+        if (standalone) collectTimings(1);
     }
     // S10 on this rank's slice of h (which must be in d_.h); only the H record of partials is written
     void runHMsm(uint8_t* partials) override { runHMsmImpl(partials, true); }
@@ -551,16 +552,22 @@ public:
             uint8_t* out = (lo == hr_.lo) ? partials : part;
             memset(part, 0, sizeof part);
             buildSchedule(d_.sh, d_.h, lo, n, tableH_);
-            ugCheck(ug_msm_g1(d_.ctx2, d_.H, d_.sh, 0, out + 320));                            // S10 :154
+            const ug_bases* sets[1] = {d_.H};
+            void* outs[1] = {out + 320};
+            ugCheck(ug_msm_batch(d_.ctx2, 1, sets, d_.sh, nullptr, outs));                     // S10 :154
             if (out == part && ug_groth16_partials_add(partials, part) != PROVER_OK) throw std::runtime_error("partial sum failed");
         }
-        if (standalone) collectTimings();
+        if (standalone) collectTimings(2);
     }
-    void collectTimings() {
-        double m1 = 0, f1 = 0, m2 = 0, f2 = 0;
-        ugCheck(ug_ctx_timings(d_.ctx, &m1, &f1, 0));
-        ugCheck(ug_ctx_timings(d_.ctx2, &m2, &f2, 0));
-        msmMs_ = m1 + m2; fftMs_ = f1 + f2;      // device time per branch; the branches overlap in wall time
+    // device time per branch since the witness was loaded; each branch's figures are touched only by the host thread that
+    // drives that branch (a sharded rank runs its chains from a second thread, see include/prover.h)
+    void collectTimings(int which) {
+        if (which & 1) ugCheck(ug_ctx_timings(d_.ctx, &m1_, &f1_, 0));
+        if (which & 2) ugCheck(ug_ctx_timings(d_.ctx2, &m2_, &f2_, 0));
+    }
+    void resetTimings() {
+        ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1)); ugCheck(ug_ctx_timings(d_.ctx2, nullptr, nullptr, 1));
+        m1_ = f1_ = m2_ = f2_ = 0;
     }
     void hpolyChain(int which, void* deviceOut) override {
         if (!witnessLoaded_ || !witnessComplete_) throw std::invalid_argument("the whole witness has not been loaded");
@@ -570,7 +577,7 @@ public:
         int rc = ug_hpoly_chain(d_.hp, d_.w, which, v);
         ug_dvec_destroy(v);
         ugCheck(rc);
-        collectTimings();
+        collectTimings(2);
     }
     void hpolyCombine(void* da, void* db, void* dc) override {
         uint64_t cnt = hr_.hi - hr_.lo;
@@ -581,7 +588,7 @@ public:
         int rc = ug_hpoly_combine(d_.hp, a, b, c, hr_.lo, cnt, d_.h);
         ug_dvec_destroy(a); ug_dvec_destroy(b); ug_dvec_destroy(c);
         ugCheck(rc);
-        collectTimings();
+        collectTimings(2);
     }
     void hRange(unsigned long long* first, unsigned long long* count, unsigned long long* domain) const override {
         if (first) *first = hr_.lo;
@@ -589,41 +596,46 @@ public:
         if (domain) *domain = hdr_.domainSize;
     }
 
-    // S1-S10 on this rank's slices with the H-polynomial block computed locally (replicated when sharded).
-    // With ULTRAGROTH_OVERLAP=1 two host threads drive two streams: S1-S4 on one, S5-S10 (H polynomial, its schedule,
-    // the H MSM) on the other, so the memory-bound kernels of one branch overlap the integer-bound kernels of the other
-    // (measured: 148 -> 144 ms per 2^24 proof, 49.9 -> 46.7 ms at 2^22). Off by default: overlapped kernels stretch each other, which blurs the
-    // per-kernel durations and the MSM | FFT split that bench.py and rocprof report.
+    // S1-S10 on this rank's slices with the H-polynomial block computed locally (replicated when sharded): everything is
+    // queued on the two streams -- S1-S4 on one, S5-S10 (H polynomial, its schedule, the H MSM) on the other -- and the host
+    // waits ONCE, at the end, before it finishes the five results. By default the second stream is ordered behind the first
+    // on the device (ug_ctx_wait), so kernels run one after the other and their durations are clean; ULTRAGROTH_OVERLAP=1
+    // drops that edge: the memory-bound kernels of one branch then overlap the integer-bound kernels of the other
+    // (measured in round 1: 148 -> 144 ms per 2^24 proof, 49.9 -> 46.7 ms at 2^22) at the price of blurred per-kernel times.
     void run(uint8_t* partials) override {
         if (!witnessLoaded_ || !witnessComplete_) throw std::invalid_argument("no witness loaded");
         if (!haveHpoly_) throw std::invalid_argument("this rank was created without the coefficient matrix");
-        ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1));
-        ugCheck(ug_ctx_timings(d_.ctx2, nullptr, nullptr, 1));
-        uint8_t hpart[UG_GROTH16_PARTIALS_SIZE];
-        const char* ov = getenv("ULTRAGROTH_OVERLAP");
-        const bool overlap = ov && atoi(ov) != 0;
-        if (!overlap) {
+        const uint64_t nw = wr_.hi - wr_.lo, nh = hr_.hi - hr_.lo;
+        if (nw > maxRange_ || nh > maxRange_) {                 // proved in pieces: partial sums are added between them
+            uint8_t hpart[UG_GROTH16_PARTIALS_SIZE];
             runWitnessMsm(partials, /*standalone*/ false);
             ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                          // S5-S9 :66-148
             runHMsmImpl(hpart, false);                                                         // S10   :154
             memcpy(partials + 320, hpart + 320, 64);
-            collectTimings();
+            collectTimings(3);
             return;
         }
-        std::exception_ptr hErr;
-        std::thread hBranch([&] {
-            try {
-                ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                      // S5-S9 :66-148
-                runHMsmImpl(hpart, false);                                                     // S10   :154
-            } catch (...) { hErr = std::current_exception(); }
-        });
-        std::exception_ptr wErr;
-        try { runWitnessMsm(partials, /*standalone*/ false); } catch (...) { wErr = std::current_exception(); }
-        hBranch.join();
-        if (wErr) std::rethrow_exception(wErr);
-        if (hErr) std::rethrow_exception(hErr);
-        memcpy(partials + 320, hpart + 320, 64);
-        collectTimings();
+        const char* ov = getenv("ULTRAGROTH_OVERLAP");
+        const bool overlap = ov && atoi(ov) != 0;
+        memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
+        buildSchedule(d_.sw, d_.w, wr_.lo, nw, tableW_);
+        {   // S1-S4 (src/groth16.cpp:55,58,61,64): A, B1, B2, C over the witness schedule, queued back to back
+            const ug_bases* sets[4] = {d_.A, d_.B1, d_.B2, d_.C};
+            const int64_t shifts[4] = {0, 0, 0, (int64_t)hdr_.nPublic + 1};
+            void* outs[4] = {partials, partials + 64, partials + 128, partials + 256};
+            ugCheck(ug_msm_batch_enqueue(d_.ctx, 4, sets, d_.sw, shifts, outs));
+        }
+        if (!overlap) ugCheck(ug_ctx_wait(d_.ctx2, d_.ctx));
+        ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                              // S5-S9 :66-148
+        buildSchedule(d_.sh, d_.h, hr_.lo, nh, tableH_);
+        {
+            const ug_bases* sets[1] = {d_.H};
+            void* outs[1] = {partials + 320};
+            ugCheck(ug_msm_batch_enqueue(d_.ctx2, 1, sets, d_.sh, nullptr, outs));             // S10 :154
+        }
+        ugCheck(ug_ctx_collect(d_.ctx2));                       // the one host wait of the device part ...
+        ugCheck(ug_ctx_collect(d_.ctx));                        // (... this one returns at once unless the streams overlap)
+        collectTimings(3);
     }
     int kernelStats(int which, double* avgMs, unsigned long long* launches, unsigned long long* entries, int reset) override {
         double a1 = 0, a2 = 0;
@@ -667,8 +679,8 @@ public:
     unsigned long long proofBufferMinSize() const override { return PROOF_MIN_GROTH16; }
     unsigned long long publicBufferMinSize() const override { return publicMin(hdr_.nPublic); }
     void timings(double* msm, double* fft, double* total) const override {
-        if (msm) *msm = msmMs_;
-        if (fft) *fft = fftMs_;
+        if (msm) *msm = m1_ + m2_;
+        if (fft) *fft = f1_ + f2_;
         if (total) *total = totalMs_;
     }
     ug_ctx* ctx() override { return d_.ctx; }
@@ -684,7 +696,7 @@ private:
     uint64_t cLo_ = 0, cHi_ = 0;       // this rank's slice of the C section
     DeviceProver d_;
     bool witnessLoaded_ = false, witnessComplete_ = false, haveHpoly_ = true;
-    double msmMs_ = 0, fftMs_ = 0, totalMs_ = 0;
+    double m1_ = 0, f1_ = 0, m2_ = 0, f2_ = 0, totalMs_ = 0;      // device ms of the MSM / FFT parts per stream
 };
 
 // =================================================================================================================
@@ -924,12 +936,35 @@ public:
         drawBlinding(r); drawBlinding(s);
         auto terms = std::async(std::launch::async, [&] { return hostTerms(r, s); });
         // (a std::async future joins in its destructor, and r, s are declared before it: they outlive the threads)
-        uint8_t sums[UG_GROTH16_PARTIALS_SIZE], hpart[UG_GROTH16_PARTIALS_SIZE];
-        runWitnessMsm(sums);
-        ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                           // FFT block :243-320
-        mark("H polynomial");
-        runHMsm(hpart);
-        memcpy(sums + 320, hpart + 320, 64);
+        uint8_t sums[UG_GROTH16_PARTIALS_SIZE];
+        if (trace_) {                                    // phase by phase, with a host wait (and a line on stderr) after each
+            uint8_t hpart[UG_GROTH16_PARTIALS_SIZE];
+            runWitnessMsm(sums);
+            ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                       // FFT block :243-320
+            mark("H polynomial");
+            runHMsm(hpart);
+            memcpy(sums + 320, hpart + 320, 64);
+        } else {
+            // the whole final round queued on the stream, ONE host wait: MSM1-3 (:201,214,227), the gather of the final
+            // witnesses (:439-445) and MSM4 (:234), the FFT block (:243-320), MSM5 (:322)
+            memset(sums, 0, sizeof sums);
+            buildSchedule(d_.sw, d_.w, wr_.lo, wr_.hi - wr_.lo, tableW_);
+            const ug_bases* sets[3] = {d_.A, d_.B1, d_.B2};
+            void* outs[3] = {sums, sums + 64, sums + 128};
+            ugCheck(ug_msm_batch_enqueue(d_.ctx, 3, sets, d_.sw, nullptr, outs));
+            ugCheck(ug_dvec_gather_index(d_.aux, d_.w, d_.finalIdx));
+            buildSchedule(d_.saux, d_.aux, 0, finalIdx_.size(), tableC2_);
+            const ug_bases* setC[1] = {d_.C};
+            void* outC[1] = {sums + 256};
+            ugCheck(ug_msm_batch_enqueue(d_.ctx, 1, setC, d_.saux, nullptr, outC));
+            ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));
+            buildSchedule(d_.sh, d_.h, hr_.lo, hr_.hi - hr_.lo, tableH_);
+            const ug_bases* setH[1] = {d_.H};
+            void* outH[1] = {sums + 320};
+            ugCheck(ug_msm_batch_enqueue(d_.ctx, 1, setH, d_.sh, nullptr, outH));
+            ugCheck(ug_ctx_collect(d_.ctx));
+            ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
+        }
         finishWith(sums, r, s, terms.get(), proof, pub);
         totalMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }

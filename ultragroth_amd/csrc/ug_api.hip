@@ -97,8 +97,15 @@ struct ug_ctx {
     hipStream_t stream = nullptr;
     MsmWorkspace ws_g1, ws_g2;
     MsmStats stats[3];                     // [0] G1, [1] G2 bucket-accumulation launches, [2] NTT pass launches
-    hipEvent_t t0 = nullptr, t1 = nullptr;
     double msm_ms = 0, fft_ms = 0;
+    // stream-time accounting without host waits: every timed span is an event pair that is resolved (elapsed time added
+    // to its accumulator) the next time the stream is known to be idle -- ug_ctx_collect, ug_ctx_timings, ug_ctx_sync
+    struct Span { hipEvent_t e0, e1; double* acc; };
+    std::vector<Span> spans_free, spans_pending;
+    // MSMs queued by ug_msm_batch_enqueue whose results are still on their way (pinned_results slot k <-> pending_msm[k])
+    struct QueuedMsm { MsmPending pend; void* out; bool g2; };
+    std::vector<QueuedMsm> pending_msm;
+    hipEvent_t order_event = nullptr;      // ug_ctx_wait
     NttPlan raw_ntt;                       // cache for ug_fr_ntt
     u32* lookup_last = nullptr; u64 lookup_last_n = 0;   // zeroed scratch of ug_dvec_apply_lookup
     u32* pinned_results = nullptr;         // MsmStats::SLOTS result blocks of queued MSMs (ug_msm_batch)
@@ -132,17 +139,38 @@ void host_to_device(ug_ctx* c, void* dst, const void* src, size_t bytes, const S
     if (after) after(0, bytes, c->stream);
     UG_HIP(hipStreamSynchronize(c->stream));
 }
-struct ScopedTimer {       // accumulates stream time between construction and stop()
-    ug_ctx* c; double* acc;
-    ScopedTimer(ug_ctx* c_, double* acc_) : c(c_), acc(acc_) { UG_HIP(hipEventRecord(c->t0, c->stream)); }
+struct ScopedTimer {       // stream time between construction and stop() goes to *acc -- later: see ug_ctx::Span
+    ug_ctx* c; ug_ctx::Span span;
+    ScopedTimer(ug_ctx* c_, double* acc_) : c(c_) {
+        if (c->spans_free.empty()) {
+            ug_ctx::Span sp{nullptr, nullptr, nullptr};
+            UG_HIP(hipEventCreate(&sp.e0)); UG_HIP(hipEventCreate(&sp.e1));
+            c->spans_free.push_back(sp);
+        }
+        span = c->spans_free.back(); c->spans_free.pop_back();
+        span.acc = acc_;
+        UG_HIP(hipEventRecord(span.e0, c->stream));
+    }
     void stop() {
-        UG_HIP(hipEventRecord(c->t1, c->stream));
-        UG_HIP(hipEventSynchronize(c->t1));
-        float ms = 0;
-        UG_HIP(hipEventElapsedTime(&ms, c->t0, c->t1));
-        *acc += ms;
+        UG_HIP(hipEventRecord(span.e1, c->stream));
+        c->spans_pending.push_back(span);
     }
 };
+// after the stream has been synchronised: account the finished spans and the kernel statistics
+void resolve_spans(ug_ctx* c) {
+    for (auto& sp : c->spans_pending) {
+        float ms = 0;
+        UG_HIP(hipEventElapsedTime(&ms, sp.e0, sp.e1));
+        *sp.acc += ms;
+        c->spans_free.push_back(sp);
+    }
+    c->spans_pending.clear();
+    for (int k = 0; k < 3; k++) c->stats[k].collect();
+}
+void sync_and_resolve(ug_ctx* c) {
+    UG_HIP(hipStreamSynchronize(c->stream));
+    resolve_spans(c);
+}
 template <class F> void store_mont256(uint8_t* out, const F& v);
 template <> void store_mont256<Fq>(uint8_t* out, const Fq& v) { u32 w[8]; to_mont256(w, v); memcpy(out, w, 32); }
 }  // namespace
@@ -167,7 +195,7 @@ int ug_ctx_create(ug_ctx** out, int device) {
     c->device = device;
     c->use();
     UG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    UG_HIP(hipEventCreate(&c->t0)); UG_HIP(hipEventCreate(&c->t1));
+    UG_HIP(hipEventCreateWithFlags(&c->order_event, hipEventDisableTiming));
     for (int k = 0; k < 3; k++) c->stats[k].create();
     UG_HIP(hipHostMalloc((void**)&c->pinned_results, (size_t)MsmStats::MAX_BATCH * MSM_PENDING_WORDS * 4, hipHostMallocDefault));
     *out = c;
@@ -179,7 +207,9 @@ void ug_ctx_destroy(ug_ctx* c) {
     hipStreamSynchronize(c->stream);
     c->ws_g1.release(); c->ws_g2.release(); c->raw_ntt.release(); c->uploader.release();
     if (c->lookup_last) hipFree(c->lookup_last);
-    hipEventDestroy(c->t0); hipEventDestroy(c->t1);
+    for (auto& sp : c->spans_free) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
+    for (auto& sp : c->spans_pending) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
+    if (c->order_event) hipEventDestroy(c->order_event);
     for (int k = 0; k < 3; k++) c->stats[k].destroy();
     if (c->pinned_results) hipHostFree(c->pinned_results);
     hipStreamDestroy(c->stream);
@@ -187,8 +217,20 @@ void ug_ctx_destroy(ug_ctx* c) {
 }
 int ug_ctx_sync(ug_ctx* c) {
     UG_TRY
+    if (!c) throw std::invalid_argument("null argument");
     c->use();
-    UG_HIP(hipStreamSynchronize(c->stream));
+    sync_and_resolve(c);
+    UG_CATCH
+}
+// everything queued on `waiter` after this call starts only when everything queued on `signal` before it has finished
+// (device-side ordering, no host wait)
+int ug_ctx_wait(ug_ctx* waiter, ug_ctx* signal) {
+    UG_TRY
+    if (!waiter || !signal) throw std::invalid_argument("null argument");
+    if (waiter->device != signal->device) throw std::invalid_argument("contexts on different devices");
+    waiter->use();
+    UG_HIP(hipEventRecord(signal->order_event, signal->stream));
+    UG_HIP(hipStreamWaitEvent(waiter->stream, signal->order_event, 0));
     UG_CATCH
 }
 
@@ -369,8 +411,7 @@ int ug_dvec_gather_index(ug_dvec* out, const ug_dvec* src, const ug_index* index
     if (index->n > out->n) throw std::invalid_argument("gather larger than the output vector");
     ug_ctx* c = out->ctx;
     c->use();
-    gather_elements(out->data, src->data, index->data, index->n, src->n, c->stream);
-    UG_HIP(hipStreamSynchronize(c->stream));
+    gather_elements(out->data, src->data, index->data, index->n, src->n, c->stream);      // queued; the stream orders its users
     UG_CATCH
 }
 int ug_dvec_scatter(ug_dvec* dst, const uint32_t* host_index, const void* host_values, uint64_t n) {
@@ -527,8 +568,10 @@ int ug_msm_g1(ug_ctx* c, const ug_bases* b, const ug_schedule* s, int64_t index_
     c->use();
     ScopedTimer tm(c, &c->msm_ms);
     int64_t delta = (int64_t)s->first - index_shift - (int64_t)b->global_first;
-    G1XYZZ r = msm_g1(s->sched, c->ws_g1, b->pts, b->n, delta, c->stream, &c->stats[0]);
+    if (!c->pending_msm.empty()) throw std::logic_error("collect the queued MSMs first (ug_ctx_collect)");
+    G1XYZZ r = msm_g1(s->sched, c->ws_g1, b->pts, b->n, delta, c->stream, &c->stats[0]);      // synchronises the stream
     tm.stop();
+    sync_and_resolve(c);
     affine_out_g1((uint8_t*)out, r);
     UG_CATCH
 }
@@ -540,8 +583,10 @@ int ug_msm_g2(ug_ctx* c, const ug_bases* b, const ug_schedule* s, int64_t index_
     c->use();
     ScopedTimer tm(c, &c->msm_ms);
     int64_t delta = (int64_t)s->first - index_shift - (int64_t)b->global_first;
-    G2XYZZ r = msm_g2(s->sched, c->ws_g2, b->pts, b->n, delta, c->stream, &c->stats[1]);
+    if (!c->pending_msm.empty()) throw std::logic_error("collect the queued MSMs first (ug_ctx_collect)");
+    G2XYZZ r = msm_g2(s->sched, c->ws_g2, b->pts, b->n, delta, c->stream, &c->stats[1]);      // synchronises the stream
     tm.stop();
+    sync_and_resolve(c);
     affine_out_g2((uint8_t*)out, r);
     UG_CATCH
 }
@@ -549,32 +594,54 @@ int ug_msm_g2(ug_ctx* c, const ug_bases* b, const ug_schedule* s, int64_t index_
 // Several MSMs over one schedule, queued back to back on the stream with ONE host synchronisation at the end: the
 // latency-bound tail of one product (bucket reduction, tree sums, result copy) no longer leaves the device idle while the
 // host converts the previous result (A, B1, B2, C of src/groth16.cpp:55-64 share the witness schedule).
-int ug_msm_batch(ug_ctx* c, int count, const ug_bases* const* bases, const ug_schedule* s, const int64_t* index_shifts,
-                 void* const* outs) {
+int ug_msm_batch_enqueue(ug_ctx* c, int count, const ug_bases* const* bases, const ug_schedule* s, const int64_t* index_shifts,
+                         void* const* outs) {
     UG_TRY
     if (!c || !s || (count && (!bases || !outs))) throw std::invalid_argument("null argument");
-    if (count < 0 || count > MsmStats::MAX_BATCH) throw std::invalid_argument("at most 8 products per batch");
+    if (count < 0 || c->pending_msm.size() + (size_t)count > (size_t)MsmStats::MAX_BATCH)
+        throw std::invalid_argument("at most 8 products may be queued before ug_ctx_collect");
     for (int k = 0; k < count; k++) {
         if (!bases[k] || !outs[k]) throw std::invalid_argument("null argument");
         check_tables(bases[k], s);
     }
     c->use();
     ScopedTimer tm(c, &c->msm_ms);
-    MsmPending pend[MsmStats::MAX_BATCH];
     for (int k = 0; k < count; k++) {
         const ug_bases* b = bases[k];
         int64_t delta = (int64_t)s->first - (index_shifts ? index_shifts[k] : 0) - (int64_t)b->global_first;
-        u32* host = c->pinned_results + (size_t)k * MSM_PENDING_WORDS;
-        pend[k] = b->g2 ? msm_enqueue_g2(s->sched, c->ws_g2, b->pts, b->n, delta, c->stream, &c->stats[1], host)
-                        : msm_enqueue_g1(s->sched, c->ws_g1, b->pts, b->n, delta, c->stream, &c->stats[0], host);
+        u32* host = c->pinned_results + c->pending_msm.size() * MSM_PENDING_WORDS;
+        ug_ctx::QueuedMsm q;
+        q.g2 = b->g2; q.out = outs[k];
+        q.pend = b->g2 ? msm_enqueue_g2(s->sched, c->ws_g2, b->pts, b->n, delta, c->stream, &c->stats[1], host)
+                       : msm_enqueue_g1(s->sched, c->ws_g1, b->pts, b->n, delta, c->stream, &c->stats[0], host);
+        c->pending_msm.push_back(q);
     }
-    tm.stop();                                       // synchronises the stream
-    c->stats[0].collect(); c->stats[1].collect();
-    for (int k = 0; k < count; k++) {
-        if (bases[k]->g2) affine_out_g2((uint8_t*)outs[k], msm_collect_g2(pend[k]));
-        else affine_out_g1((uint8_t*)outs[k], msm_collect_g1(pend[k]));
+    tm.stop();
+    UG_CATCH
+}
+// ONE host wait for everything queued on the context; then the queued MSM results are finished on the host
+// (Horner over the window sums, affine conversion) and written to their `out` records
+int ug_ctx_collect(ug_ctx* c) {
+    UG_TRY
+    if (!c) throw std::invalid_argument("null argument");
+    c->use();
+    sync_and_resolve(c);
+    std::vector<ug_ctx::QueuedMsm> done;
+    done.swap(c->pending_msm);
+    for (auto& q : done) {
+        if (q.g2) affine_out_g2((uint8_t*)q.out, msm_collect_g2(q.pend));
+        else affine_out_g1((uint8_t*)q.out, msm_collect_g1(q.pend));
     }
     UG_CATCH
+}
+// Several MSMs over one schedule, queued back to back on the stream with ONE host synchronisation at the end: the
+// latency-bound tail of one product (bucket reduction, tree sums, result copy) no longer leaves the device idle while the
+// host converts the previous result (A, B1, B2, C of src/groth16.cpp:55-64 share the witness schedule).
+int ug_msm_batch(ug_ctx* c, int count, const ug_bases* const* bases, const ug_schedule* s, const int64_t* index_shifts,
+                 void* const* outs) {
+    int rc = ug_msm_batch_enqueue(c, count, bases, s, index_shifts, outs);
+    if (rc != UG_OK) { if (c) c->pending_msm.clear(); return rc; }
+    return ug_ctx_collect(c);
 }
 
 int ug_hpoly_create(ug_ctx* c, const void* host_coefs, uint64_t n_coefs, uint32_t domain, uint32_t n_vars, ug_hpoly** out) {
@@ -635,7 +702,6 @@ int ug_hpoly_run(ug_hpoly* hp, const ug_dvec* w, ug_dvec* h_out) {
     NttFusion cfwd; cfwd.work = hp->c; cfwd.fin_a = hp->a; cfwd.fin_b = hp->b;
     hp->ntt.transform(h_out->data, hp->t2, /*inverse*/ false, false, false, nullptr, nullptr, st, &c->stats[2], &cfwd);
     tm.stop();
-    c->stats[2].collect();
     UG_CATCH
 }
 
@@ -669,7 +735,7 @@ int ug_hpoly_chain(ug_hpoly* hp, const ug_dvec* w, int which, ug_dvec* out) {
     }
     hp->ntt.transform(out->data, hp->t, /*inverse*/ false, false, false, nullptr, nullptr, st, &c->stats[2]);
     tm.stop();
-    c->stats[2].collect();
+    sync_and_resolve(c);                         // the caller hands the buffer to other libraries (RCCL): complete on return
     UG_CATCH
 }
 // h[first .. first + count) = plain(a o b - c) from the matching slices of the three coset evaluation vectors
@@ -775,6 +841,8 @@ int ug_synth_points(ug_ctx* c, int g2, const void* generator_record, uint64_t se
 int ug_ctx_timings(ug_ctx* c, double* msm_ms, double* fft_ms, int reset) {
     UG_TRY
     if (!c) throw std::invalid_argument("null argument");
+    c->use();
+    sync_and_resolve(c);
     if (msm_ms) *msm_ms = c->msm_ms;
     if (fft_ms) *fft_ms = c->fft_ms;
     if (reset) { c->msm_ms = 0; c->fft_ms = 0; }
@@ -784,6 +852,8 @@ int ug_ctx_kernel_stats(ug_ctx* c, int which, double* avg_ms, uint64_t* launches
     UG_TRY
     if (!c) throw std::invalid_argument("null argument");
     if (which < 0 || which > 2) throw std::invalid_argument("kernel stats: 0 = G1 accumulation, 1 = G2 accumulation, 2 = NTT pass");
+    c->use();
+    sync_and_resolve(c);
     MsmStats& st = c->stats[which];
     if (avg_ms) *avg_ms = st.launches ? st.accumulate_ms / (double)st.launches : 0.0;
     if (launches) *launches = st.launches;
