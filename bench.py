@@ -381,13 +381,15 @@ def main():
         bufs = torch.empty((3, sl, 32), dtype=torch.uint8, device=ev_dev)
 
     def scatter_slices(out, src_full, src):
+        """returns a work handle (nccl: the three scatters, from three different roots, are in flight together) or None"""
         if backend == "nccl":
-            dist.scatter(out, [src_full[r * sl:(r + 1) * sl] for r in range(world)] if rank == src else None, src=src)
-        else:                                   # gloo rehearsal: through host memory
-            o = torch.empty(out.shape, dtype=torch.uint8)
-            lst = [src_full[r * sl:(r + 1) * sl].cpu() for r in range(world)] if rank == src else None
-            dist.scatter(o, lst, src=src)
-            out.copy_(o)
+            return dist.scatter(out, [src_full[r * sl:(r + 1) * sl] for r in range(world)] if rank == src else None, src=src,
+                                async_op=True)
+        o = torch.empty(out.shape, dtype=torch.uint8)               # gloo rehearsal: through host memory
+        lst = [src_full[r * sl:(r + 1) * sl].cpu() for r in range(world)] if rank == src else None
+        dist.scatter(o, lst, src=src)
+        out.copy_(o)
+        return None
 
     my_chains = [k for k in range(3) if k % world == rank] if split_h else []
 
@@ -410,8 +412,10 @@ def main():
             part = prover.run_witness_msm()
             if th is not None:
                 th.join()
-            for k in range(3):
-                scatter_slices(bufs[k], fulls.get(k), k % world)
+            works = [scatter_slices(bufs[k], fulls.get(k), k % world) for k in range(3)]
+            for wk in works:
+                if wk is not None:
+                    wk.wait()
             torch.cuda.synchronize()
             prover.hpoly_combine(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr())
             part = part[:320] + prover.run_h_msm()[320:384]

@@ -239,6 +239,13 @@ def test_hpoly_matches_oracle_and_known_answers(device, zkey, wtns):
     a, b, c = hp.debug_abc()
     n = info["domainSize"] * 32
     assert a == abc[:n] and b == abc[n:2 * n] and c == abc[2 * n:]
+    # the block is queued without a host wait: a caller that never asks for timings may queue it many times over
+    # (the event pairs behind the kernel statistics are recycled as launches finish), and results stay right
+    wv = device.dvec(info["nVars"], w)
+    outs = [hp.run(wv) for _ in range(40)]
+    assert device.download(outs[-1], 0, info["domainSize"]) == h_exp and device.download(outs[0], 0, info["domainSize"]) == h_exp
+    ms, launches, points = device.kernel_stats(which=2)
+    assert launches > 0 and points == launches * info["domainSize"]
 
 
 @pytest.mark.parametrize("domain", [1, 2, 64])

@@ -104,7 +104,8 @@ struct MsmStats {                 // HIP-event timing of one kernel's launches (
     void create();
     void destroy();
     void collect();                                 // after the stream has been synchronised
-    int begin(hipStream_t stream, u64 units);       // records the start event; returns the slot
+    void collect_ready();                           // the launches that have finished, without waiting
+    int begin(hipStream_t stream, u64 units);       // records the start event; returns the slot (-1: none free, untimed)
     void end(int slot, hipStream_t stream);
 };
 typedef MsmStats KernelStats;

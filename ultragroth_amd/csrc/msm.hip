@@ -876,14 +876,30 @@ XYZZ<typename Cfg::F> msm_run(const MsmSchedule& s, MsmWorkspace& ws, const u32*
 
 void MsmStats::create() { for (int i = 0; i < SLOTS; i++) { UG_HIP(hipEventCreate(&ev0[i])); UG_HIP(hipEventCreate(&ev1[i])); } }
 void MsmStats::destroy() { for (int i = 0; i < SLOTS; i++) { if (ev0[i]) hipEventDestroy(ev0[i]); if (ev1[i]) hipEventDestroy(ev1[i]); ev0[i] = ev1[i] = nullptr; } }
+// launches whose end event has already fired are accounted and their slots freed (no host wait)
+void MsmStats::collect_ready() {
+    int keep = 0;
+    for (int i = 0; i < pending; i++) {
+        if (hipEventQuery(ev1[i]) == hipSuccess) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev0[i], ev1[i]) == hipSuccess) { accumulate_ms += ms; launches++; entries += slot_entries[i]; }
+        } else {
+            if (keep != i) { std::swap(ev0[keep], ev0[i]); std::swap(ev1[keep], ev1[i]); slot_entries[keep] = slot_entries[i]; }
+            keep++;
+        }
+    }
+    (void)hipGetLastError();                       // hipEventQuery reports hipErrorNotReady through the error state
+    pending = keep;
+}
 int MsmStats::begin(hipStream_t stream, u64 units) {
-    if (pending == SLOTS) throw std::logic_error("kernel stats: too many launches in flight");
+    if (pending == SLOTS) collect_ready();
+    if (pending == SLOTS) return -1;               // a caller that never waits: this launch goes untimed
     int slot = pending++;
     slot_entries[slot] = units;
     UG_HIP(hipEventRecord(ev0[slot], stream));
     return slot;
 }
-void MsmStats::end(int slot, hipStream_t stream) { UG_HIP(hipEventRecord(ev1[slot], stream)); }
+void MsmStats::end(int slot, hipStream_t stream) { if (slot >= 0) UG_HIP(hipEventRecord(ev1[slot], stream)); }
 void MsmStats::collect() {
     for (int i = 0; i < pending; i++) {
         float ms = 0;
