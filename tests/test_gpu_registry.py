@@ -109,6 +109,43 @@ def test_registry_interleaved_proofs_and_eviction(device, circuits, zkey, wtns, 
             reg.load("small", circuits["small"][0])
 
 
+def test_registry_from_several_threads_under_pressure(device, circuits):
+    """callers on several threads (ctypes drops the GIL inside the calls) prove different circuits while the budget keeps
+    the registry giving memory back: a circuit that is proving is never trimmed or evicted under it, proofs stay exact"""
+    import threading
+    import ultragroth_amd as ug
+    with ug.Registry(0) as reg:
+        for name in circuits:
+            reg.load(name, circuits[name][0])
+        for name in circuits:
+            _prove_fixed(reg.prove, name, circuits[name][1])
+        total = reg.info()[0]
+    r, s = fixed_rs()
+    ug.set_test_blinding(r + s)                   # an even number of 31-byte draws per proof: every proof sees (r, s)
+    try:
+        with ug.Registry(0, int(total * 0.5)) as reg:
+            for name in circuits:
+                reg.load(name, circuits[name][0])
+            errors = []
+
+            def worker(name):
+                try:
+                    for _ in range(4):
+                        if reg.prove(name, circuits[name][1]) != circuits[name][2]:
+                            errors.append("wrong proof for " + name)
+                except Exception as e:              # noqa: BLE001
+                    errors.append("%s: %r" % (name, e))
+            threads = [threading.Thread(target=worker, args=(n,)) for n in circuits for _ in range(2)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            assert not errors, errors
+            assert reg.info()[2] == 4 * len(threads)
+    finally:
+        ug.set_test_blinding(b"")
+
+
 def test_registry_holds_ultragroth_and_groth16_together(device):
     import ultragroth_amd as ug
     td = os.path.join(GOLDEN, "trapdoor")

@@ -1051,6 +1051,10 @@ public:
     void load(const std::string& name, const void* zkey, uint64_t size, const std::string& path) {
         std::lock_guard<std::mutex> lock(mutex_);
         if (name.empty()) throw std::invalid_argument("empty circuit name");
+        {
+            auto it = entries_.find(name);
+            if (it != entries_.end() && it->second->busy) throw std::invalid_argument("circuit is proving, it cannot be replaced now: " + name);
+        }
         entries_.erase(name);
         // the header tells the protocol (1 = groth16, 1337 = ultragroth, src/zkey_utils.cpp:48-50,129-131)
         BinFile f(zkey, size, "zkey", 1);
@@ -1102,22 +1106,30 @@ public:
             checkBufferSizes(e->prover->proofBufferMinSize(), proofSize, e->prover->publicBufferMinSize(), publicSize, "Minimum");
             // room for the proof's workspaces (known after the circuit's first proof; a guess from its size before)
             makeRoom(e->workBytes ? 0 : e->coreBytes / 2, e);
+            e->busy++;                                                     // from here on nobody may take it away
         }
+        std::exception_ptr failure;
         {
             std::lock_guard<std::mutex> device(deviceMutex_);              // one proof on the device at a time, as fullprover's `busy`
             std::lock_guard<std::mutex> turn(e->prover->proveMutex);
-            const uint64_t before = used();
-            e->prover->prove(wtns, wtnsSize, proof, pub);
-            const uint64_t after = used();
-            if (after > before) e->workBytes += after - before;
-            e->proofs++;
+            try {
+                const uint64_t before = used();
+                e->prover->prove(wtns, wtnsSize, proof, pub);
+                const uint64_t after = used();
+                if (after > before) e->workBytes += after - before;
+                e->proofs++;
+            } catch (...) { failure = std::current_exception(); }
         }
         std::lock_guard<std::mutex> lock(mutex_);
+        e->busy--;
+        if (failure) std::rethrow_exception(failure);
         makeRoom(0, e);
         growTables();
     }
     void evict(const std::string& name) {
         std::lock_guard<std::mutex> lock(mutex_);
+        auto it = entries_.find(name);
+        if (it != entries_.end() && it->second->busy) throw std::invalid_argument("circuit is proving, it cannot be evicted now: " + name);
         if (!entries_.erase(name) && !evictedPaths_.erase(name)) throw std::invalid_argument("circuit not loaded: " + name);
     }
     // name empty: totals. state: 0 not loaded, 1 resident without tables, 2 resident with tables, 3 evicted (reloadable)
@@ -1149,6 +1161,7 @@ private:
         std::unique_ptr<ProverBase> prover;
         uint64_t coreBytes = 0, workBytes = 0, lastUsed = 0, proofs = 0;
         uint64_t tablesDroppedAt = 0;      // tick at which its tables were taken away (it gets them back only after it was used again)
+        int busy = 0;                      // proofs in flight on it: a busy circuit is never trimmed, evicted or replaced
     };
     uint64_t used() {
         uint64_t freeB = 0, total = 0;
@@ -1159,7 +1172,7 @@ private:
         Entry* best = nullptr;
         for (auto& kv : entries_) {
             Entry* e = kv.second.get();
-            if (e == keep || !has(*e)) continue;
+            if (e == keep || e->busy || !has(*e)) continue;
             if (!best || e->lastUsed < best->lastUsed) best = e;
         }
         return best;
@@ -1186,7 +1199,7 @@ private:
     // tables for the most recently used circuits that lack them, while they fit the budget (with room for a proof's workspaces)
     void growTables() {
         std::vector<Entry*> order;
-        for (auto& kv : entries_) if (!kv.second->prover->tableBytes) order.push_back(kv.second.get());
+        for (auto& kv : entries_) if (!kv.second->prover->tableBytes && !kv.second->busy) order.push_back(kv.second.get());
         std::sort(order.begin(), order.end(), [](Entry* a, Entry* b) { return a->lastUsed > b->lastUsed; });
         for (Entry* e : order) {
             if (e->tablesDroppedAt && e->lastUsed < e->tablesDroppedAt) continue;      // no thrashing: not before its next use
