@@ -252,6 +252,19 @@ static unsigned bitrev(unsigned x, int bits) {
     return r;
 }
 
+/* t[i] = w^i for i < count (Montgomery form): blocks of 2^12 entries, each started with one exponentiation, in parallel */
+static void power_table(fe *t, const fe *w, size_t count) {
+    const size_t B = (size_t)1 << 12;
+    size_t nblocks = (count + B - 1) / B;
+#pragma omp parallel for schedule(static) if (count >= 2 * B)
+    for (size_t blk = 0; blk < nblocks; blk++) {
+        size_t i0 = blk * B, i1 = i0 + B < count ? i0 + B : count;
+        u64 e[4] = {(u64)i0, 0, 0, 0};
+        if (i0 == 0) fe_set_one(&t[0], &UGO_FR); else fe_pow(&t[i0], w, e, &UGO_FR);
+        for (size_t i = i0 + 1; i < i1; i++) r_mul(&t[i], &t[i - 1], w);
+    }
+}
+
 /* In-place radix-2 transform, natural order in and out.
  * inverse = 0:  X[k] = sum_j x[j] w^(jk),  w = omega_n
  * inverse = 1:  x[j] = n^-1 sum_k X[k] w^(-jk)      (reference: fft->fft / fft->ifft,
@@ -264,9 +277,9 @@ void ugo_fr_ntt(uint64_t *data, int logn, int inverse) {
     /* twiddles w^0 .. w^(n/2-1) */
     size_t half = n / 2 ? n / 2 : 1;
     fe *tw = (fe *)malloc(half * sizeof(fe));
-    fe_set_one(&tw[0], &UGO_FR);
-    for (size_t i = 1; i < half; i++) r_mul(&tw[i], &tw[i - 1], &w);
-    for (size_t i = 0; i < n; i++) {
+    power_table(tw, &w, half);
+#pragma omp parallel for schedule(static) if (n >= 4096)
+    for (size_t i = 0; i < n; i++) {            /* each pair is swapped by the thread that owns its smaller index */
         size_t j = bitrev((unsigned)i, logn);
         if (i < j) { fe t = x[i]; x[i] = x[j]; x[j] = t; }
     }
@@ -307,23 +320,39 @@ int ugo_hpoly(uint64_t *h_out, const uint8_t *coefs, uint64_t ncoefs, const uint
     size_t n = domain_size;
     int logn = 0; while (((size_t)1 << logn) < n) logn++;
     fe *a = (fe *)calloc(n, sizeof(fe)), *b = (fe *)calloc(n, sizeof(fe)), *c = (fe *)malloc(n * sizeof(fe));
-    /* S6: serial scatter-add (the reference takes striped locks; the sum is order-independent) */
+    /* S6: scatter-add under striped locks, as the reference does it (src/groth16.cpp:70-99: NLOCKS = 1024 mutexes,
+     * lock[c % NLOCKS]); the sum is order-independent */
+    int bad = 0;
+#ifdef _OPENMP
+    enum { NLOCKS = 1024 };
+    static omp_lock_t locks[NLOCKS];
+    static int locks_ready = 0;
+#pragma omp critical(ugo_locks_init)
+    if (!locks_ready) { for (int i = 0; i < NLOCKS; i++) omp_init_lock(&locks[i]); locks_ready = 1; }
+#endif
+#pragma omp parallel for schedule(static) reduction(|:bad) if (ncoefs >= 4096)
     for (uint64_t i = 0; i < ncoefs; i++) {
         coef_rec rec; memcpy(&rec, coefs + i * 44, 44);
-        if (rec.c >= n || rec.s >= nvars) { free(a); free(b); free(c); return 1; }
+        if (rec.c >= n || rec.s >= nvars) { bad |= 1; continue; }
         fe w, aux; memcpy(&w, wtns + (size_t)rec.s * 32, 32);
         r_mul(&aux, &w, &rec.coef);
         fe *ab = rec.m == 0 ? a : b;
+#ifdef _OPENMP
+        omp_set_lock(&locks[rec.c % NLOCKS]);
+#endif
         r_add(&ab[rec.c], &ab[rec.c], &aux);
+#ifdef _OPENMP
+        omp_unset_lock(&locks[rec.c % NLOCKS]);
+#endif
     }
+    if (bad) { free(a); free(b); free(c); return 1; }
     /* S7 */
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; i++) r_mul(&c[i], &a[i], &b[i]);
     /* S8: ifft, twist by omega_{2n}^i, fft */
     fe w2n; ugo_fr_root_of_unity(w2n.v, logn + 1);
     fe *tw = (fe *)malloc(n * sizeof(fe));
-    fe_set_one(&tw[0], &UGO_FR);
-    for (size_t i = 1; i < n; i++) r_mul(&tw[i], &tw[i - 1], &w2n);
+    power_table(tw, &w2n, n);
     fe *polys[3] = {a, b, c};
     for (int p = 0; p < 3; p++) {
         fe *x = polys[p];

@@ -91,7 +91,8 @@ def coefficients(domain, nvars, seed, out=None):
     k = 4 * domain
     rec = np.zeros(k, dtype=COEF_DTYPE) if out is None else np.frombuffer(out, dtype=COEF_DTYPE)
     assert len(rec) == k
-    for ci, r0 in enumerate(range(0, domain, COEF_CHUNK_ROWS)):
+    def chunk(ci):
+        r0 = ci * COEF_CHUNK_ROWS
         r1 = min(domain, r0 + COEF_CHUNK_ROWS)
         n = 4 * (r1 - r0)
         rng = np.random.Generator(np.random.PCG64([seed, ci]))
@@ -103,6 +104,15 @@ def coefficients(domain, nvars, seed, out=None):
         val[:, 3] &= np.uint64((1 << 60) - 1)
         part["v"] = val
         rec[4 * r0:4 * r1] = part[rng.permutation(n)]
+    n_chunks = (domain + COEF_CHUNK_ROWS - 1) // COEF_CHUNK_ROWS
+    if n_chunks <= 2:
+        for ci in range(n_chunks):
+            chunk(ci)
+    else:                                          # chunks are independent (own PRNG stream, own slice): numpy drops the GIL
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=max(1, min(8, len(os.sched_getaffinity(0))))) as pool:
+            list(pool.map(chunk, range(n_chunks)))
     return rec
 
 
