@@ -66,12 +66,13 @@ struct MsmSchedule {
     const u32* tvals = nullptr;
     u32* bucket_start = nullptr;  // per bucket: first entry
     u32* bucket_count = nullptr;  // per bucket: number of entries
+    u32* small_list = nullptr;    // buckets cut into 2 .. 32 segment pieces (meta[4] of them), any order
     int log_seg = 0;              // entries per lane of the segmented accumulation = 2^log_seg
     u32* heavy_list = nullptr;    // device: HeavyBucket[heavy_cap]
     u32 heavy_cap = 0;
     u32* medium_list = nullptr;   // device: HeavyBucket[heavy_cap] for buckets of FIX_MAX < pieces <= MEDIUM_MAX
     u32* heavy_offsets = nullptr; // device: first task of each heavy bucket (n_heavy + 1 entries)
-    u32* meta = nullptr;          // device: [n_heavy, n_valid, n_heavy_tasks, n_medium] -- read by the kernels, never by the host
+    u32* meta = nullptr;          // device: [n_heavy, n_valid, n_heavy_tasks, n_medium, n_small, ...] -- read by the kernels, never by the host
     // workspace
     u32 *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;

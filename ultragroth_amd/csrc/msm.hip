@@ -195,7 +195,7 @@ __global__ void bucket_bounds_kernel(const u32* keys, u64 total, u32 sentinel, u
 }
 // buckets whose entries span more than FIX_MAX lanes of the segmented accumulation are listed as heavy
 __global__ void bucket_counts_kernel(u32* start, u32* count, u32 nb, int log_seg, u32* meta, u32* heavy_list, u32* medium_list,
-                                     u32 heavy_cap) {
+                                     u32 heavy_cap, u32* small_list) {
     u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     u32 e = count[b];
@@ -204,6 +204,7 @@ __global__ void bucket_counts_kernel(u32* start, u32* count, u32 nb, int log_seg
     if (!c) return;
     u32 first = start[b] >> log_seg, last = (start[b] + c - 1) >> log_seg;
     u32 pieces = last - first + 1;
+    if (pieces >= 2 && pieces <= FIX_MAX) small_list[atomicAdd(&meta[4], 1u)] = b;      // at most one entry per bucket: nb slots
     if (pieces > MEDIUM_MAX) {
         u32 pos = atomicAdd(&meta[0], 1u);
         if (pos < heavy_cap) { heavy_list[4 * pos] = b; heavy_list[4 * pos + 1] = first; heavy_list[4 * pos + 2] = last; heavy_list[4 * pos + 3] = 0; }
@@ -330,28 +331,21 @@ __device__ __forceinline__ XYZZ<typename Cfg::F> load_piece(const u32* slot_pts,
     return Cfg::from_words(slot_pts + slot * Cfg::PT_WORDS, 1);
 }
 
-// One lane per segment boundary: the bucket that crosses the boundary after segment t is summed by the lane of
-// the segment in which it starts, so the active lanes are dense (a lane-per-bucket sweep leaves 3/4 of a wave idle
-// when most buckets lie inside one segment). Buckets with more than FIX_MAX pieces go to the wave / workgroup paths.
+// Buckets cut into 2 .. FIX_MAX pieces (listed by bucket_counts_kernel; the order of the list is arbitrary, the sums are
+// not): one lane per listed bucket, so the lanes of a wave are all busy. (A lane per segment boundary left three quarters
+// of the lanes idle when a bucket is cut several times -- the short segments of many-GPU shards: 2.4 ms of a 22 ms
+// witness phase in kernels that run one wave per SIMD.) Buckets with more pieces go to the wave / workgroup paths.
 template <class Cfg>
-__global__ __launch_bounds__(128) void bucket_fixup_kernel(const u32* __restrict__ keys, const u32* __restrict__ start,
-                                                           const u32* __restrict__ count, const u32* __restrict__ meta, int log_seg,
+__global__ __launch_bounds__(128) void bucket_fixup_kernel(const u32* __restrict__ small_list, const u32* __restrict__ meta,
+                                                           const u32* __restrict__ start, const u32* __restrict__ count, int log_seg,
                                                            const u32* __restrict__ slot_pts, u32* __restrict__ bucket_pts) {
-    const u32 n_valid = meta[1];
-    const u32 nseg = (u32)(((u64)n_valid + ((u64)1 << log_seg) - 1) >> log_seg);
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t + 1 >= nseg) return;
+    if (t >= meta[4]) return;
     typedef typename Cfg::F F;
-    u64 idx = ((u64)t + 1) << log_seg;             // first entry of segment t + 1
-    if (idx >= n_valid) return;
-    u32 b = keys[idx];
-    if (keys[idx - 1] != b) return;                // no bucket crosses this boundary
-    u32 st = start[b];
-    u32 first = st >> log_seg;
-    if (first != t) return;                        // the bucket started in an earlier segment: that lane sums it
-    u32 last = (st + count[b] - 1) >> log_seg;
-    u32 pieces = last - first + 1;
-    if (pieces > FIX_MAX) return;
+    const u32 b = small_list[t];
+    const u32 st = start[b];
+    const u32 first = st >> log_seg, last = (st + count[b] - 1) >> log_seg;
+    const u32 pieces = last - first + 1;
     XYZZ<F> acc = load_piece<Cfg>(slot_pts, first, 0);
     for (u32 k = 1; k < pieces; k++) acc = xyzz_add(acc, load_piece<Cfg>(slot_pts, first, k));
     Cfg::to_words(bucket_pts + (size_t)b * Cfg::PT_WORDS, acc, 1);
@@ -694,6 +688,7 @@ void MsmSchedule::reserve(const MsmGeometry& g) {
     if (g.total_buckets() > capacity_buckets) {
         dev_alloc(bucket_start, g.total_buckets() * 4);
         dev_alloc(bucket_count, g.total_buckets() * 4);
+        dev_alloc(small_list, g.total_buckets() * 4);
         capacity_buckets = g.total_buckets();
     }
     u64 hcap = (total >> 5) / (FIX_MAX - 1) + 2;         // a listed bucket covers at least FIX_MAX - 1 whole segments (>= 2^5 entries each)
@@ -701,7 +696,7 @@ void MsmSchedule::reserve(const MsmGeometry& g) {
         dev_alloc(heavy_list, 4 * hcap * 4); dev_alloc(medium_list, 4 * hcap * 4); dev_alloc(heavy_offsets, (hcap + 1) * 4);
         heavy_cap = (u32)hcap;
     }
-    if (!meta) dev_alloc(meta, 16);
+    if (!meta) dev_alloc(meta, 32);
 }
 
 void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_t stream) {
@@ -726,12 +721,12 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
     vals = dv.Current();
     UG_HIP(hipMemsetAsync(bucket_start, 0, (size_t)nb * 4, stream));
     UG_HIP(hipMemsetAsync(bucket_count, 0, (size_t)nb * 4, stream));
-    UG_HIP(hipMemsetAsync(meta, 0, 16, stream));
+    UG_HIP(hipMemsetAsync(meta, 0, 32, stream));
     hipLaunchKernelGGL(bucket_bounds_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                        keys, total, sentinel, bucket_start, bucket_count, meta);
     UG_KERNEL_CHECK();
     hipLaunchKernelGGL(bucket_counts_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, bucket_start, bucket_count, nb,
-                       log_seg, meta, heavy_list, medium_list, heavy_cap);
+                       log_seg, meta, heavy_list, medium_list, heavy_cap, small_list);
     UG_KERNEL_CHECK();
     hipLaunchKernelGGL(heavy_plan_kernel, dim3(1), dim3(1024), 0, stream, (const HeavyBucket*)heavy_list, heavy_cap, meta, heavy_offsets);
     UG_KERNEL_CHECK();
@@ -753,7 +748,7 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
 
 void MsmSchedule::release() {
     dev_free(keys_a); dev_free(keys_b); dev_free(vals_a); dev_free(vals_b); dev_free(sort_tmp);
-    dev_free(bucket_start); dev_free(bucket_count); dev_free(heavy_list); dev_free(medium_list); dev_free(heavy_offsets); dev_free(meta);
+    dev_free(bucket_start); dev_free(bucket_count); dev_free(small_list); dev_free(heavy_list); dev_free(medium_list); dev_free(heavy_offsets); dev_free(meta);
     capacity_n = capacity_buckets = 0; sort_tmp_bytes = 0; vals = nullptr; keys = nullptr; heavy_cap = 0;
 }
 
@@ -804,8 +799,9 @@ MsmPending msm_enqueue(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases,
     }
     if (stats) stats->end(slot, stream);
     if (nseg > 1) {
-        hipLaunchKernelGGL(bucket_fixup_kernel<Cfg>, dim3((unsigned)((nseg + 127) / 128)), dim3(128), 0, stream,
-                           s.keys, s.bucket_start, s.bucket_count, s.meta, s.log_seg, ws.slot_pts, ws.bucket_pts);
+        const u64 small_max = std::min<u64>(g.total_buckets(), nseg);       // a listed bucket crosses a segment boundary of its own
+        hipLaunchKernelGGL(bucket_fixup_kernel<Cfg>, dim3((unsigned)((small_max + 127) / 128)), dim3(128), 0, stream,
+                           s.small_list, s.meta, s.bucket_start, s.bucket_count, s.log_seg, ws.slot_pts, ws.bucket_pts);
         UG_KERNEL_CHECK();
         if (nseg > FIX_MAX) {
             hipLaunchKernelGGL(medium_bucket_kernel<Cfg>, dim3((medium_max + 3) / 4), dim3(256), 0, stream,
