@@ -69,6 +69,12 @@ int  ug_ctx_sync(ug_ctx* ctx);
  * sharded prover can hold a slice. */
 int  ug_bases_create_g1(ug_ctx* ctx, const void* host_points, uint64_t n, uint64_t global_first, ug_bases** out);
 int  ug_bases_create_g2(ug_ctx* ctx, const void* host_points, uint64_t n, uint64_t global_first, ug_bases** out);
+/* The same WITH the fixed-base window tables described below (table_c = their window width, 0 = none): the tables are
+ * allocated with the set, the points are uploaded straight into table 0 and the table kernel is queued on the context
+ * without a host wait, so the upload of the caller's next section overlaps it (zkey ingest). Work queued
+ * on the context afterwards is ordered behind the build; ug_ctx_sync waits for it. */
+int  ug_bases_create_tables_g1(ug_ctx* ctx, const void* host_points, uint64_t n, uint64_t global_first, int table_c, ug_bases** out);
+int  ug_bases_create_tables_g2(ug_ctx* ctx, const void* host_points, uint64_t n, uint64_t global_first, int table_c, ug_bases** out);
 /* Fixed-base window tables (no reference counterpart: the zkey's points never change between proofs, and 288 GB of
  * HBM holds them): extend the set by tables 2^(c j) * P_i, j = 1 .. ceil(255/c) - 1, c in [16, 24]. A schedule built
  * with ug_schedule_build_tables(.., c) then puts every window digit into ONE bucket set. Fails (nothing changed)

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_CSRC, "libultragroth_hip.so")
 # every symbol that include/ultragroth_hip.h and include/prover.h declare
 INNER_SYMBOLS = [
     "ug_last_error", "ug_device_count", "ug_ctx_create", "ug_ctx_destroy", "ug_ctx_sync",
-    "ug_bases_create_g1", "ug_bases_create_g2", "ug_bases_destroy",
+    "ug_bases_create_g1", "ug_bases_create_g2", "ug_bases_create_tables_g1", "ug_bases_create_tables_g2", "ug_bases_destroy",
     "ug_msm_table_window", "ug_bases_tables_bytes", "ug_bases_precompute", "ug_ctx_mem_info", "ug_schedule_build_tables",
     "ug_dvec_create", "ug_dvec_upload", "ug_dvec_upload_range", "ug_dvec_download", "ug_dvec_gather", "ug_dvec_scatter", "ug_dvec_apply_lookup", "ug_fr_lookup_table", "ug_index_create", "ug_index_destroy", "ug_dvec_gather_index", "ug_dvec_wrap", "ug_dvec_size", "ug_dvec_destroy",
     "ug_schedule_create", "ug_schedule_build", "ug_schedule_destroy",

@@ -275,6 +275,24 @@ uint64_t planWindowTables(ug_ctx* ctx, std::vector<TableGroup>& groups, uint64_t
     }
     return taken;
 }
+// The same decision taken BEFORE the base sets exist (only their sizes are known): widths[k] = the table width of group k,
+// or 0. `otherBytes` = what the caller is still going to allocate besides the tables (the points themselves, matrix,
+// vectors). With the widths known, every set is created together with its tables (ug_bases_create_tables_*), whose build
+// overlaps the upload of the next section.
+std::vector<int> planTableWidthsAhead(ug_ctx* ctx, const std::vector<TableGroup>& groups, uint64_t otherBytes) {
+    std::vector<int> none(groups.size(), 0);
+    const char* e = getenv("ULTRAGROTH_TABLES");
+    if (e && e[0] == '0') return none;
+    if (g_registryCreate || (g_oneShotProver && !(e && e[0] == '2'))) return none;
+    std::vector<int> width;
+    uint64_t workspace = 0;
+    const uint64_t need = tablesNeed(groups, width, &workspace);
+    if (!need) return none;
+    uint64_t freeB = 0, totalB = 0;
+    ugCheck(ug_ctx_mem_info(ctx, &freeB, &totalB));
+    if (need + workspace + otherBytes > freeB) return none;
+    return width;
+}
 void buildSchedule(ug_schedule* s, const ug_dvec* scalars, uint64_t first, uint64_t count, int tableC) {
     if (tableC) ugCheck(ug_schedule_build_tables(s, scalars, first, count, tableC));
     else ugCheck(ug_schedule_build(s, scalars, first, count));
@@ -438,26 +456,48 @@ private:
         }
 
         ugCheck(ug_ctx_create(&d_.ctx, device));
-        ugCheck(ug_bases_create_g1(d_.ctx, pA, wr_.hi - wr_.lo, wr_.lo, &d_.A));
-        ugCheck(ug_bases_create_g1(d_.ctx, pB1, wr_.hi - wr_.lo, wr_.lo, &d_.B1));
-        ugCheck(ug_bases_create_g2(d_.ctx, pB2, wr_.hi - wr_.lo, wr_.lo, &d_.B2));
-        ugCheck(ug_bases_create_g1(d_.ctx, pC, cHi - cLo, cLo, &d_.C));
-        // the H branch (coefficient mat-vec, NTT chains, h schedule, H MSM) gets its own stream so that its
-        // memory-bound kernels (sort, transpose, gathers) overlap the integer-bound witness accumulations
+        // the H branch (coefficient mat-vec, NTT chains, h schedule, H MSM) gets its own stream
         ugCheck(ug_ctx_create(&d_.ctx2, device));
-        ugCheck(ug_bases_create_g1(d_.ctx2, pH, hr_.hi - hr_.lo, hr_.lo, &d_.H));
-        if (haveHpoly_) ugCheck(ug_hpoly_create(d_.ctx2, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
-        ugCheck(ug_dvec_create(d_.ctx, M, &d_.w));
-        ugCheck(ug_dvec_create(d_.ctx2, N, &d_.h));
-        ugCheck(ug_schedule_create(d_.ctx, &d_.sw));
-        ugCheck(ug_schedule_create(d_.ctx2, &d_.sh));
         if (const char* mr = getenv("ULTRAGROTH_MAX_RANGE")) {
             uint64_t v = strtoull(mr, nullptr, 10);
             if (v >= 1 && v < MAX_RANGE) maxRange_ = v;
         }
         cLo_ = cLo; cHi_ = cHi;
-        std::vector<TableGroup> groups = tableGroups();
-        tableBytes = planWindowTables(d_.ctx, groups);
+        // Window tables are decided ahead, from the sizes alone, so that every set is created WITH its tables: the table
+        // kernel of one section runs while the next section is uploaded (zkey ingest: the 0.25 s of copies disappear
+        // behind the 2.4 s of table building at 2^24).
+        const uint64_t nw = wr_.hi - wr_.lo, nh = hr_.hi - hr_.lo;
+        const uint64_t otherBytes = nw * (64 * 2 + 128) + (cHi - cLo) * 64 + nh * 64 + (haveHpoly_ ? hdr_.nCoefs * 80 + N * 32 * 5 + N * 100 : 0) +
+                                    M * 32 + N * 32;
+        std::vector<int> ahead = planTableWidthsAhead(d_.ctx, tableGroups(), otherBytes);
+        bool withTables = true;
+        auto create = [&](ug_ctx* ctx, bool g2, const uint8_t* pts, uint64_t n, uint64_t first, int width, ug_bases** out) {
+            if (width && withTables) {
+                int rc = g2 ? ug_bases_create_tables_g2(ctx, pts, n, first, width, out) : ug_bases_create_tables_g1(ctx, pts, n, first, width, out);
+                if (rc == UG_OK) return;
+                withTables = false;                 // memory ran short after all: this set and the rest without tables
+            }
+            ugCheck(g2 ? ug_bases_create_g2(ctx, pts, n, first, out) : ug_bases_create_g1(ctx, pts, n, first, out));
+        };
+        create(d_.ctx, false, pA, nw, wr_.lo, ahead[0], &d_.A);
+        create(d_.ctx, false, pB1, nw, wr_.lo, ahead[0], &d_.B1);
+        create(d_.ctx, true, pB2, nw, wr_.lo, ahead[0], &d_.B2);
+        create(d_.ctx, false, pC, cHi - cLo, cLo, ahead[0], &d_.C);
+        const bool group0 = withTables && ahead[0];
+        create(d_.ctx2, false, pH, nh, hr_.lo, ahead[1], &d_.H);
+        const bool group1 = withTables && ahead[1];
+        if (ahead[0] && !group0) { ug_bases_drop_tables(d_.A); ug_bases_drop_tables(d_.B1); ug_bases_drop_tables(d_.B2); ug_bases_drop_tables(d_.C); }
+        tableW_ = group0 ? ahead[0] : 0;
+        tableH_ = group1 ? ahead[1] : 0;
+        if (group0) tableBytes += ug_bases_tables_bytes(nw, 0, tableW_) * 2 + ug_bases_tables_bytes(nw, 1, tableW_) + ug_bases_tables_bytes(cHi - cLo, 0, tableW_);
+        if (group1) tableBytes += ug_bases_tables_bytes(nh, 0, tableH_);
+        if (haveHpoly_) ugCheck(ug_hpoly_create(d_.ctx2, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
+        ugCheck(ug_dvec_create(d_.ctx, M, &d_.w));
+        ugCheck(ug_dvec_create(d_.ctx2, N, &d_.h));
+        ugCheck(ug_schedule_create(d_.ctx, &d_.sw));
+        ugCheck(ug_schedule_create(d_.ctx2, &d_.sh));
+        ugCheck(ug_ctx_sync(d_.ctx));                // the table builds queued above end here: create returns a finished prover
+        ugCheck(ug_ctx_sync(d_.ctx2));
     }
 
 public:

@@ -131,8 +131,13 @@ struct ug_hpoly {
 
 namespace {
 // blocking copy of a caller buffer into device memory; `after` as in StagedUploader::upload (called once for a small copy)
-void host_to_device(ug_ctx* c, void* dst, const void* src, size_t bytes, const StagedUploader::After& after = StagedUploader::After()) {
+// fresh: dst was allocated just now, nothing queued on the device refers to it -- the copy then neither waits for the
+// context's stream nor uses it (a window-table build of the previous section may be running there: the upload of the next
+// section overlaps it)
+void host_to_device(ug_ctx* c, void* dst, const void* src, size_t bytes, const StagedUploader::After& after = StagedUploader::After(),
+                    bool fresh = false) {
     if (!bytes) return;
+    if (fresh) { c->uploader.upload(c->device, dst, src, bytes, after); return; }
     UG_HIP(hipStreamSynchronize(c->stream));                   // nothing queued earlier may still read or write dst
     if (bytes >= StagedUploader::MIN_BYTES) { c->uploader.upload(c->device, dst, src, bytes, after); return; }
     UG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
@@ -244,29 +249,45 @@ int ug_ctx_wait(ug_ctx* waiter, ug_ctx* signal) {
     UG_CATCH
 }
 
-static int bases_create(ug_ctx* c, const void* host, u64 n, u64 global_first, bool g2, ug_bases** out) {
+// table_c != 0: the set is created WITH its fixed-base window tables -- room for all of them is allocated at once, the points
+// go straight into table 0, and the table kernel is queued on the context's stream without a host wait, so that the upload
+// of the caller's next section (staged through the uploader's own streams) runs beside it. Everything queued on the
+// context later is ordered behind the tables; ug_ctx_sync ends the build.
+static int bases_create(ug_ctx* c, const void* host, u64 n, u64 global_first, bool g2, int table_c, ug_bases** out) {
     UG_TRY
     if (!c || !out || (!host && n)) throw std::invalid_argument("null argument");
     c->use();
+    int windows = 1;
+    if (table_c) {
+        windows = MsmGeometry::choose_tables(n, table_c).windows;      // validates the width
+        if (n > ((u64)1 << TABLE_INDEX_BITS)) throw std::invalid_argument("window tables need at most 2^27 points per set");
+    }
     ug_bases* b = new ug_bases{c, g2, n, global_first, nullptr, 0};
-    size_t bytes = (size_t)n * (g2 ? 128 : 64);
-    UG_HIP(hipMalloc(&b->pts, bytes ? bytes : 4));
+    const size_t rec = g2 ? 128 : 64, bytes = (size_t)n * rec;
+    if (hipMalloc(&b->pts, bytes ? bytes * (size_t)windows : 4) != hipSuccess) {
+        (void)hipGetLastError();
+        delete b;
+        throw std::runtime_error(table_c ? "not enough device memory for the window tables" : "not enough device memory for the base points");
+    }
     if (n) {
         // each chunk's records are converted to the device form behind its own DMA (chunks are whole records: 8 MiB / 128)
-        const size_t rec = g2 ? 128 : 64;
         u32* pts = b->pts;
         try {
             host_to_device(c, pts, host, bytes, [pts, rec, g2](size_t off, size_t len, hipStream_t st) {
                 u32* p = pts + off / 4;
                 if (g2) convert_points_g2(p, len / rec, st); else convert_points_g1(p, len / rec, st);
-            });
+            }, /*fresh*/ true);
+            if (table_c) build_window_tables(g2, pts, n, table_c, windows, c->stream);
         } catch (...) { hipFree(b->pts); delete b; throw; }
     }
+    b->table_c = table_c;
     *out = b;
     UG_CATCH
 }
-int ug_bases_create_g1(ug_ctx* c, const void* host, uint64_t n, uint64_t gf, ug_bases** out) { return bases_create(c, host, n, gf, false, out); }
-int ug_bases_create_g2(ug_ctx* c, const void* host, uint64_t n, uint64_t gf, ug_bases** out) { return bases_create(c, host, n, gf, true, out); }
+int ug_bases_create_g1(ug_ctx* c, const void* host, uint64_t n, uint64_t gf, ug_bases** out) { return bases_create(c, host, n, gf, false, 0, out); }
+int ug_bases_create_g2(ug_ctx* c, const void* host, uint64_t n, uint64_t gf, ug_bases** out) { return bases_create(c, host, n, gf, true, 0, out); }
+int ug_bases_create_tables_g1(ug_ctx* c, const void* host, uint64_t n, uint64_t gf, int table_c, ug_bases** out) { return bases_create(c, host, n, gf, false, table_c, out); }
+int ug_bases_create_tables_g2(ug_ctx* c, const void* host, uint64_t n, uint64_t gf, int table_c, ug_bases** out) { return bases_create(c, host, n, gf, true, table_c, out); }
 int ug_msm_table_window(uint64_t n) { return MsmGeometry::table_window(n); }
 uint64_t ug_bases_tables_bytes(uint64_t n, int g2, int c) {
     if (c < TABLE_MIN_C || c > TABLE_MAX_C) return 0;
