@@ -7,8 +7,12 @@
 A step is one proof of a seeded synthetic circuit (ultragroth_amd/synth.py, shapes of SURVEY.md section 8d) as SURVEY.md
 section 8(d) defines the metric: the wall time of `groth16_prover_prove` on a CREATED prover with the .wtns in HOST
 memory -- parse, host-to-device copy of the witness, the five MSMs and the H-polynomial block on the device, blinding and
-JSON on the host. `value` is therefore PCIe-inclusive for the witness (512 MiB at 2^24); `witness_upload_ms_per_proof`
-and `resident_ms_per_step` (the same step minus the upload) are extra keys. `create` (zkey upload, conversion, window
+JSON on the host. `value` is therefore PCIe-inclusive for the witness (512 MiB at 2^24). At N = 1 the K timed steps are
+issued from two host threads on the ONE prover object (--host-threads): the reference's prover keeps no per-proof state,
+so callers may do that, and here the witness of the next call is copied into a second device buffer while the kernels of
+the current call run -- `value` = K / the wall time of those K whole proofs. `sequential_ms_per_step` (the same K steps
+strictly one after the other: the latency of one proof), `witness_upload_ms_per_proof` and `resident_ms_per_step` (a
+sequential step minus its upload) are extra keys. `create` (zkey upload, conversion, window
 tables) is reported separately as `create_s`. Default workload: configs[2] of BASELINE.json, the 2^24-constraint circuit
 with full G1+G2 MSMs that the 10x target is quoted on.
 
@@ -46,6 +50,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-domain", type=int, default=24)
     ap.add_argument("--mix", default="U", choices=["U", "C"])
+    ap.add_argument("--host-threads", type=int, default=2, help="N=1: host threads that issue the K timed steps on the one prover object "
+                    "(2: the witness copy of a step runs beside the kernels of the step before; 1: strictly one proof after the other)")
     ap.add_argument("--cpu-sample-log", type=int, default=None, help="log2 domain of the CPU-baseline sample circuit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="one more proof with fixed blinding, compared byte for byte with the expected proof "
@@ -438,14 +444,41 @@ def main():
     for which in range(3):
         prover.kernel_stats(which=which, reset=True)
     msm_ms = fft_ms = upload_ms = 0.0
+    host_threads = max(1, args.host_threads) if world == 1 else 1
+    sequential_ms = None
+    if host_threads > 1:
+        # the same K steps strictly one after the other first (an extra figure: the latency of one proof)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        sequential_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+    tally = threading.Lock()
+    todo = iter(range(args.steps))
+
+    def issue_steps():
+        nonlocal out, msm_ms, fft_ms, upload_ms
+        while True:
+            with tally:
+                if next(todo, None) is None:
+                    return
+            o = step()
+            m, f, _ = prover.last_timings()
+            with tally:
+                out = o
+                msm_ms += m
+                fft_ms += f
+                upload_ms += prover.last_upload_ms()
+
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-        m, f, _ = prover.last_timings()
-        msm_ms += m
-        fft_ms += f
-        upload_ms += prover.last_upload_ms()
+    helpers = [threading.Thread(target=issue_steps) for _ in range(host_threads - 1)]
+    for th in helpers:
+        th.start()
+    issue_steps()
+    for th in helpers:
+        th.join()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -496,13 +529,17 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 254-bit modular integers)",
             "data": "synthetic",
             "config": {"workload": "groth16-bn254 2^%d constraints, nVars 2^%d-1, nCoefs 4N, %s + H-poly FFT, scalar mix %s "
-                                   "(BASELINE.json configs[%d] shape); step = groth16_prover_prove on a created prover, .wtns in host memory"
+                                   "(BASELINE.json configs[%d] shape); step = groth16_prover_prove on a created prover, .wtns in host memory%s"
                                    % (log_domain, log_domain, "G1 MSMs A and H only" if args.g1_only else "full G1+G2 MSM", args.mix,
-                                      1 if args.g1_only else 2),
-                       "log_domain": log_domain, "mix": args.mix, "overlap": bool(os.environ.get("ULTRAGROTH_OVERLAP", "0") not in ("", "0")),
+                                      1 if args.g1_only else 2,
+                                      "; the K steps are issued from %d host threads on the one prover object, so the witness copy of a "
+                                      "step runs beside the kernels of the step before" % host_threads if host_threads > 1 else ""),
+                       "log_domain": log_domain, "mix": args.mix, "host_threads": host_threads, "overlap": bool(os.environ.get("ULTRAGROTH_OVERLAP", "0") not in ("", "0")),
                        "parallelism": "one GPU" if world == 1 else "base-range shard x%d%s" % (world, ", H-poly chains split over ranks" if split_h else "")},
             "msm_ms_per_proof": msm_ms / args.steps, "fft_ms_per_proof": fft_ms / args.steps,
-            "witness_upload_ms_per_proof": upload_ms / args.steps, "resident_ms_per_step": ms_per_step - upload_ms / args.steps,
+            "witness_upload_ms_per_proof": upload_ms / args.steps,
+            "sequential_ms_per_step": sequential_ms if sequential_ms is not None else ms_per_step,
+            "resident_ms_per_step": (sequential_ms if sequential_ms is not None else ms_per_step) - upload_ms / args.steps,
             "witness_upload_gbs": (32.0 * info["nVars"] / (upload_ms / args.steps * 1e-3) / 1e9) if upload_ms > 0 else None,
             "create_s": create_s, "zkey_bytes": zkey_bytes, "zkey_ingest_gbs": zkey_bytes / create_s / 1e9,
             "host_peak_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 2),

@@ -26,8 +26,13 @@
  *     reference, which keeps raw pointers into the caller's zkey buffer -- the buffer may be released as
  *     soon as *_create returns (this also removes the reference's dangling-mapping defect in
  *     *_create_zkey_file, src/prover.cpp:449-473);
- *   - one prove at a time per prover object; a prover object is bound to one HIP device
- *     (environment variable ULTRAGROTH_DEVICE, default 0).
+ *   - a prover object may be used from several host threads at once, as the reference's (whose prove
+ *     allocates everything per call, src/prover.cpp:341-391): the calls take turns on the device. A
+ *     Groth16 prover copies the witness of a waiting call into its second witness buffer meanwhile, so
+ *     two threads proving on one object hide the host-to-device copy of one proof behind the kernels of
+ *     the other (2^24: 10 ms of a 155 ms proof). The ug_ phase calls of a sharded proof below are driven
+ *     by one thread per object and must not be mixed with concurrent *_prove calls on the same object;
+ *   - a prover object is bound to one HIP device (environment variable ULTRAGROTH_DEVICE, default 0).
  *
  * Additions (not in the reference), all prefixed ug_: deterministic blinding for tests, per-phase
  * timings, and the sharded entry points a multi-GPU launcher uses (one process per GPU).

@@ -95,6 +95,10 @@ int  ug_dvec_upload(ug_dvec* v, const void* host, uint64_t n);           /* host
 /* the same into elements [first, first + n); `via`: the context whose stream and staging buffers carry the copy (NULL =
  * the vector's own), so that two host threads can fill disjoint ranges of one vector at the same time */
 int  ug_dvec_upload_range(ug_dvec* v, const void* host, uint64_t first, uint64_t n, ug_ctx* via);
+/* the same as ug_dvec_upload for a vector NOTHING queued on the device refers to (the caller vouches for it): the copy
+ * uses the staging streams only and does not wait for the context's stream -- the witness of the NEXT proof is staged this
+ * way from a second host thread while the current proof runs (groth16_prover_prove from two threads on one prover) */
+int  ug_dvec_upload_idle(ug_dvec* v, const void* host, uint64_t n);
 int  ug_dvec_download(const ug_dvec* v, void* host, uint64_t first, uint64_t n);
 /* out[i] = src[index[i]] for i < n (UltraGroth round / final witness gathers, src/ultra_groth.cpp:415-445) */
 int  ug_dvec_gather(ug_dvec* out, const ug_dvec* src, const uint32_t* host_index, uint64_t n);

@@ -670,3 +670,49 @@ def test_overlap_mode_is_bit_exact(device, monkeypatch):
         assert ug.groth16_prover(zkey, wtns) == (exp[0], exp[1])
     finally:
         ug.set_test_blinding(b"")
+
+
+def test_one_prover_object_from_three_host_threads(device):
+    """The reference's prover keeps no per-proof state, so callers may prove from several threads on one object
+    (src/prover.cpp:341-391 allocates everything per call). Here the object owns the device buffers: calls take turns on
+    the device, and the witness of a waiting call is staged into the second witness buffer meanwhile (Groth16Prover::
+    proveTurn). Three threads, three different witnesses, eight proofs each, every one bit-exact -- a witness staged
+    into a buffer a running proof still reads, or public signals taken from the wrong call, would show here. Sized so
+    that the copy takes one staging lane (2^13 constraints) and, second round, all of them (2^20: 32 MiB). The phase
+    calls of a sharded rank (load_witness / run / finish) stage the same way: test_sharded_* above."""
+    import threading
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    r, s = fixed_rs()
+    ri, si = int.from_bytes(r, "little"), int.from_bytes(s, "little")
+    for log_domain, rounds in ((13, 8), (20, 3)):
+        zkey, wtns, info = synth.build_circuit(device, log_domain, mix="U", seed=0x5EED0700 + log_domain)
+        witnesses = [wtns]
+        off = O.section(wtns, "wtns", 2)[0]
+        for k in (1, 2):                                        # other witnesses: the low limbs rotated (values stay below r)
+            body = np.frombuffer(wtns, dtype=np.uint8).copy()
+            vals = body[off:].reshape(-1, 4, 8)
+            vals[1:, :3] = np.roll(vals[1:, :3], k, axis=1)
+            witnesses.append(body.tobytes())
+        expected = [O.groth16_prove(zkey, w, ri, si)[:2] for w in witnesses]
+        assert len({e[0] for e in expected}) == 3
+        failures = []
+        with ug.Groth16Prover(zkey) as p:
+            def caller(k):
+                try:
+                    for it in range(rounds):
+                        got = p.prove(witnesses[k])
+                        if got != expected[k]:
+                            failures.append("2^%d: thread %d proof %d differs" % (log_domain, k, it))
+                except Exception as e:                          # noqa: BLE001 (reported below)
+                    failures.append("2^%d: thread %d: %r" % (log_domain, k, e))
+            ug.set_test_blinding(r + s)
+            try:
+                threads = [threading.Thread(target=caller, args=(k,)) for k in range(3)]
+                for t in threads:
+                    t.start()
+                for t in threads:
+                    t.join()
+            finally:
+                ug.set_test_blinding(b"")
+        assert not failures, failures

@@ -8,7 +8,7 @@ import json
 d=json.load(open("gpurun_out/q24.json"))
 r=d["roofline"]
 k=r["kernels"]
-print("%.1f ms/proof (%.2f proofs/s)  upload %.1f  msm %.1f  fft %.1f | G1 acc %.2f ms  G2 acc %.2f ms  ntt pass %.3f ms" % (d["ms_per_step"], d["value"], d["witness_upload_ms_per_proof"], d["msm_ms_per_proof"], d["fft_ms_per_proof"], r["avg_launch_ms"], k["segment_accumulate_kernel<G2Cfg>"]["avg_launch_ms"], k["ntt_pass_kernel"]["avg_launch_ms"]))
+print("seq %.1f ms | " % d.get("sequential_ms_per_step", 0) + "%.1f ms/proof (%.2f proofs/s)  upload %.1f  msm %.1f  fft %.1f | G1 acc %.2f ms  G2 acc %.2f ms  ntt pass %.3f ms" % (d["ms_per_step"], d["value"], d["witness_upload_ms_per_proof"], d["msm_ms_per_proof"], d["fft_ms_per_proof"], r["avg_launch_ms"], k["segment_accumulate_kernel<G2Cfg>"]["avg_launch_ms"], k["ntt_pass_kernel"]["avg_launch_ms"]))
 PY
 python -c "
 import json; d=json.load(open('gpurun_out/q24.json')); print('create_s %.2f' % d['create_s'])"

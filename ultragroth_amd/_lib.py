@@ -15,7 +15,7 @@ INNER_SYMBOLS = [
     "ug_last_error", "ug_device_count", "ug_ctx_create", "ug_ctx_destroy", "ug_ctx_sync",
     "ug_bases_create_g1", "ug_bases_create_g2", "ug_bases_create_tables_g1", "ug_bases_create_tables_g2", "ug_bases_destroy",
     "ug_msm_table_window", "ug_bases_tables_bytes", "ug_bases_precompute", "ug_ctx_mem_info", "ug_schedule_build_tables",
-    "ug_dvec_create", "ug_dvec_upload", "ug_dvec_upload_range", "ug_dvec_download", "ug_dvec_gather", "ug_dvec_scatter", "ug_dvec_apply_lookup", "ug_fr_lookup_table", "ug_index_create", "ug_index_destroy", "ug_dvec_gather_index", "ug_dvec_wrap", "ug_dvec_size", "ug_dvec_destroy",
+    "ug_dvec_create", "ug_dvec_upload", "ug_dvec_upload_range", "ug_dvec_upload_idle", "ug_dvec_download", "ug_dvec_gather", "ug_dvec_scatter", "ug_dvec_apply_lookup", "ug_fr_lookup_table", "ug_index_create", "ug_index_destroy", "ug_dvec_gather_index", "ug_dvec_wrap", "ug_dvec_size", "ug_dvec_destroy",
     "ug_schedule_create", "ug_schedule_build", "ug_schedule_destroy",
     "ug_msm_g1", "ug_msm_g2", "ug_msm_batch", "ug_msm_batch_enqueue", "ug_ctx_collect", "ug_ctx_wait",
     "ug_hpoly_create", "ug_hpoly_run", "ug_hpoly_chain", "ug_hpoly_combine", "ug_hpoly_debug_abc", "ug_hpoly_destroy",
@@ -83,6 +83,7 @@ def load():
     L.ug_schedule_build_tables.argtypes = [vp, vp, u64, u64, C.c_int]
     L.ug_dvec_create.argtypes = [vp, u64, pp]
     L.ug_dvec_upload.argtypes = [vp, vp, u64]
+    L.ug_dvec_upload_idle.argtypes = [vp, vp, u64]
     L.ug_dvec_download.argtypes = [vp, vp, u64, u64]
     L.ug_dvec_gather.argtypes = [vp, vp, vp, u64]
     L.ug_dvec_scatter.argtypes = [vp, vp, vp, u64]

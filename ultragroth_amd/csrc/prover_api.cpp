@@ -10,13 +10,16 @@
 //                                                 src/prover.cpp:89-117
 //   extern "C" entry points and error mapping     src/prover.cpp:311-891
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
 #include <exception>
+#include <functional>
 #include <future>
 #include <map>
 #include <string>
@@ -196,12 +199,13 @@ struct DeviceProver {
     ug_bases *A = nullptr, *B1 = nullptr, *B2 = nullptr, *C = nullptr, *H = nullptr, *roundC = nullptr;
     ug_hpoly* hp = nullptr;
     ug_dvec *w = nullptr, *h = nullptr, *aux = nullptr;
+    ug_dvec* w2 = nullptr;       // second witness buffer (Groth16): the next proof's witness is staged here while a proof runs
     ug_schedule *sw = nullptr, *sh = nullptr, *saux = nullptr;
     ug_index *roundIdx = nullptr, *finalIdx = nullptr;      // UltraGroth: zkey sections 10 and 11, resident
     ~DeviceProver() {
         ug_index_destroy(roundIdx); ug_index_destroy(finalIdx);
         ug_schedule_destroy(sw); ug_schedule_destroy(sh); ug_schedule_destroy(saux);
-        ug_dvec_destroy(w); ug_dvec_destroy(h); ug_dvec_destroy(aux);
+        ug_dvec_destroy(w); ug_dvec_destroy(w2); ug_dvec_destroy(h); ug_dvec_destroy(aux);
         ug_hpoly_destroy(hp);
         ug_bases_destroy(A); ug_bases_destroy(B1); ug_bases_destroy(B2); ug_bases_destroy(C); ug_bases_destroy(H);
         ug_bases_destroy(roundC);
@@ -302,6 +306,22 @@ struct ProverBase {        // what the extern "C" layer stores behind the opaque
     std::mutex proveMutex;
     virtual ~ProverBase() {}
     virtual void prove(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub) = 0;
+    // One proof for a caller that may share the object with other host threads (the extern "C" prove calls and the
+    // registry come through here): the calls take turns on the device -- `device`, when given, is the lock of everything
+    // on the card (registry), `around(true/false)` brackets the device part. A prover may do the part of a proof that
+    // needs no device turn (parsing the witness, copying it into a buffer no running proof uses) BEFORE it takes its turn:
+    // Groth16Prover does, so that two host threads proving on one object hide the PCIe copy of one proof behind the
+    // kernels of the other.
+    typedef std::function<void(bool)> Around;
+    virtual void proveTurn(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub,
+                           std::mutex* device = nullptr, const Around& around = Around()) {
+        std::unique_lock<std::mutex> card;
+        if (device) card = std::unique_lock<std::mutex>(*device);
+        std::lock_guard<std::mutex> turn(proveMutex);
+        if (around) around(true);
+        prove(wtns, wtnsSize, proof, pub);
+        if (around) around(false);
+    }
     virtual unsigned long long proofBufferMinSize() const = 0;
     virtual unsigned long long publicBufferMinSize() const = 0;
     virtual void timings(double* msm, double* fft, double* total) const = 0;
@@ -520,20 +540,89 @@ public:
 
     const ZkeyHeader& header() const { return hdr_; }
 
-    void loadWitness(const void* wtns, unsigned long long wtnsSize) override {
-        auto t0 = std::chrono::steady_clock::now();
-        BinFile f(wtns, wtnsSize, "wtns", 2);
+    // the whole witness section of a .wtns buffer, checked against the circuit (src/prover.cpp:183-196)
+    const uint8_t* witnessData(const BinFile& f) const {
         WtnsHeader wh = loadWtnsHeader(f);
         if (hdr_.nVars != wh.nVars)
             throw InvalidWitnessLengthException("Invalid witness length. Circuit: " + std::to_string(hdr_.nVars) +
                                                 ", witness: " + std::to_string(wh.nVars));
         if (!wh.primeIsBn254) throw std::invalid_argument("different wtns curve");
-        const uint8_t* data = checkedSection(f, 2, (uint64_t)hdr_.nVars * 32);
-        publicPart_.assign(data, data + ((size_t)hdr_.nPublic + 1) * 32);
+        return checkedSection(f, 2, (uint64_t)hdr_.nVars * 32);
+    }
+    // phase call (the caller drives the phases of one proof from one thread and holds no lock): staged like a proof's
+    void loadWitness(const void* wtns, unsigned long long wtnsSize) override {
+        WitnessLease lease(*this);
+        stage(*lease, wtns, wtnsSize);
+        std::lock_guard<std::mutex> turn(proveMutex);
+        adopt(*lease);
+    }
+
+    // ---- two witness buffers: the next proof's witness is staged while a proof runs ------------------------------------
+    // A buffer is leased from the moment a host thread starts to fill it until the proof that reads it has left the device.
+    // The second buffer (nVars * 32 bytes) is allocated the first time two calls overlap; if that fails the calls simply
+    // take turns on the first.
+    struct WitnessSlot { ug_dvec* buf = nullptr; bool leased = false; std::vector<uint8_t> publicPart; double uploadMs = 0; };
+    struct WitnessLease {
+        Groth16Prover& p; int slot;
+        explicit WitnessLease(Groth16Prover& p_) : p(p_), slot(p_.leaseSlot()) {}
+        ~WitnessLease() {
+            { std::lock_guard<std::mutex> lk(p.slotMutex_); p.slots_[slot].leased = false; }
+            p.slotFree_.notify_all();
+        }
+        WitnessSlot& operator*() { return p.slots_[slot]; }
+    };
+    int leaseSlot() {
+        std::unique_lock<std::mutex> lk(slotMutex_);
+        if (!slots_[0].buf) slots_[0].buf = d_.w;
+        for (;;) {
+            for (int k = 0; k < 2; k++) {
+                WitnessSlot& sl = slots_[k];
+                if (sl.leased) continue;
+                if (!sl.buf) {
+                    if (secondBufferFailed_) continue;
+                    if (ug_dvec_create(d_.ctx, hdr_.nVars, &sl.buf) != UG_OK) { sl.buf = nullptr; secondBufferFailed_ = true; continue; }
+                    d_.w2 = sl.buf;
+                }
+                sl.leased = true;
+                return k;
+            }
+            slotFree_.wait(lk);
+        }
+    }
+    // staging: parse the .wtns and copy the witness into the leased buffer; needs no turn on the device, only the
+    // uploader (one copy at a time)
+    void stage(WitnessSlot& sl, const void* wtns, unsigned long long wtnsSize) {
+        std::lock_guard<std::mutex> st(stageMutex_);
+        auto u0 = std::chrono::steady_clock::now();
+        BinFile f(wtns, wtnsSize, "wtns", 2);
+        const uint8_t* data = witnessData(f);
+        sl.publicPart.assign(data, data + ((size_t)hdr_.nPublic + 1) * 32);
+        ugCheck(ug_dvec_upload_idle(sl.buf, data, hdr_.nVars));
+        sl.uploadMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - u0).count();
+    }
+    // the staged witness becomes the prover's (proveMutex held)
+    void adopt(WitnessSlot& sl) {
+        if (d_.w != sl.buf) std::swap(d_.w, d_.w2);
+        if (d_.w != sl.buf) throw std::logic_error("witness buffers out of step");
+        publicPart_.swap(sl.publicPart);
+        uploadMs = sl.uploadMs;
         resetTimings();
-        ugCheck(ug_dvec_upload(d_.w, data, hdr_.nVars));
         witnessLoaded_ = true; witnessComplete_ = true;
-        uploadMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    // lock order everywhere: witness lease -> stageMutex_ (released again) -> the card's lock -> proveMutex
+    void proveTurn(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub, std::mutex* device,
+                   const Around& around) override {
+        auto t0 = std::chrono::steady_clock::now();
+        WitnessLease lease(*this);
+        stage(*lease, wtns, wtnsSize);
+        std::unique_lock<std::mutex> card;
+        if (device) card = std::unique_lock<std::mutex>(*device);
+        std::lock_guard<std::mutex> turn(proveMutex);
+        if (around) around(true);
+        adopt(*lease);
+        proveLoaded(proof, pub);
+        totalMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (around) around(false);
     }
     // The witness in two parts, for a rank of a sharded prover: part 0 = the scalars of this rank's MSM slice (what
     // runWitnessMsm reads), part 1 = everything else (only the H-polynomial mat-vec reads it; a rank that runs no
@@ -702,9 +791,11 @@ public:
         pub = publicJson(publicPart_.data(), hdr_.nPublic, 0);
     }
 
+    // (every caller comes through proveTurn, which this class overrides; kept for the interface)
     void prove(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub) override {
-        auto t0 = std::chrono::steady_clock::now();
-        loadWitness(wtns, wtnsSize);
+        proveTurn(wtns, wtnsSize, proof, pub, nullptr, Around());
+    }
+    void proveLoaded(std::string& proof, std::string& pub) {
         // S11 (:158-166) drawn up front, in the reference's order: the multiples of delta that need only r and s are
         // formed on host threads while the device runs S1-S10
         uint8_t r[32], s[32];
@@ -713,7 +804,6 @@ public:
         uint8_t partials[UG_GROTH16_PARTIALS_SIZE];
         run(partials);                                   // (the future joins in its destructor if this throws)
         finishWith(partials, r, s, terms.get(), proof, pub);
-        totalMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 
     unsigned long long proofBufferMinSize() const override { return PROOF_MIN_GROTH16; }
@@ -736,6 +826,10 @@ private:
     uint64_t cLo_ = 0, cHi_ = 0;       // this rank's slice of the C section
     DeviceProver d_;
     bool witnessLoaded_ = false, witnessComplete_ = false, haveHpoly_ = true;
+    WitnessSlot slots_[2];
+    std::mutex slotMutex_, stageMutex_;
+    std::condition_variable slotFree_;
+    bool secondBufferFailed_ = false;
     double m1_ = 0, f1_ = 0, m2_ = 0, f2_ = 0, totalMs_ = 0;      // device ms of the MSM / FFT parts per stream
 };
 
@@ -1150,14 +1244,17 @@ public:
         }
         std::exception_ptr failure;
         {
-            std::lock_guard<std::mutex> device(deviceMutex_);              // one proof on the device at a time, as fullprover's `busy`
-            std::lock_guard<std::mutex> turn(e->prover->proveMutex);
+            // one proof on the device at a time (deviceMutex_), as fullprover's `busy`; the witness of a waiting call may be
+            // copied to the device meanwhile (ProverBase::proveTurn)
             try {
-                const uint64_t before = used();
-                e->prover->prove(wtns, wtnsSize, proof, pub);
-                const uint64_t after = used();
-                if (after > before) e->workBytes += after - before;
-                e->proofs++;
+                uint64_t before = 0;
+                e->prover->proveTurn(wtns, wtnsSize, proof, pub, &deviceMutex_, [&](bool begin) {
+                    if (begin) { before = used(); return; }
+                    const uint64_t after = used();
+                    if (after > before) e->workBytes += after - before;
+                    e->proofs++;
+                    proofsTotal_++;
+                });
             } catch (...) { failure = std::current_exception(); }
         }
         std::lock_guard<std::mutex> lock(mutex_);
@@ -1178,7 +1275,7 @@ public:
         if (name.empty()) {
             if (bytes) *bytes = used();
             if (state) *state = (int)entries_.size();
-            if (proofs) { *proofs = 0; for (auto& kv : entries_) *proofs += kv.second->proofs; }
+            if (proofs) *proofs = proofsTotal_;            // (all proofs made here, also those of circuits evicted since)
             return;
         }
         auto it = entries_.find(name);
@@ -1254,6 +1351,7 @@ private:
     uint64_t budget_, baselineFree_ = 0, tick_ = 0;
     ug_ctx* probe_ = nullptr;
     std::mutex mutex_, deviceMutex_;
+    std::atomic<uint64_t> proofsTotal_{0};
     std::map<std::string, std::unique_ptr<Entry>> entries_;
     std::map<std::string, std::string> evictedPaths_;
 };
@@ -1284,9 +1382,9 @@ int proveImpl(void* prover_object, const void* wtns_buffer, unsigned long long w
     std::string stringProof, stringPublic;
     {
         // the reference's prover keeps no per-proof state, so callers may prove from several threads on one object;
-        // here the object owns the device buffers of a proof: concurrent calls take turns
-        std::lock_guard<std::mutex> turn(prover->proveMutex);
-        prover->prove(wtns_buffer, wtns_size, stringProof, stringPublic);
+        // here the object owns the device buffers of a proof: concurrent calls take turns on the device (and the witness
+        // of the next call is copied there while they wait)
+        prover->proveTurn(wtns_buffer, wtns_size, stringProof, stringPublic);
     }
     checkBufferSizes(stringProof.length(), proof_size, stringPublic.length(), public_size, "Required");
     std::strncpy(proof_buffer, stringProof.c_str(), *proof_size);

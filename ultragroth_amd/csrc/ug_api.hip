@@ -5,6 +5,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -39,6 +40,8 @@ struct StagedUploader {
     struct Lane { hipStream_t stream = nullptr; uint8_t* buf[DEPTH] = {nullptr, nullptr}; hipEvent_t done[DEPTH] = {nullptr, nullptr}; };
     Lane lanes[MAX_LANES];
     int n_lanes = 0;
+    std::mutex turn;            // one upload at a time: the lanes' pinned buffers are the uploader's (a witness staged for the
+                                // next proof from a second host thread meets the uploads of the running one here)
     typedef std::function<void(size_t offset, size_t bytes, hipStream_t stream)> After;
     void init() {
         if (n_lanes) return;
@@ -55,6 +58,7 @@ struct StagedUploader {
         }
     }
     void upload(int device, void* dst, const void* src, size_t bytes, const After& after = After()) {
+        std::lock_guard<std::mutex> one(turn);
         init();
         const size_t n_chunks = (bytes + CHUNK - 1) / CHUNK;
         std::exception_ptr errs[MAX_LANES];
@@ -76,7 +80,7 @@ struct StagedUploader {
             } catch (...) { errs[l] = std::current_exception(); }
         };
         std::vector<std::thread> th;
-        for (int l = 1; l < n_lanes; l++) th.emplace_back(work, l);
+        for (int l = 1; l < n_lanes && (size_t)l < n_chunks; l++) th.emplace_back(work, l);
         work(0);
         for (auto& t : th) t.join();
         for (int l = 0; l < n_lanes; l++) if (errs[l]) std::rethrow_exception(errs[l]);
@@ -393,6 +397,16 @@ int ug_dvec_upload_range(ug_dvec* v, const void* host, uint64_t first, uint64_t 
     if (c->device != v->ctx->device) throw std::invalid_argument("upload context on another device");
     c->use();
     host_to_device(c, v->data + first * 8, host, (size_t)n * 32);
+    UG_CATCH
+}
+int ug_dvec_upload_idle(ug_dvec* v, const void* host, uint64_t n) {
+    UG_TRY
+    if (!v || (!host && n)) throw std::invalid_argument("null argument");
+    if (n > v->n) throw std::invalid_argument("upload larger than the vector");
+    v->ctx->use();
+    // the caller vouches that nothing queued on the device reads or writes v: the copy runs on the uploader's own streams and
+    // neither waits for the context's stream nor touches it (a proof may be running there)
+    host_to_device(v->ctx, v->data, host, (size_t)n * 32, StagedUploader::After(), /*fresh*/ true);
     UG_CATCH
 }
 int ug_dvec_download(const ug_dvec* v, void* host, uint64_t first, uint64_t n) {
