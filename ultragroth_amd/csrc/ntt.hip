@@ -6,7 +6,7 @@
 // Conventions (pinned by SURVEY.md Appendix A): omega_{2^s} = 5^((r-1)/2^s); ifft scales by 1/n.
 //
 // Structure: every transform is decimation-in-time -- input in bit-reversed order, output in
-// natural order -- done in passes of up to 11 stages. One workgroup stages a tile through LDS
+// natural order -- done in passes of up to 10 stages. One workgroup stages a tile through LDS
 // as 9 limb planes (conflict-free 4-byte accesses), runs its stages with one butterfly per thread
 // per stage, and writes the tile back. DIT is used for both directions because its butterfly
 // (a + w b, a - w b) adds a freshly reduced product at every stage, so lazily reduced values grow
@@ -23,8 +23,11 @@ namespace ug {
 
 namespace {
 
-constexpr int NTT_MAX_LOG_TILE = 11;      // 2^11 elements * 36 B = 72 KiB of LDS: two workgroups per CU
-constexpr int NTT_THREADS = 512;          // one radix-4 butterfly per lane per step at the full tile
+// 2^10 elements * 36 B = 36 KiB of LDS: four workgroups per CU, each in its own phase (load | butterfly steps | store), keep
+// memory and vector issue busy together: 0.79 ms per pass at 2^24 against 0.84 with 2^11-element tiles (two workgroups per
+// CU) and 1.01 with 2^12 (one); 2^9 measures the same as 2^10. 2^24 = 10 + 7 + 7 stages, still three passes.
+constexpr int NTT_MAX_LOG_TILE = 10;
+constexpr int NTT_THREADS = 256;          // one radix-4 butterfly per lane per step at the full tile
 
 struct PassArgs {
     const u32* in;
@@ -290,12 +293,12 @@ void NttPlan::transform(u32* out, const u32* in, bool inverse, bool gather_bitre
     }
     if (gather_bitrev && scatter_bitrev) throw std::invalid_argument("ntt: gather and scatter together not supported");
     if ((gather_bitrev || scatter_bitrev) && out == in) throw std::invalid_argument("ntt: permuting transform must be out of place");
-    // split the stages: first pass contiguous (up to 11 stages), then strided passes with 2^j adjacent elements per row
+    // split the stages: first pass contiguous (up to NTT_MAX_LOG_TILE stages), then strided passes with 2^j adjacent elements per row
     int stages[8], nj[8], np = 0, rem = logn;
     int first = rem < NTT_MAX_LOG_TILE ? rem : NTT_MAX_LOG_TILE;
     stages[np] = first; nj[np] = 0; np++; rem -= first;
     while (rem > 0) {
-        // strided pass: k <= 8 stages and 2^j adjacent tiles, k + j = 11 (runs of 2^j * 32 bytes)
+        // strided pass: k <= 8 stages and 2^j adjacent tiles, k + j = NTT_MAX_LOG_TILE (runs of 2^j * 32 bytes)
         int npass_left = (rem + 7) / 8;
         int k = (rem + npass_left - 1) / npass_left;
         stages[np] = k; nj[np] = NTT_MAX_LOG_TILE - k; np++; rem -= k;
