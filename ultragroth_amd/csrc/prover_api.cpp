@@ -200,6 +200,7 @@ struct DeviceProver {
     ug_hpoly* hp = nullptr;
     ug_dvec *w = nullptr, *h = nullptr, *aux = nullptr;
     ug_dvec* w2 = nullptr;       // second witness buffer (Groth16): the next proof's witness is staged here while a proof runs
+                                 // (written once, under the prover's slot lock; the device part reads Groth16Prover::wCur_)
     ug_schedule *sw = nullptr, *sh = nullptr, *saux = nullptr;
     ug_index *roundIdx = nullptr, *finalIdx = nullptr;      // UltraGroth: zkey sections 10 and 11, resident
     ~DeviceProver() {
@@ -513,6 +514,8 @@ private:
         if (group1) tableBytes += ug_bases_tables_bytes(nh, 0, tableH_);
         if (haveHpoly_) ugCheck(ug_hpoly_create(d_.ctx2, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
         ugCheck(ug_dvec_create(d_.ctx, M, &d_.w));
+        wCur_ = d_.w;
+        slots_[0].buf = d_.w;
         ugCheck(ug_dvec_create(d_.ctx2, N, &d_.h));
         ugCheck(ug_schedule_create(d_.ctx, &d_.sw));
         ugCheck(ug_schedule_create(d_.ctx2, &d_.sh));
@@ -536,6 +539,15 @@ public:
         std::lock_guard<std::mutex> turn(proveMutex);
         ug_schedule_trim(d_.sw); ug_schedule_trim(d_.sh);
         ug_ctx_trim(d_.ctx); ug_ctx_trim(d_.ctx2);
+        // the witness buffer that is neither the current one nor being filled goes too (it comes back with the next overlap)
+        std::lock_guard<std::mutex> lk(slotMutex_);
+        for (WitnessSlot& sl : slots_) {
+            if (!sl.buf || sl.leased || sl.buf == wCur_) continue;
+            if (d_.w == sl.buf) { d_.w = d_.w2; d_.w2 = nullptr; } else if (d_.w2 == sl.buf) d_.w2 = nullptr;
+            ug_dvec_destroy(sl.buf);
+            sl.buf = nullptr;
+            secondBufferFailed_ = false;
+        }
     }
 
     const ZkeyHeader& header() const { return hdr_; }
@@ -573,7 +585,6 @@ public:
     };
     int leaseSlot() {
         std::unique_lock<std::mutex> lk(slotMutex_);
-        if (!slots_[0].buf) slots_[0].buf = d_.w;
         for (;;) {
             for (int k = 0; k < 2; k++) {
                 WitnessSlot& sl = slots_[k];
@@ -581,7 +592,7 @@ public:
                 if (!sl.buf) {
                     if (secondBufferFailed_) continue;
                     if (ug_dvec_create(d_.ctx, hdr_.nVars, &sl.buf) != UG_OK) { sl.buf = nullptr; secondBufferFailed_ = true; continue; }
-                    d_.w2 = sl.buf;
+                    (d_.w ? d_.w2 : d_.w) = sl.buf;            // (the owner that is free)
                 }
                 sl.leased = true;
                 return k;
@@ -602,8 +613,7 @@ public:
     }
     // the staged witness becomes the prover's (proveMutex held)
     void adopt(WitnessSlot& sl) {
-        if (d_.w != sl.buf) std::swap(d_.w, d_.w2);
-        if (d_.w != sl.buf) throw std::logic_error("witness buffers out of step");
+        wCur_ = sl.buf;
         publicPart_.swap(sl.publicPart);
         uploadMs = sl.uploadMs;
         resetTimings();
@@ -639,13 +649,13 @@ public:
         if (part == 0) {
             resetTimings();
             publicPart_.assign(data, data + ((size_t)hdr_.nPublic + 1) * 32);
-            ugCheck(ug_dvec_upload_range(d_.w, data + wr_.lo * 32, wr_.lo, wr_.hi - wr_.lo, 0));
+            ugCheck(ug_dvec_upload_range(wCur_, data + wr_.lo * 32, wr_.lo, wr_.hi - wr_.lo, 0));
             witnessLoaded_ = true; witnessComplete_ = false;
             uploadMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         } else if (part == 1) {
             // on the H branch's context: its stream orders the copy before the mat-vec, and the MSM stream is left alone
-            if (wr_.lo) ugCheck(ug_dvec_upload_range(d_.w, data, 0, wr_.lo, d_.ctx2));
-            if (wr_.hi < hdr_.nVars) ugCheck(ug_dvec_upload_range(d_.w, data + wr_.hi * 32, wr_.hi, hdr_.nVars - wr_.hi, d_.ctx2));
+            if (wr_.lo) ugCheck(ug_dvec_upload_range(wCur_, data, 0, wr_.lo, d_.ctx2));
+            if (wr_.hi < hdr_.nVars) ugCheck(ug_dvec_upload_range(wCur_, data + wr_.hi * 32, wr_.hi, hdr_.nVars - wr_.hi, d_.ctx2));
             witnessComplete_ = true;
         } else throw std::invalid_argument("witness part must be 0 or 1");
     }
@@ -661,7 +671,7 @@ public:
             uint64_t n = std::min<uint64_t>(maxRange_, wr_.hi - lo);
             uint8_t* out = (lo == wr_.lo) ? partials : part;
             memset(part, 0, sizeof part);
-            buildSchedule(d_.sw, d_.w, lo, n, tableW_);
+            buildSchedule(d_.sw, wCur_, lo, n, tableW_);
             // S1-S4 (src/groth16.cpp:55,58,61,64): A, B1, B2, C over the witness schedule, queued back to back
             const ug_bases* sets[4] = {d_.A, d_.B1, d_.B2, d_.C};
             const int64_t shifts[4] = {0, 0, 0, (int64_t)hdr_.nPublic + 1};
@@ -703,7 +713,7 @@ public:
         if (!haveHpoly_) throw std::invalid_argument("this rank was created without the coefficient matrix");
         ug_dvec* v = nullptr;
         ugCheck(ug_dvec_wrap(d_.ctx2, deviceOut, hdr_.domainSize, &v));
-        int rc = ug_hpoly_chain(d_.hp, d_.w, which, v);
+        int rc = ug_hpoly_chain(d_.hp, wCur_, which, v);
         ug_dvec_destroy(v);
         ugCheck(rc);
         collectTimings(2);
@@ -738,7 +748,7 @@ public:
         if (nw > maxRange_ || nh > maxRange_) {                 // proved in pieces: partial sums are added between them
             uint8_t hpart[UG_GROTH16_PARTIALS_SIZE];
             runWitnessMsm(partials, /*standalone*/ false);
-            ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                          // S5-S9 :66-148
+            ugCheck(ug_hpoly_run(d_.hp, wCur_, d_.h));                                          // S5-S9 :66-148
             runHMsmImpl(hpart, false);                                                         // S10   :154
             memcpy(partials + 320, hpart + 320, 64);
             collectTimings(3);
@@ -747,7 +757,7 @@ public:
         const char* ov = getenv("ULTRAGROTH_OVERLAP");
         const bool overlap = ov && atoi(ov) != 0;
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
-        buildSchedule(d_.sw, d_.w, wr_.lo, nw, tableW_);
+        buildSchedule(d_.sw, wCur_, wr_.lo, nw, tableW_);
         {   // S1-S4 (src/groth16.cpp:55,58,61,64): A, B1, B2, C over the witness schedule, queued back to back
             const ug_bases* sets[4] = {d_.A, d_.B1, d_.B2, d_.C};
             const int64_t shifts[4] = {0, 0, 0, (int64_t)hdr_.nPublic + 1};
@@ -755,7 +765,7 @@ public:
             ugCheck(ug_msm_batch_enqueue(d_.ctx, 4, sets, d_.sw, shifts, outs));
         }
         if (!overlap) ugCheck(ug_ctx_wait(d_.ctx2, d_.ctx));
-        ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                              // S5-S9 :66-148
+        ugCheck(ug_hpoly_run(d_.hp, wCur_, d_.h));                                              // S5-S9 :66-148
         buildSchedule(d_.sh, d_.h, hr_.lo, nh, tableH_);
         {
             const ug_bases* sets[1] = {d_.H};
@@ -826,6 +836,7 @@ private:
     uint64_t cLo_ = 0, cHi_ = 0;       // this rank's slice of the C section
     DeviceProver d_;
     bool witnessLoaded_ = false, witnessComplete_ = false, haveHpoly_ = true;
+    ug_dvec* wCur_ = nullptr;          // the witness the device part reads: one of the two buffers (d_.w, d_.w2 own them)
     WitnessSlot slots_[2];
     std::mutex slotMutex_, stageMutex_;
     std::condition_variable slotFree_;
