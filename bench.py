@@ -122,6 +122,10 @@ def cpu_baseline(dev, args, log_domain):
     else:
         dt_hi, msm_hi, fft_hi = dt_lo, msm_lo, fft_lo
     rest_hi = max(dt_hi - msm_hi - fft_hi, 0.0)                # parsing, blinding, JSON: grows at most linearly
+    # for reference, one thread against all of them on a small circuit
+    one_log = min(lo, 16)
+    one = timed(one_log, 1)
+    many = timed(one_log, cores)
     if log_domain > hi:
         e_msm = math.log2(msm_hi / msm_lo) / (hi - lo)
         e_fft = math.log2(fft_hi / fft_lo) / (hi - lo)
@@ -138,6 +142,7 @@ def cpu_baseline(dev, args, log_domain):
         "sample": "oracle (restated rapidsnark-equivalent CPU path, plain C + OpenMP, %d threads) proving the 2^%d circuit of the "
                   "same generator in %.2f s (MSM %.2f | FFT %.2f) and the 2^%d circuit in %.2f s (MSM %.2f | FFT %.2f); %s"
                   % (cores, lo, dt_lo, msm_lo, fft_lo, hi, dt_hi, msm_hi, fft_hi, how),
+        "single_thread": {"log_domain": one_log, "seconds_1_thread": one[0], "seconds_all_threads": many[0], "threads": cores},
     }
 
 
