@@ -92,7 +92,7 @@ def cpu_model():
 
 def cpu_baseline(dev, args, log_domain):
     """Oracle (plain C + OpenMP) on bounded samples of the same generator. The proof is timed at two sizes (2^20 and 2^22
-    by default, about 25 s of CPU work together), MSM and FFT parts separately; each part is extrapolated to the
+    by default, the larger one twice, about 30 s of CPU work together), MSM and FFT parts separately; each part is extrapolated to the
     benchmarked size with ITS OWN fitted exponent (t ~ N^e: Pippenger is sub-linear, the FFT block N log N), not
     linearly. A benchmarked size at or below the larger sample is measured directly. The box may show more cores than
     its share (16 per GPU): the small sample is timed with the detected share and with 16 and 32 threads when those are
@@ -118,7 +118,9 @@ def cpu_baseline(dev, args, log_domain):
             best = t
     dt_lo, msm_lo, fft_lo, cores = best
     if hi > lo:
-        dt_hi, msm_hi, fft_hi, _ = timed(hi, cores)
+        # the host is shared with other tenants' jobs: the faster of two runs (12 vs 14 s were seen for the same sample, and
+        # the fitted exponents double such noise in the extrapolation)
+        dt_hi, msm_hi, fft_hi, _ = min(timed(hi, cores), timed(hi, cores))
     else:
         dt_hi, msm_hi, fft_hi = dt_lo, msm_lo, fft_lo
     rest_hi = max(dt_hi - msm_hi - fft_hi, 0.0)                # parsing, blinding, JSON: grows at most linearly

@@ -184,27 +184,56 @@ __global__ void msm_digits_kernel(const u32* scalars, u64 n, int c, int windows,
 
 // ---- 3. bucket bounds -----------------------------------------------------------------------------------
 // meta[0] = number of heavy buckets, meta[1] = number of non-sentinel entries
+// (four entries per lane, one 16-byte load: with one entry per lane the launch was bound by wave dispatch, 0.65 ms for
+// 0.8 GB of keys at 2^24)
 __global__ void bucket_bounds_kernel(const u32* keys, u64 total, u32 sentinel, u32* start, u32* count, u32* meta) {
-    u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= total) return;
-    u32 k = keys[p];
-    if (k == sentinel) return;
-    if (p == 0 || keys[p - 1] != k) start[k] = (u32)p;
-    if (p + 1 == total || keys[p + 1] != k) count[k] = (u32)p + 1;      // end for now
-    if (p + 1 == total || keys[p + 1] == sentinel) meta[1] = (u32)p + 1;
+    const u64 p0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (p0 >= total) return;
+    u32 k[6];                                   // k[0] = the entry before the four, k[5] = the one after (sentinel past the end)
+    if (p0 + 4 <= total) {
+        const uint4 v = *reinterpret_cast<const uint4*>(keys + p0);
+        k[1] = v.x; k[2] = v.y; k[3] = v.z; k[4] = v.w;
+    } else {
+        for (int i = 0; i < 4; i++) k[1 + i] = p0 + i < total ? keys[p0 + i] : sentinel;
+    }
+    k[0] = p0 ? keys[p0 - 1] : sentinel;
+    k[5] = p0 + 4 < total ? keys[p0 + 4] : sentinel;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const u64 p = p0 + i;
+        const u32 key = k[1 + i];
+        if (p >= total || key == sentinel) continue;
+        if (p == 0 || k[i] != key) start[key] = (u32)p;
+        if (k[2 + i] != key) count[key] = (u32)p + 1;                   // end for now (past the end reads as the sentinel)
+        if (k[2 + i] == sentinel) meta[1] = (u32)p + 1;
+    }
 }
 // buckets whose entries span more than FIX_MAX lanes of the segmented accumulation are listed as heavy
-__global__ void bucket_counts_kernel(u32* start, u32* count, u32 nb, int log_seg, u32* meta, u32* heavy_list, u32* medium_list,
-                                     u32 heavy_cap, u32* small_list) {
-    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    u32 e = count[b];
-    u32 c = e ? e - start[b] : 0;
-    count[b] = c;
-    if (!c) return;
-    u32 first = start[b] >> log_seg, last = (start[b] + c - 1) >> log_seg;
-    u32 pieces = last - first + 1;
-    if (pieces >= 2 && pieces <= FIX_MAX) small_list[atomicAdd(&meta[4], 1u)] = b;      // at most one entry per bucket: nb slots
+// The list of buckets with 2 .. FIX_MAX pieces takes most buckets of a large MSM (one and a half million at 2^24): its
+// slots are handed out per WORKGROUP -- lanes count themselves in LDS, one lane adds the workgroup's total to meta[4].
+// (Same-address atomics are served one after the other by L2, about 11 ns each: one per wave, which is what the compiler
+// makes of a per-lane atomicAdd, is 32 768 of them = 0.33 of this kernel's 0.38 ms; one per 1 024 lanes is 2 048.)
+__global__ __launch_bounds__(1024) void bucket_counts_kernel(u32* start, u32* count, u32 nb, int log_seg, u32* meta, u32* heavy_list,
+                                                           u32* medium_list, u32 heavy_cap, u32* small_list) {
+    __shared__ u32 listed, list_base;
+    if (threadIdx.x == 0) listed = 0;
+    __syncthreads();
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 c = 0, first = 0, last = 0;
+    if (b < nb) {
+        const u32 e = count[b];
+        c = e ? e - start[b] : 0;
+        count[b] = c;
+        if (c) { first = start[b] >> log_seg; last = (start[b] + c - 1) >> log_seg; }
+    }
+    const u32 pieces = c ? last - first + 1 : 0;
+    const bool small = pieces >= 2 && pieces <= FIX_MAX;      // at most one entry per bucket: nb slots
+    u32 slot = 0;
+    if (small) slot = atomicAdd(&listed, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0 && listed) list_base = atomicAdd(&meta[4], listed);
+    __syncthreads();
+    if (small) small_list[list_base + slot] = b;
     if (pieces > MEDIUM_MAX) {
         u32 pos = atomicAdd(&meta[0], 1u);
         if (pos < heavy_cap) { heavy_list[4 * pos] = b; heavy_list[4 * pos + 1] = first; heavy_list[4 * pos + 2] = last; heavy_list[4 * pos + 3] = 0; }
@@ -369,21 +398,24 @@ __device__ __forceinline__ XYZZ<typename Cfg::F> block_reduce(XYZZ<typename Cfg:
 template <class Cfg>
 __global__ __launch_bounds__(256) void medium_bucket_kernel(const HeavyBucket* mb, const u32* meta, u32 cap, const u32* slot_pts, u32* bucket_pts) {
     typedef typename Cfg::F F;
-    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const u32 lane = threadIdx.x & 63, n_waves = (gridDim.x * blockDim.x) >> 6;
     const u32 n_medium = meta[3] < cap ? meta[3] : cap;
-    if (wave >= n_medium) return;
-    HeavyBucket h = mb[wave];
-    u32 pieces = h.last_seg - h.first_seg + 1;
-    XYZZ<F> acc = xyzz_inf<F>();
-    for (u32 k = lane; k < pieces; k += 64) acc = xyzz_add(acc, load_piece<Cfg>(slot_pts, h.first_seg, k));
-    u32 w[Cfg::PT_WORDS];
-    for (int off = 32; off > 0; off >>= 1) {
-        Cfg::to_words(w, acc, 1);
+    // the waves stride over the list: the host knows only an upper bound of its length (tens of thousands at 2^24, where
+    // uniform scalars list none: a grid of that size took 0.16 ms to find nothing to do)
+    for (u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wave < n_medium; wave += n_waves) {
+        HeavyBucket h = mb[wave];
+        u32 pieces = h.last_seg - h.first_seg + 1;
+        XYZZ<F> acc = xyzz_inf<F>();
+        for (u32 k = lane; k < pieces; k += 64) acc = xyzz_add(acc, load_piece<Cfg>(slot_pts, h.first_seg, k));
+        u32 w[Cfg::PT_WORDS];
+        for (int off = 32; off > 0; off >>= 1) {
+            Cfg::to_words(w, acc, 1);
 #pragma unroll
-        for (int i = 0; i < Cfg::PT_WORDS; i++) w[i] = __shfl_xor(w[i], off, 64);
-        acc = xyzz_add(acc, Cfg::from_words(w, 1));
+            for (int i = 0; i < Cfg::PT_WORDS; i++) w[i] = __shfl_xor(w[i], off, 64);
+            acc = xyzz_add(acc, Cfg::from_words(w, 1));
+        }
+        if (lane == 0) Cfg::to_words(bucket_pts + (size_t)h.bucket * Cfg::PT_WORDS, acc, 1);
     }
-    if (lane == 0) Cfg::to_words(bucket_pts + (size_t)h.bucket * Cfg::PT_WORDS, acc, 1);
 }
 
 // Heavy buckets (a 0/1-heavy witness, or the short top window of uniform scalars, puts up to millions of
@@ -722,10 +754,10 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
     UG_HIP(hipMemsetAsync(bucket_start, 0, (size_t)nb * 4, stream));
     UG_HIP(hipMemsetAsync(bucket_count, 0, (size_t)nb * 4, stream));
     UG_HIP(hipMemsetAsync(meta, 0, 32, stream));
-    hipLaunchKernelGGL(bucket_bounds_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(bucket_bounds_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, stream,
                        keys, total, sentinel, bucket_start, bucket_count, meta);
     UG_KERNEL_CHECK();
-    hipLaunchKernelGGL(bucket_counts_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, bucket_start, bucket_count, nb,
+    hipLaunchKernelGGL(bucket_counts_kernel, dim3((nb + 1023) / 1024), dim3(1024), 0, stream, bucket_start, bucket_count, nb,
                        log_seg, meta, heavy_list, medium_list, heavy_cap, small_list);
     UG_KERNEL_CHECK();
     hipLaunchKernelGGL(heavy_plan_kernel, dim3(1), dim3(1024), 0, stream, (const HeavyBucket*)heavy_list, heavy_cap, meta, heavy_offsets);
@@ -804,7 +836,7 @@ MsmPending msm_enqueue(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases,
                            s.small_list, s.meta, s.bucket_start, s.bucket_count, s.log_seg, ws.slot_pts, ws.bucket_pts);
         UG_KERNEL_CHECK();
         if (nseg > FIX_MAX) {
-            hipLaunchKernelGGL(medium_bucket_kernel<Cfg>, dim3((medium_max + 3) / 4), dim3(256), 0, stream,
+            hipLaunchKernelGGL(medium_bucket_kernel<Cfg>, dim3(std::min<u32>((medium_max + 3) / 4, 2048)), dim3(256), 0, stream,
                                (const HeavyBucket*)s.medium_list, s.meta, medium_max, ws.slot_pts, ws.bucket_pts);
             UG_KERNEL_CHECK();
         }
