@@ -620,17 +620,30 @@ public:
         witnessLoaded_ = true; witnessComplete_ = true;
     }
     // lock order everywhere: witness lease -> stageMutex_ (released again) -> the card's lock -> proveMutex
+    // ULTRAGROTH_TRACE=1: when each step of a call happens, in ms of a process-wide clock, on stderr (two callers' lines
+    // interleave: how long the device waits between one proof's last kernel and the next one's first)
+    static void traceStep(const char* what) {
+        static const bool on = getenv("ULTRAGROTH_TRACE") && atoi(getenv("ULTRAGROTH_TRACE")) != 0;
+        if (!on) return;
+        static const auto origin = std::chrono::steady_clock::now();
+        fprintf(stderr, "[groth16 %5.5zx] %9.3f ms  %s\n", std::hash<std::thread::id>()(std::this_thread::get_id()) & 0xfffff,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - origin).count(), what);
+    }
     void proveTurn(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub, std::mutex* device,
                    const Around& around) override {
         auto t0 = std::chrono::steady_clock::now();
+        traceStep("call");
         WitnessLease lease(*this);
         stage(*lease, wtns, wtnsSize);
+        traceStep("witness staged");
         std::unique_lock<std::mutex> card;
         if (device) card = std::unique_lock<std::mutex>(*device);
         std::lock_guard<std::mutex> turn(proveMutex);
+        traceStep("turn on the device");
         if (around) around(true);
         adopt(*lease);
         proveLoaded(proof, pub);
+        traceStep("proof finished");
         totalMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (around) around(false);
     }
@@ -812,7 +825,9 @@ public:
         drawBlinding(r); drawBlinding(s);
         auto terms = std::async(std::launch::async, [&] { return blindingTerms(hdr_, r, s); });
         uint8_t partials[UG_GROTH16_PARTIALS_SIZE];
+        traceStep("device part queued from here");
         run(partials);                                   // (the future joins in its destructor if this throws)
+        traceStep("device part done");
         finishWith(partials, r, s, terms.get(), proof, pub);
     }
 
