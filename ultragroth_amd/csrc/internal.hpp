@@ -67,7 +67,8 @@ struct MsmSchedule {
     u32* bucket_start = nullptr;  // per bucket: first entry
     u32* bucket_count = nullptr;  // per bucket: number of entries
     u32* small_list = nullptr;    // buckets cut into 2 .. 32 segment pieces (meta[4] of them), any order
-    int log_seg = 0;              // entries per lane of the segmented accumulation = 2^log_seg
+    int log_seg = 0;              // entries per lane of the segmented accumulation = 2^log_seg ...
+    int log_seg_tail = 0;         // ... and 2^log_seg_tail for the segments of the last eighth of the entries (msm.hip: SegMap)
     u32* heavy_list = nullptr;    // device: HeavyBucket[heavy_cap]
     u32 heavy_cap = 0;
     u32* medium_list = nullptr;   // device: HeavyBucket[heavy_cap] for buckets of FIX_MAX < pieces <= MEDIUM_MAX

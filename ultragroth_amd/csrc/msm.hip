@@ -182,6 +182,42 @@ __global__ void msm_digits_kernel(const u32* scalars, u64 n, int c, int windows,
     }
 }
 
+// ---- segments -------------------------------------------------------------------------------------------------
+// The sorted entry list is cut into segments, one lane of the accumulation kernel each: 2^log_a entries per segment up to
+// entry `split`, 2^log_b (shorter) after it. Workgroups are dispatched in index order, so the short segments are the last
+// to start and fill the end of the launch, where CUs that drifted apart over the 8 - 12 rounds of workgroups would
+// otherwise wait for the slowest. Measured at 2^24 (A/B on one box, UG_SEG_TAPER): G1 launch 15.20 -> 15.07 ms, G2 40.98 ->
+// 40.59, the MSM part of a proof 122.85 -> 122.55 ms -- the end of the launch costs less than it might (short segments
+// everywhere gain 1.0 / 2.9 ms per launch, but that is a per-entry effect: an eighth of the entries gives an eighth of
+// it, and four times as many bucket pieces cost the fix-up far more). split is a whole number of wave tiles (64 long
+// segments), so both kinds of tile stay contiguous in the lane-transposed copy. The map is made on the device from the
+// number of valid entries (meta[1]), which the host never reads.
+struct SegMap {
+    u32 split, seg0;          // first entry / first segment of the short kind
+    int log_a, log_b;
+    __host__ __device__ static SegMap make(u64 n_valid, int log_a, int log_b) {
+        SegMap m;
+        m.log_a = log_a; m.log_b = log_b;
+        const u64 tile = (u64)64 << log_a;
+        const u64 split = log_b < log_a ? ((n_valid - (n_valid >> 3)) / tile) * tile : ((n_valid + tile - 1) / tile) * tile;
+        m.split = (u32)split; m.seg0 = (u32)(split >> log_a);
+        return m;
+    }
+    __host__ __device__ u32 seg_of(u32 pos) const { return pos < split ? pos >> log_a : seg0 + ((pos - split) >> log_b); }
+    __host__ __device__ u32 first_entry(u32 seg) const { return seg < seg0 ? seg << log_a : split + ((seg - seg0) << log_b); }
+    __host__ __device__ int log_len(u32 seg) const { return seg < seg0 ? log_a : log_b; }
+    // position of entry k of segment seg in the lane-transposed copy (seg0 is a multiple of 64)
+    __host__ __device__ u64 transposed(u32 seg, u32 k) const {
+        const u64 tile0 = seg < seg0 ? (u64)(seg >> 6) << (log_a + 6) : (u64)split + ((u64)((seg - seg0) >> 6) << (log_b + 6));
+        return tile0 + ((u64)k << 6) + (seg & 63);
+    }
+    // upper bound of the number of segments of any n_valid <= total (what the host sizes grids and slot arrays with)
+    static u64 max_segments(u64 total, int log_a, int log_b) {
+        if (log_b >= log_a) return (total + ((u64)1 << log_a) - 1) >> log_a;
+        return (total >> log_a) + (((total >> 3) + ((u64)64 << log_a)) >> log_b) + 64;
+    }
+};
+
 // ---- 3. bucket bounds -----------------------------------------------------------------------------------
 // meta[0] = number of heavy buckets, meta[1] = number of non-sentinel entries
 // (four entries per lane, one 16-byte load: with one entry per lane the launch was bound by wave dispatch, 0.65 ms for
@@ -213,7 +249,7 @@ __global__ void bucket_bounds_kernel(const u32* keys, u64 total, u32 sentinel, u
 // slots are handed out per WORKGROUP -- lanes count themselves in LDS, one lane adds the workgroup's total to meta[4].
 // (Same-address atomics are served one after the other by L2, about 11 ns each: one per wave, which is what the compiler
 // makes of a per-lane atomicAdd, is 32 768 of them = 0.33 of this kernel's 0.38 ms; one per 1 024 lanes is 2 048.)
-__global__ __launch_bounds__(1024) void bucket_counts_kernel(u32* start, u32* count, u32 nb, int log_seg, u32* meta, u32* heavy_list,
+__global__ __launch_bounds__(1024) void bucket_counts_kernel(u32* start, u32* count, u32 nb, int log_a, int log_b, u32* meta, u32* heavy_list,
                                                            u32* medium_list, u32 heavy_cap, u32* small_list) {
     __shared__ u32 listed, list_base;
     if (threadIdx.x == 0) listed = 0;
@@ -224,7 +260,7 @@ __global__ __launch_bounds__(1024) void bucket_counts_kernel(u32* start, u32* co
         const u32 e = count[b];
         c = e ? e - start[b] : 0;
         count[b] = c;
-        if (c) { first = start[b] >> log_seg; last = (start[b] + c - 1) >> log_seg; }
+        if (c) { const SegMap map = SegMap::make(meta[1], log_a, log_b); first = map.seg_of(start[b]); last = map.seg_of(start[b] + c - 1); }
     }
     const u32 pieces = c ? last - first + 1 : 0;
     const bool small = pieces >= 2 && pieces <= FIX_MAX;      // at most one entry per bucket: nb slots
@@ -252,27 +288,27 @@ __global__ __launch_bounds__(1024) void bucket_counts_kernel(u32* start, u32* co
 // bucket_fixup_kernel then adds the pieces of every bucket that straddles segments (normally two).
 // Entries are stored "lane-transposed": the 2^log_seg entries of the 64 segments handled by one wave are
 // interleaved so that step k of all 64 lanes reads 64 consecutive words (one fully coalesced 256-byte access).
-__host__ __device__ __forceinline__ u64 transposed_index(u64 seg, u32 k, int log_seg) {
-    return ((seg >> 6) << (log_seg + 6)) + ((u64)k << 6) + (seg & 63);
-}
-// one workgroup per tile of 64 segments: coalesced reads of the tile's 64 * 2^log_seg consecutive entries,
-// transposition through LDS (row stride padded by one word), coalesced writes
+// one workgroup per tile of 64 segments: coalesced reads of the tile's 64 * 2^log consecutive entries, transposition
+// through LDS (row stride padded by one word), coalesced writes
 __global__ __launch_bounds__(1024) void transpose_entries_kernel(const u32* __restrict__ keys, const u32* __restrict__ vals,
-                                                                const u32* __restrict__ meta, u32 sentinel, int log_seg,
+                                                                const u32* __restrict__ meta, u32 sentinel, int log_a, int log_b,
                                                                 u32* __restrict__ tkeys, u32* __restrict__ tvals) {
-    extern __shared__ u32 tile[];                                   // 2 arrays of 64 * (S + 1) words
+    extern __shared__ u32 tile[];                                   // 2 arrays of 64 * (2^log_a + 1) words
+    const u32 n_valid = meta[1];                                    // (the grid covers every entry: the host never reads the count)
+    const SegMap map = SegMap::make(n_valid, log_a, log_b);
+    const u32 seg = blockIdx.x << 6;                                // first segment of the tile
+    const u64 base = map.first_entry(seg);
+    if (base >= n_valid) return;
+    const int log_seg = map.log_len(seg);
     const u32 S = 1u << log_seg, row = S + 1;
     u32* tk = tile;
     u32* tv = tile + 64 * row;
-    const u32 n_valid = meta[1];                                    // (the grid covers every entry: the host never reads the count)
-    const u64 base = (u64)blockIdx.x << (log_seg + 6);
-    if (base >= n_valid) return;
     for (u32 i = threadIdx.x; i < (64u << log_seg); i += blockDim.x) {
         u64 src = base + i;
         bool in = src < n_valid;
-        u32 seg = i >> log_seg, k = i & (S - 1);
-        tk[seg * row + k] = in ? keys[src] : sentinel;
-        tv[seg * row + k] = in ? vals[src] : 0u;
+        u32 sg = i >> log_seg, k = i & (S - 1);
+        tk[sg * row + k] = in ? keys[src] : sentinel;
+        tv[sg * row + k] = in ? vals[src] : 0u;
     }
     __syncthreads();
     for (u32 o = threadIdx.x; o < (64u << log_seg); o += blockDim.x) {
@@ -285,17 +321,18 @@ __global__ __launch_bounds__(1024) void transpose_entries_kernel(const u32* __re
 template <class Cfg>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Cfg::ACC_WAVES, Cfg::ACC_WAVES))) void segment_accumulate_kernel(const u32* __restrict__ bases, u64 n_bases, int64_t delta,
                                                                  const u32* __restrict__ keys, const u32* __restrict__ tkeys,
-                                                                 const u32* __restrict__ tvals, const u32* __restrict__ meta, int log_seg,
+                                                                 const u32* __restrict__ tvals, const u32* __restrict__ meta, int log_a, int log_b,
                                                                  u32* __restrict__ bucket_pts, u32* __restrict__ slot_pts) {
     typedef typename Cfg::F F;
     const u32 n_valid = meta[1];
+    const SegMap map = SegMap::make(n_valid, log_a, log_b);
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    u64 lo = (u64)t << log_seg;
+    u64 lo = map.first_entry(t);
     if (lo >= n_valid) return;
-    u64 hi = lo + ((u64)1 << log_seg);
+    u64 hi = lo + ((u64)1 << map.log_len(t));
     if (hi > n_valid) hi = n_valid;
     const u32 cnt = (u32)(hi - lo);
-    const u64 tbase = transposed_index(t, 0, log_seg);
+    const u64 tbase = map.transposed(t, 0);
     u32 cur = tkeys[tbase];
     bool first_run = true;
     const bool start_open = lo > 0 && keys[lo - 1] == cur;
@@ -366,14 +403,15 @@ __device__ __forceinline__ XYZZ<typename Cfg::F> load_piece(const u32* slot_pts,
 // witness phase in kernels that run one wave per SIMD.) Buckets with more pieces go to the wave / workgroup paths.
 template <class Cfg>
 __global__ __launch_bounds__(128) void bucket_fixup_kernel(const u32* __restrict__ small_list, const u32* __restrict__ meta,
-                                                           const u32* __restrict__ start, const u32* __restrict__ count, int log_seg,
+                                                           const u32* __restrict__ start, const u32* __restrict__ count, int log_a, int log_b,
                                                            const u32* __restrict__ slot_pts, u32* __restrict__ bucket_pts) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= meta[4]) return;
     typedef typename Cfg::F F;
     const u32 b = small_list[t];
     const u32 st = start[b];
-    const u32 first = st >> log_seg, last = (st + count[b] - 1) >> log_seg;
+    const SegMap map = SegMap::make(meta[1], log_a, log_b);
+    const u32 first = map.seg_of(st), last = map.seg_of(st + count[b] - 1);
     const u32 pieces = last - first + 1;
     XYZZ<F> acc = load_piece<Cfg>(slot_pts, first, 0);
     for (u32 k = 1; k < pieces; k++) acc = xyzz_add(acc, load_piece<Cfg>(slot_pts, first, k));
@@ -735,6 +773,10 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
     geo = g;
     reserve(g);
     log_seg = segment_log(g.n * g.windows);
+    // short segments for the last eighth of a large schedule (SegMap): worth it once the accumulation takes several rounds
+    // of workgroups (UG_SEG_TAPER=0 turns it off)
+    static const bool taper = !(getenv("UG_SEG_TAPER") && atoi(getenv("UG_SEG_TAPER")) == 0);
+    log_seg_tail = (taper && log_seg == LOG_SEG && ((g.n * g.windows) >> log_seg) >= ((u64)1 << 16)) ? log_seg - 2 : log_seg;
     if (g.n == 0) return;
     u64 total = g.n * g.windows;
     if (total >= ((u64)1 << 31)) throw std::invalid_argument("msm: n * windows exceeds 2^31 entries");
@@ -758,21 +800,20 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
                        keys, total, sentinel, bucket_start, bucket_count, meta);
     UG_KERNEL_CHECK();
     hipLaunchKernelGGL(bucket_counts_kernel, dim3((nb + 1023) / 1024), dim3(1024), 0, stream, bucket_start, bucket_count, nb,
-                       log_seg, meta, heavy_list, medium_list, heavy_cap, small_list);
+                       log_seg, log_seg_tail, meta, heavy_list, medium_list, heavy_cap, small_list);
     UG_KERNEL_CHECK();
     hipLaunchKernelGGL(heavy_plan_kernel, dim3(1), dim3(1024), 0, stream, (const HeavyBucket*)heavy_list, heavy_cap, meta, heavy_offsets);
     UG_KERNEL_CHECK();
     // No read-back of the counts: every later launch is sized by an upper bound derived from n * windows and reads the
     // true counts (meta) on the device, so a schedule costs the host no synchronisation.
     // lane-transposed copy of the valid entries into the sort's spare buffers
-    u64 tile = (u64)64 << log_seg;
-    u64 n_tiles = (total + tile - 1) / tile;
+    u64 n_tiles = (SegMap::max_segments(total, log_seg, log_seg_tail) + 63) / 64;
     u32* tk = (keys == keys_a) ? keys_b : keys_a;
     u32* tv = (vals == vals_a) ? vals_b : vals_a;
     {
         size_t lds = (size_t)2 * 64 * (((size_t)1 << log_seg) + 1) * 4;
         hipLaunchKernelGGL(transpose_entries_kernel, dim3((unsigned)n_tiles), dim3(1024), lds, stream,
-                           keys, vals, meta, sentinel, log_seg, tk, tv);
+                           keys, vals, meta, sentinel, log_seg, log_seg_tail, tk, tv);
         UG_KERNEL_CHECK();
     }
     tkeys = tk; tvals = tv;
@@ -818,7 +859,7 @@ MsmPending msm_enqueue(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases,
     // upper bounds of what the schedule holds (the true counts stay on the device, MsmSchedule::meta):
     // segments; heavy buckets (each spans more than MEDIUM_MAX segments); their 1024-piece tasks; medium buckets
     const u64 total = g.n * g.windows;
-    const u64 nseg = (total + ((u64)1 << s.log_seg) - 1) >> s.log_seg;
+    const u64 nseg = SegMap::max_segments(total, s.log_seg, s.log_seg_tail);
     const u32 heavy_max = (u32)std::min<u64>(s.heavy_cap, nseg / MEDIUM_MAX + 1);
     const u32 tasks_max = (u32)((nseg + heavy_max) / HEAVY_TASK + heavy_max + 1);
     const u32 medium_max = (u32)std::min<u64>(s.heavy_cap, nseg / (FIX_MAX - 1) + 1);
@@ -826,14 +867,14 @@ MsmPending msm_enqueue(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases,
     int slot = stats ? stats->begin(stream, g.n * g.windows) : -1;
     if (nseg) {
         hipLaunchKernelGGL(segment_accumulate_kernel<Cfg>, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, stream,
-                           bases, n_bases, delta, s.keys, s.tkeys, s.tvals, s.meta, s.log_seg, ws.bucket_pts, ws.slot_pts);
+                           bases, n_bases, delta, s.keys, s.tkeys, s.tvals, s.meta, s.log_seg, s.log_seg_tail, ws.bucket_pts, ws.slot_pts);
         UG_KERNEL_CHECK();
     }
     if (stats) stats->end(slot, stream);
     if (nseg > 1) {
         const u64 small_max = std::min<u64>(g.total_buckets(), nseg);       // a listed bucket crosses a segment boundary of its own
         hipLaunchKernelGGL(bucket_fixup_kernel<Cfg>, dim3((unsigned)((small_max + 127) / 128)), dim3(128), 0, stream,
-                           s.small_list, s.meta, s.bucket_start, s.bucket_count, s.log_seg, ws.slot_pts, ws.bucket_pts);
+                           s.small_list, s.meta, s.bucket_start, s.bucket_count, s.log_seg, s.log_seg_tail, ws.slot_pts, ws.bucket_pts);
         UG_KERNEL_CHECK();
         if (nseg > FIX_MAX) {
             hipLaunchKernelGGL(medium_bucket_kernel<Cfg>, dim3(std::min<u32>((medium_max + 3) / 4, 2048)), dim3(256), 0, stream,
