@@ -30,7 +30,7 @@
  *     allocates everything per call, src/prover.cpp:341-391): the calls take turns on the device. A
  *     Groth16 prover copies the witness of a waiting call into its second witness buffer meanwhile, so
  *     two threads proving on one object hide the host-to-device copy of one proof behind the kernels of
- *     the other (2^24: 10 ms of a 155 ms proof). The ug_ phase calls of a sharded proof below are driven
+ *     the other (2^24: 10 ms of a 150 ms proof). The ug_ phase calls of a sharded proof below are driven
  *     by one thread per object and must not be mixed with concurrent *_prove calls on the same object;
  *   - a prover object is bound to one HIP device (environment variable ULTRAGROTH_DEVICE, default 0).
  *
