@@ -187,10 +187,9 @@ __global__ void msm_digits_kernel(const u32* scalars, u64 n, int c, int windows,
 // entry `split`, 2^log_b (shorter) after it. Workgroups are dispatched in index order, so the short segments are the last
 // to start and fill the end of the launch, where CUs that drifted apart over the 8 - 12 rounds of workgroups would
 // otherwise wait for the slowest. Measured at 2^24 (A/B on one box, UG_SEG_TAPER): G1 launch 15.20 -> 15.07 ms, G2 40.98 ->
-// 40.59, the MSM part of a proof 122.85 -> 122.55 ms -- the end of the launch costs less than it might (short segments
-// everywhere gain 1.0 / 2.9 ms per launch, but that is a per-entry effect: an eighth of the entries gives an eighth of
-// it, and four times as many bucket pieces cost the fix-up far more). split is a whole number of wave tiles (64 long
-// segments), so both kinds of tile stay contiguous in the lane-transposed copy. The map is made on the device from the
+// 40.59, the MSM part of a proof 122.85 -> 122.55 ms (short segments everywhere would cost the fix-up more than that:
+// four times as many bucket pieces). split is a whole number of wave tiles (64 long segments), so both kinds of tile stay
+// contiguous in the lane-transposed copy. The map is made on the device from the
 // number of valid entries (meta[1]), which the host never reads.
 struct SegMap {
     u32 split, seg0;          // first entry / first segment of the short kind
