@@ -135,3 +135,20 @@ def test_curve_formulas_and_exceptional_cases(hm, zkey):
     for k in (1, 2, O.R_MOD - 1, rng.randrange(1 << 256)):
         hm.ugt_g2_mul(out2, p2, O.to_le(k))
         assert out2.raw == O.g2_mul(p2, k)
+
+
+def test_segment_map_invariants(hm):
+    """csrc/segmap.hpp: the cut of an MSM schedule's sorted entries into long segments and, for the last eighth, short
+    ones. Every kernel of msm.hip derives positions from this map (on the device, from the number of valid entries), so
+    its invariants are checked here for sizes around every boundary: segments tile the entries in order, seg_of inverts
+    first_entry, the lane-transposed position stays inside the wave's tile, and the host's upper bound of the segment
+    count (grid and slot sizes) holds for every n_valid <= total."""
+    hm.ugt_segmap_check.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int]
+    rng = random.Random(77)
+    for log_a, log_b in ((7, 5), (7, 7), (6, 6), (5, 5), (7, 6)):
+        tile = 64 << log_a
+        sizes = {0, 1, 63, 64, 65, tile - 1, tile, tile + 1, 8 * tile - 1, 8 * tile, 8 * tile + 1, 9 * tile + 77, 64 * tile + 5}
+        sizes |= {rng.randrange(1, 3_000_000) for _ in range(40)}
+        for n in sorted(sizes):
+            for total in (n, n + n // 3 + 1, 2 * n + tile):
+                assert hm.ugt_segmap_check(n, total, log_a, log_b) == 0, (n, total, log_a, log_b)

@@ -4,8 +4,10 @@
 // tests compare results with the oracle. Interface: reference byte formats (32-byte little-endian
 // Montgomery R=2^256 values, zkey affine records, (0,0) = infinity).
 #include <cstring>
+#include <initializer_list>
 #include <cstdint>
 #include "ec.hpp"
+#include "segmap.hpp"
 
 using namespace ug;
 
@@ -159,6 +161,34 @@ void ugt_g2_mul(uint8_t out[128], const uint8_t base[128], const uint8_t scalar[
     Fq2 x, y; u32 k[8]; memcpy(k, scalar, 32);
     if (!g2_load(base, x, y)) { memset(out, 0, 128); return; }
     g2_store(out, xyzz_mul_scalar(xyzz_from_affine(x, y), k, 256));
+}
+
+// SegMap (segmap.hpp): every invariant the kernels of msm.hip rely on, for one (n_valid, log_a, log_b); 0 = all hold
+int ugt_segmap_check(uint64_t n_valid, uint64_t total, int log_a, int log_b) {
+    const SegMap m = SegMap::make(n_valid, log_a, log_b);
+    if (m.seg0 % 64 || m.split % ((uint64_t)64 << log_a) || m.split > n_valid + ((uint64_t)64 << log_a)) return 1;
+    if (log_b < log_a && m.split > n_valid) return 2;
+    // segments tile [0, n_valid) in order, each entry belongs to the segment seg_of names, lengths as log_len says
+    uint64_t pos = 0; uint32_t t = 0;
+    while (pos < n_valid) {
+        if (m.first_entry(t) != pos) return 3;
+        const uint64_t len = (uint64_t)1 << m.log_len(t);
+        if (m.log_len(t) != (t < m.seg0 ? log_a : log_b)) return 4;
+        const uint64_t probes[3] = {pos, pos + len / 2, pos + len - 1};
+        for (uint64_t p : probes) if (p < n_valid && m.seg_of((uint32_t)p) != t) return 5;
+        // lane-transposed positions: inside the tile of the segment's wave, distinct for the 64 segments of the tile
+        const uint64_t tile0 = m.first_entry(t & ~63u), tile_len = (uint64_t)64 << m.log_len(t);
+        const uint32_t ks[2] = {0u, (uint32_t)(len - 1)};
+        for (uint32_t k : ks) {
+            const uint64_t q = m.transposed(t, k);
+            if (q < tile0 || q >= tile0 + tile_len || (q - tile0) % 64 != (t & 63) || (q - tile0) / 64 != k) return 6;
+        }
+        pos += len; t++;
+    }
+    if (n_valid > total) return 7;
+    if (t > SegMap::max_segments(total, log_a, log_b)) return 8;        // the host's grid / slot bound covers every segment
+    if (m.first_entry(t) < n_valid) return 9;
+    return 0;
 }
 
 }  // extern "C"
