@@ -468,13 +468,20 @@ def main():
     tally = threading.Lock()
     todo = iter(range(args.steps))
 
+    failures = []
+
     def issue_steps():
         nonlocal out, msm_ms, fft_ms, upload_ms
         while True:
             with tally:
-                if next(todo, None) is None:
+                if failures or next(todo, None) is None:
                     return
-            o = step()
+            try:
+                o = step()
+            except BaseException as e:          # a helper thread must not lose a step silently: the run fails below
+                with tally:
+                    failures.append(e)
+                return
             m, f, _ = prover.last_timings()
             with tally:
                 out = o
@@ -491,6 +498,8 @@ def main():
     issue_steps()
     for th in helpers:
         th.join()
+    if failures:
+        raise failures[0]
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
