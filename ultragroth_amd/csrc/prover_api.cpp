@@ -785,6 +785,7 @@ public:
             void* outs[1] = {partials + 320};
             ugCheck(ug_msm_batch_enqueue(d_.ctx2, 1, sets, d_.sh, nullptr, outs));             // S10 :154
         }
+        traceStep("device part fully queued");
         ugCheck(ug_ctx_collect(d_.ctx2));                       // the one host wait of the device part ...
         ugCheck(ug_ctx_collect(d_.ctx));                        // (... this one returns at once unless the streams overlap)
         collectTimings(3);
