@@ -767,19 +767,24 @@ public:
             collectTimings(3);
             return;
         }
+        // ULTRAGROTH_OVERLAP: 0 (default) the second stream waits for the first; 1 no edge at all; 2 the G2 product goes
+        // first and the H branch's mat-vec, NTT passes and schedule run beside it, its MSM after the witness branch -- so
+        // that no two G1 accumulation launches share the chip
         const char* ov = getenv("ULTRAGROTH_OVERLAP");
-        const bool overlap = ov && atoi(ov) != 0;
+        const int overlap = ov ? atoi(ov) : 0;
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
         buildSchedule(d_.sw, wCur_, wr_.lo, nw, tableW_);
         {   // S1-S4 (src/groth16.cpp:55,58,61,64): A, B1, B2, C over the witness schedule, queued back to back
             const ug_bases* sets[4] = {d_.A, d_.B1, d_.B2, d_.C};
             const int64_t shifts[4] = {0, 0, 0, (int64_t)hdr_.nPublic + 1};
             void* outs[4] = {partials, partials + 64, partials + 128, partials + 256};
+            if (overlap == 2) { std::swap(sets[0], sets[2]); std::swap(outs[0], outs[2]); }        // B2, B1, A, C
             ugCheck(ug_msm_batch_enqueue(d_.ctx, 4, sets, d_.sw, shifts, outs));
         }
-        if (!overlap) ugCheck(ug_ctx_wait(d_.ctx2, d_.ctx));
+        if (overlap == 0) ugCheck(ug_ctx_wait(d_.ctx2, d_.ctx));
         ugCheck(ug_hpoly_run(d_.hp, wCur_, d_.h));                                              // S5-S9 :66-148
         buildSchedule(d_.sh, d_.h, hr_.lo, nh, tableH_);
+        if (overlap == 2) ugCheck(ug_ctx_wait(d_.ctx2, d_.ctx));
         {
             const ug_bases* sets[1] = {d_.H};
             void* outs[1] = {partials + 320};
