@@ -246,6 +246,37 @@ def test_bench_two_ranks_over_rccl():
         assert line["n_gpus"] == 2 and ("bit-exact" in (line.get("check") or line["config"]["workload"]))
 
 
+def test_bench_line_contract_one_gpu():
+    """`python bench.py` as the driver runs it at N = 1 (here at 2^16 so that it takes seconds): exactly one JSON line
+    with the contract's keys, the `roofline` and `cpu_baseline` objects, K timed steps issued from two host threads,
+    `--check` bit-exact (a mismatch would make the exit code 3)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--log-domain", "16",
+                        "--cpu-sample-log", "14", "--check"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["metric"] == "proofs/s" and d["unit"] == "proofs/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] * d["ms_per_step"] - 1e3) < 1e-6 * 1e3
+    assert d["config"]["host_threads"] == 2 and d["sequential_ms_per_step"] > 0
+    rf = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rf, key
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches"] > 0
+    cb = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cb, key
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert d.get("check") == "bit-exact"
+
+
 def test_api_errors_on_device(zkey, wtns):
     import ultragroth_amd as ug
     with ug.Groth16Prover(zkey) as p:
