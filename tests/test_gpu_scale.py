@@ -687,14 +687,15 @@ def test_overlap_mode_is_bit_exact(device, monkeypatch):
     zkey, wtns, info = synth.build_circuit(device, 15, mix="U", seed=0x5EED0600)
     r, s = fixed_rs()
     exp = O.groth16_prove(zkey, wtns, int.from_bytes(r, "little"), int.from_bytes(s, "little"))
-    monkeypatch.setenv("ULTRAGROTH_OVERLAP", "1")
     with ug.Groth16Prover(zkey) as p:
-        for _ in range(3):
+        for mode in ("1", "2", "1", "0", "2"):      # 2: the G2 product first, the H branch's preparation beside it, its MSM last
+            monkeypatch.setenv("ULTRAGROTH_OVERLAP", mode)
             ug.set_test_blinding(r + s)
             try:
-                assert p.prove(wtns) == (exp[0], exp[1])
+                assert p.prove(wtns) == (exp[0], exp[1]), mode
             finally:
                 ug.set_test_blinding(b"")
+    monkeypatch.setenv("ULTRAGROTH_OVERLAP", "1")
     monkeypatch.setenv("ULTRAGROTH_TABLES", "2")
     ug.set_test_blinding(r + s)
     try:
