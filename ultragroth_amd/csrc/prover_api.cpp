@@ -638,14 +638,19 @@ public:
         traceStep("witness staged");
         std::unique_lock<std::mutex> card;
         if (device) card = std::unique_lock<std::mutex>(*device);
-        std::lock_guard<std::mutex> turn(proveMutex);
+        std::unique_lock<std::mutex> turn(proveMutex);
         traceStep("turn on the device");
         if (around) around(true);
         adopt(*lease);
-        proveLoaded(proof, pub);
+        // the turn ends with the device part: blinding and JSON of this proof run on the host while the next caller's
+        // kernels start (0.7 ms of idle device per proof otherwise)
+        proveLoaded(proof, pub, [&] {
+            totalMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (around) around(false);
+            turn.unlock();
+            if (card.owns_lock()) card.unlock();
+        });
         traceStep("proof finished");
-        totalMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (around) around(false);
     }
     // The witness in two parts, for a rank of a sharded prover: part 0 = the scalars of this rank's MSM slice (what
     // runWitnessMsm reads), part 1 = everything else (only the H-polynomial mat-vec reads it; a rank that runs no
@@ -812,19 +817,21 @@ public:
         finishWith(sums, r, s, blindingTerms(hdr_, r, s), proof, pub);
     }
     void finishWith(const uint8_t* sums, const uint8_t r[32], const uint8_t s[32], const BlindingTerms& terms, std::string& proof,
-                    std::string& pub) {
+                    std::string& pub, const std::vector<uint8_t>* publicPart = nullptr) {
         uint8_t A[64], B[128], C[64];
         blind(A, B, C, sums, sums + 64, sums + 128, sums + 256, sums + 320, hdr_, r, s, terms, nullptr);
         // nlohmann dump(): keys in lexicographic order, no whitespace (src/groth16.cpp:217-250)
         proof = "{\"pi_a\":" + g1Json(A) + ",\"pi_b\":" + g2Json(B) + ",\"pi_c\":" + g1Json(C) + ",\"protocol\":\"groth16\"}";
-        pub = publicJson(publicPart_.data(), hdr_.nPublic, 0);
+        pub = publicJson((publicPart ? *publicPart : publicPart_).data(), hdr_.nPublic, 0);
     }
 
     // (every caller comes through proveTurn, which this class overrides; kept for the interface)
     void prove(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub) override {
         proveTurn(wtns, wtnsSize, proof, pub, nullptr, Around());
     }
-    void proveLoaded(std::string& proof, std::string& pub) {
+    // deviceDone (optional) is called once the device part has left the device: nothing after it touches the prover's
+    // per-proof state (the public signals are copied first), so the caller may give up its turn there
+    void proveLoaded(std::string& proof, std::string& pub, const std::function<void()>& deviceDone = std::function<void()>()) {
         // S11 (:158-166) drawn up front, in the reference's order: the multiples of delta that need only r and s are
         // formed on host threads while the device runs S1-S10
         uint8_t r[32], s[32];
@@ -834,7 +841,9 @@ public:
         traceStep("device part queued from here");
         run(partials);                                   // (the future joins in its destructor if this throws)
         traceStep("device part done");
-        finishWith(partials, r, s, terms.get(), proof, pub);
+        const std::vector<uint8_t> publicPart = publicPart_;
+        if (deviceDone) deviceDone();
+        finishWith(partials, r, s, terms.get(), proof, pub, &publicPart);
     }
 
     unsigned long long proofBufferMinSize() const override { return PROOF_MIN_GROTH16; }
