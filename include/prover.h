@@ -28,7 +28,7 @@
  *     *_create_zkey_file, src/prover.cpp:449-473);
  *   - a prover object may be used from several host threads at once, as the reference's (whose prove
  *     allocates everything per call, src/prover.cpp:341-391): the calls take turns on the device. A
- *     Groth16 prover copies the witness of a waiting call into its second witness buffer meanwhile, so
+ *     prover (Groth16 or UltraGroth) copies the witness of a waiting call into its second witness buffer meanwhile, so
  *     two threads proving on one object hide the host-to-device copy of one proof behind the kernels of
  *     the other (2^24: 10 ms of a 150 ms proof). The ug_ phase calls of a sharded proof below are driven
  *     by one thread per object and must not be mixed with concurrent *_prove calls on the same object;

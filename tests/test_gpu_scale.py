@@ -526,6 +526,37 @@ def test_ultragroth_created_prover_with_window_tables(device):
             assert got == exp
 
 
+def test_ultragroth_prover_object_from_three_host_threads(device):
+    """ultra_groth_prover_prove from three threads on one prover object: the .uwtns of a waiting call (signals and the
+    four lookup sections) is staged into the second witness buffer while another proof runs and patches ITS copy of the
+    witness on the device; the three blinding draws of a proof happen inside its turn. Every proof == oracle."""
+    import threading
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, uwtns, info = synth.build_ultra_circuit(device, 15)
+    rk, r, s = bytes(range(1, 32)), bytes(range(40, 71)), bytes(range(80, 111))
+    exp = O.ultra_groth_prove(zkey, uwtns, int.from_bytes(rk, "little"), int.from_bytes(r, "little"), int.from_bytes(s, "little"))
+    failures = []
+    with ug.UltraGrothProver(zkey) as p:
+        def caller(k):
+            try:
+                for it in range(6):
+                    if p.prove(uwtns) != exp:
+                        failures.append("thread %d proof %d differs" % (k, it))
+            except Exception as e:                              # noqa: BLE001 (reported below)
+                failures.append("thread %d: %r" % (k, e))
+        ug.set_test_blinding(rk + r + s)
+        try:
+            threads = [threading.Thread(target=caller, args=(k,)) for k in range(3)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            ug.set_test_blinding(b"")
+    assert not failures, failures
+
+
 def test_ranges_above_the_schedule_limit_are_proved_in_pieces(device, monkeypatch):
     """a schedule holds at most 2^26 scalars, so the reference's largest legal domain (2^27) is proved in pieces whose
     partial sums are added; ULTRAGROTH_MAX_RANGE lowers the limit so that a 2^13 circuit takes that path (7 pieces)"""

@@ -215,6 +215,72 @@ struct DeviceProver {
     }
 };
 
+// ---- two witness buffers per prover: the next call's witness is staged while a proof runs -----------------------------
+// A buffer is leased from the moment a host thread starts to fill it until the proof that reads it has left the device.
+// The second buffer (nVars * 32 bytes) is allocated the first time two calls overlap; if that fails the calls simply take
+// turns on the first. Lock order everywhere: witness lease -> stageMutex (released again) -> the card's lock -> proveMutex.
+struct StagedWitness {
+    ug_dvec* buf = nullptr; bool leased = false;
+    std::vector<uint8_t> publicPart; double uploadMs = 0;
+    std::vector<uint32_t> chunks, freq, wIdx, pIdx;            // UltraGroth: uwtns sections 3-6
+};
+class WitnessBuffers {
+public:
+    // first / second: the two owners in the prover's DeviceProver (w, w2); *first holds the buffer made at create
+    void attach(ug_ctx* ctx, uint64_t n, ug_dvec** first, ug_dvec** second) {
+        ctx_ = ctx; n_ = n; own_[0] = first; own_[1] = second; slots_[0].buf = *first;
+    }
+    int lease() {
+        std::unique_lock<std::mutex> lk(mutex_);
+        for (;;) {
+            for (int k = 0; k < 2; k++) {
+                StagedWitness& sl = slots_[k];
+                if (sl.leased) continue;
+                if (!sl.buf) {
+                    if (allocFailed_) continue;
+                    if (ug_dvec_create(ctx_, n_, &sl.buf) != UG_OK) { sl.buf = nullptr; allocFailed_ = true; continue; }
+                    (*own_[0] ? *own_[1] : *own_[0]) = sl.buf;            // (the owner that is free)
+                }
+                sl.leased = true;
+                return k;
+            }
+            free_.wait(lk);
+        }
+    }
+    void release(int k) {
+        { std::lock_guard<std::mutex> lk(mutex_); slots_[k].leased = false; }
+        free_.notify_all();
+    }
+    StagedWitness& operator[](int k) { return slots_[k]; }
+    // the buffer that is neither the current one nor being filled goes (it comes back with the next overlap); the caller
+    // holds the prover's proveMutex
+    void trim(const ug_dvec* current) {
+        std::lock_guard<std::mutex> lk(mutex_);
+        for (StagedWitness& sl : slots_) {
+            if (!sl.buf || sl.leased || sl.buf == current) continue;
+            if (*own_[0] == sl.buf) { *own_[0] = *own_[1]; *own_[1] = nullptr; } else if (*own_[1] == sl.buf) *own_[1] = nullptr;
+            ug_dvec_destroy(sl.buf);
+            sl.buf = nullptr;
+            allocFailed_ = false;
+        }
+    }
+    std::mutex stageMutex;          // one staging copy at a time (the uploader is the context's)
+private:
+    ug_ctx* ctx_ = nullptr; uint64_t n_ = 0; ug_dvec** own_[2] = {nullptr, nullptr};
+    StagedWitness slots_[2];
+    std::mutex mutex_;
+    std::condition_variable free_;
+    bool allocFailed_ = false;
+};
+struct WitnessLease {
+    WitnessBuffers& b; int slot;
+    explicit WitnessLease(WitnessBuffers& b_) : b(b_), slot(b_.lease()) {}
+    ~WitnessLease() { b.release(slot); }
+    WitnessLease(const WitnessLease&) = delete;
+    WitnessLease& operator=(const WitnessLease&) = delete;
+    StagedWitness& operator*() { return b[slot]; }
+};
+
 // ---- fixed-base window tables ---------------------------------------------------------------------------------
 // A zkey's points never change between proofs, so a created prover may trade HBM for work: with tables 2^(c j) P_i
 // every window digit of an MSM lands in one bucket set (ultragroth_hip.h: ug_bases_precompute). A group is the base
@@ -515,7 +581,7 @@ private:
         if (haveHpoly_) ugCheck(ug_hpoly_create(d_.ctx2, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
         ugCheck(ug_dvec_create(d_.ctx, M, &d_.w));
         wCur_ = d_.w;
-        slots_[0].buf = d_.w;
+        witness_.attach(d_.ctx, M, &d_.w, &d_.w2);
         ugCheck(ug_dvec_create(d_.ctx2, N, &d_.h));
         ugCheck(ug_schedule_create(d_.ctx, &d_.sw));
         ugCheck(ug_schedule_create(d_.ctx2, &d_.sh));
@@ -539,15 +605,7 @@ public:
         std::lock_guard<std::mutex> turn(proveMutex);
         ug_schedule_trim(d_.sw); ug_schedule_trim(d_.sh);
         ug_ctx_trim(d_.ctx); ug_ctx_trim(d_.ctx2);
-        // the witness buffer that is neither the current one nor being filled goes too (it comes back with the next overlap)
-        std::lock_guard<std::mutex> lk(slotMutex_);
-        for (WitnessSlot& sl : slots_) {
-            if (!sl.buf || sl.leased || sl.buf == wCur_) continue;
-            if (d_.w == sl.buf) { d_.w = d_.w2; d_.w2 = nullptr; } else if (d_.w2 == sl.buf) d_.w2 = nullptr;
-            ug_dvec_destroy(sl.buf);
-            sl.buf = nullptr;
-            secondBufferFailed_ = false;
-        }
+        witness_.trim(wCur_);
     }
 
     const ZkeyHeader& header() const { return hdr_; }
@@ -563,47 +621,15 @@ public:
     }
     // phase call (the caller drives the phases of one proof from one thread and holds no lock): staged like a proof's
     void loadWitness(const void* wtns, unsigned long long wtnsSize) override {
-        WitnessLease lease(*this);
+        WitnessLease lease(witness_);
         stage(*lease, wtns, wtnsSize);
         std::lock_guard<std::mutex> turn(proveMutex);
         adopt(*lease);
     }
-
-    // ---- two witness buffers: the next proof's witness is staged while a proof runs ------------------------------------
-    // A buffer is leased from the moment a host thread starts to fill it until the proof that reads it has left the device.
-    // The second buffer (nVars * 32 bytes) is allocated the first time two calls overlap; if that fails the calls simply
-    // take turns on the first.
-    struct WitnessSlot { ug_dvec* buf = nullptr; bool leased = false; std::vector<uint8_t> publicPart; double uploadMs = 0; };
-    struct WitnessLease {
-        Groth16Prover& p; int slot;
-        explicit WitnessLease(Groth16Prover& p_) : p(p_), slot(p_.leaseSlot()) {}
-        ~WitnessLease() {
-            { std::lock_guard<std::mutex> lk(p.slotMutex_); p.slots_[slot].leased = false; }
-            p.slotFree_.notify_all();
-        }
-        WitnessSlot& operator*() { return p.slots_[slot]; }
-    };
-    int leaseSlot() {
-        std::unique_lock<std::mutex> lk(slotMutex_);
-        for (;;) {
-            for (int k = 0; k < 2; k++) {
-                WitnessSlot& sl = slots_[k];
-                if (sl.leased) continue;
-                if (!sl.buf) {
-                    if (secondBufferFailed_) continue;
-                    if (ug_dvec_create(d_.ctx, hdr_.nVars, &sl.buf) != UG_OK) { sl.buf = nullptr; secondBufferFailed_ = true; continue; }
-                    (d_.w ? d_.w2 : d_.w) = sl.buf;            // (the owner that is free)
-                }
-                sl.leased = true;
-                return k;
-            }
-            slotFree_.wait(lk);
-        }
-    }
     // staging: parse the .wtns and copy the witness into the leased buffer; needs no turn on the device, only the
     // uploader (one copy at a time)
-    void stage(WitnessSlot& sl, const void* wtns, unsigned long long wtnsSize) {
-        std::lock_guard<std::mutex> st(stageMutex_);
+    void stage(StagedWitness& sl, const void* wtns, unsigned long long wtnsSize) {
+        std::lock_guard<std::mutex> st(witness_.stageMutex);
         auto u0 = std::chrono::steady_clock::now();
         BinFile f(wtns, wtnsSize, "wtns", 2);
         const uint8_t* data = witnessData(f);
@@ -612,14 +638,13 @@ public:
         sl.uploadMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - u0).count();
     }
     // the staged witness becomes the prover's (proveMutex held)
-    void adopt(WitnessSlot& sl) {
+    void adopt(StagedWitness& sl) {
         wCur_ = sl.buf;
         publicPart_.swap(sl.publicPart);
         uploadMs = sl.uploadMs;
         resetTimings();
         witnessLoaded_ = true; witnessComplete_ = true;
     }
-    // lock order everywhere: witness lease -> stageMutex_ (released again) -> the card's lock -> proveMutex
     // ULTRAGROTH_TRACE=1: when each step of a call happens, in ms of a process-wide clock, on stderr (two callers' lines
     // interleave: how long the device waits between one proof's last kernel and the next one's first)
     static void traceStep(const char* what) {
@@ -633,7 +658,7 @@ public:
                    const Around& around) override {
         auto t0 = std::chrono::steady_clock::now();
         traceStep("call");
-        WitnessLease lease(*this);
+        WitnessLease lease(witness_);
         stage(*lease, wtns, wtnsSize);
         traceStep("witness staged");
         std::unique_lock<std::mutex> card;
@@ -867,10 +892,7 @@ private:
     DeviceProver d_;
     bool witnessLoaded_ = false, witnessComplete_ = false, haveHpoly_ = true;
     ug_dvec* wCur_ = nullptr;          // the witness the device part reads: one of the two buffers (d_.w, d_.w2 own them)
-    WitnessSlot slots_[2];
-    std::mutex slotMutex_, stageMutex_;
-    std::condition_variable slotFree_;
-    bool secondBufferFailed_ = false;
+    WitnessBuffers witness_;
     double m1_ = 0, f1_ = 0, m2_ = 0, f2_ = 0, totalMs_ = 0;      // device ms of the MSM / FFT parts per stream
 };
 
@@ -920,6 +942,8 @@ public:
         ugCheck(ug_bases_create_g1(d_.ctx, pH + hr_.lo * 64, hr_.hi - hr_.lo, hr_.lo, &d_.H));
         ugCheck(ug_hpoly_create(d_.ctx, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
         ugCheck(ug_dvec_create(d_.ctx, M, &d_.w));
+        wCur_ = d_.w;
+        witness_.attach(d_.ctx, M, &d_.w, &d_.w2);
         ugCheck(ug_dvec_create(d_.ctx, N, &d_.h));
         uint64_t auxN = std::max<uint64_t>(roundIdx_.size(), finalIdx_.size());
         ugCheck(ug_dvec_create(d_.ctx, auxN ? auxN : 1, &d_.aux));
@@ -946,12 +970,15 @@ public:
         std::lock_guard<std::mutex> turn(proveMutex);
         ug_schedule_trim(d_.sw); ug_schedule_trim(d_.sh); ug_schedule_trim(d_.saux);
         ug_ctx_trim(d_.ctx);
+        witness_.trim(wCur_);
     }
 
     const ZkeyHeader& header() const { return hdr_; }
 
-    // ---- phases (a sharded proof calls them one by one, see include/prover.h; prove() below strings them together) ----
-    void loadWitness(const void* wtns, unsigned long long wtnsSize) override {
+    // Staging: parse the .uwtns and copy the signals into the leased buffer -- no turn on the device needed, so the witness
+    // of a waiting call is copied while another proof runs (as Groth16Prover::proveTurn).
+    void stage(StagedWitness& sl, const void* wtns, unsigned long long wtnsSize) {
+        std::lock_guard<std::mutex> st(witness_.stageMutex);
         auto tLoad0 = std::chrono::steady_clock::now();
         BinFile f(wtns, wtnsSize, "wtns", 2);
         WtnsHeader wh = loadWtnsHeader(f);
@@ -967,21 +994,36 @@ public:
             memcpy(v.data(), f.sectionData(id), v.size() * 4);
             return v;
         };
-        chunks_ = u32Section(3); freq_ = u32Section(4); wIdx_ = u32Section(5); pIdx_ = u32Section(6);
-        if (wIdx_.size() != pIdx_.size()) throw std::range_error("uwtns: wtns_indxs and push_indxs differ in length");
-        publicPart_.assign(signals0, signals0 + ((size_t)hdr_.nPublic + 1) * 32);
-        mark("parse uwtns");
+        sl.chunks = u32Section(3); sl.freq = u32Section(4); sl.wIdx = u32Section(5); sl.pIdx = u32Section(6);
+        if (sl.wIdx.size() != sl.pIdx.size()) throw std::range_error("uwtns: wtns_indxs and push_indxs differ in length");
+        sl.publicPart.assign(signals0, signals0 + ((size_t)hdr_.nPublic + 1) * 32);
+        ugCheck(ug_dvec_upload_idle(sl.buf, signals0, M));
+        sl.uploadMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tLoad0).count();
+    }
+    // the staged witness becomes the prover's (proveMutex held)
+    void adopt(StagedWitness& sl) {
+        wCur_ = sl.buf;
+        chunks_.swap(sl.chunks); freq_.swap(sl.freq); wIdx_.swap(sl.wIdx); pIdx_.swap(sl.pIdx);
+        publicPart_.swap(sl.publicPart);
+        uploadMs = sl.uploadMs;
         ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1));
-        ugCheck(ug_dvec_upload(d_.w, signals0, M));
-        mark("witness upload");
         witnessLoaded_ = true; committed_ = false; haveRoundScalar_ = false;
-        uploadMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tLoad0).count();
+        if (trace_) fprintf(stderr, "[ultragroth] %-28s %8.3f ms\n", "parse uwtns + witness upload", uploadMs);
+        tPhase_ = std::chrono::steady_clock::now();
+    }
+    // ---- phases (a sharded proof calls them one by one, see include/prover.h; proveTurn() below strings them together) ----
+    // (the caller drives the phases of one proof from one thread and holds no lock)
+    void loadWitness(const void* wtns, unsigned long long wtnsSize) override {
+        WitnessLease lease(witness_);
+        stage(*lease, wtns, wtnsSize);
+        std::lock_guard<std::mutex> turn(proveMutex);
+        adopt(*lease);
     }
 
     // round 1: this rank's part of the commitment to the round witnesses (ultra_groth.cpp:415-419, execute_round :161-184)
     void roundCommit(uint8_t* out64) override {
         if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
-        ugCheck(ug_dvec_gather_index(d_.aux, d_.w, d_.roundIdx));
+        ugCheck(ug_dvec_gather_index(d_.aux, wCur_, d_.roundIdx));
         mark("round gather");
         buildSchedule(d_.saux, d_.aux, 0, roundIdx_.size(), tableC1_);
         ugCheck(ug_msm_g1(d_.ctx, d_.roundC, d_.saux, 0, out64));
@@ -1023,14 +1065,14 @@ public:
     void runWitnessMsm(uint8_t* partials, bool = true) override {
         if (!committed_) throw std::invalid_argument("the round commitment has not been applied");
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
-        buildSchedule(d_.sw, d_.w, wr_.lo, wr_.hi - wr_.lo, tableW_);
+        buildSchedule(d_.sw, wCur_, wr_.lo, wr_.hi - wr_.lo, tableW_);
         {                                                                                   // MSM1-3 :201,214,227
             const ug_bases* sets[3] = {d_.A, d_.B1, d_.B2};
             void* outs[3] = {partials, partials + 64, partials + 128};
             ugCheck(ug_msm_batch(d_.ctx, 3, sets, d_.sw, nullptr, outs));
         }
         mark("A, B1, B2 MSMs");
-        ugCheck(ug_dvec_gather_index(d_.aux, d_.w, d_.finalIdx));                           // :439-445
+        ugCheck(ug_dvec_gather_index(d_.aux, wCur_, d_.finalIdx));                           // :439-445
         mark("final gather");
         buildSchedule(d_.saux, d_.aux, 0, finalIdx_.size(), tableC2_);
         ugCheck(ug_msm_g1(d_.ctx, d_.C, d_.saux, 0, partials + 256));                       // MSM4 :234
@@ -1040,7 +1082,7 @@ public:
         if (!committed_) throw std::invalid_argument("the round commitment has not been applied");
         ug_dvec* v = nullptr;
         ugCheck(ug_dvec_wrap(d_.ctx, deviceOut, hdr_.domainSize, &v));
-        int rc = ug_hpoly_chain(d_.hp, d_.w, which, v);
+        int rc = ug_hpoly_chain(d_.hp, wCur_, which, v);
         ug_dvec_destroy(v);
         ugCheck(rc);
     }
@@ -1095,12 +1137,22 @@ public:
         mark("blinding + JSON");
     }
 
+    // (every caller comes through proveTurn, which this class overrides; kept for the interface)
     void prove(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub) override {
+        proveTurn(wtns, wtnsSize, proof, pub, nullptr, Around());
+    }
+    void proveTurn(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub, std::mutex* device,
+                   const Around& around) override {
         auto t0 = std::chrono::steady_clock::now();
+        WitnessLease lease(witness_);
+        stage(*lease, wtns, wtnsSize);
+        std::unique_lock<std::mutex> card;
+        if (device) card = std::unique_lock<std::mutex>(*device);
+        std::lock_guard<std::mutex> turn(proveMutex);
+        if (around) around(true);
         // ULTRAGROTH_TRACE=1: host wall-clock per phase on stderr (where the non-MSM, non-FFT time of a proof goes)
         trace_ = getenv("ULTRAGROTH_TRACE") && atoi(getenv("ULTRAGROTH_TRACE")) != 0;
-        tPhase_ = std::chrono::steady_clock::now();
-        loadWitness(wtns, wtnsSize);
+        adopt(*lease);
         uint8_t part[64], commit[64];
         roundCommit(part);
         roundFinish(part, commit);
@@ -1115,7 +1167,7 @@ public:
         if (trace_) {                                    // phase by phase, with a host wait (and a line on stderr) after each
             uint8_t hpart[UG_GROTH16_PARTIALS_SIZE];
             runWitnessMsm(sums);
-            ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));                                       // FFT block :243-320
+            ugCheck(ug_hpoly_run(d_.hp, wCur_, d_.h));                                       // FFT block :243-320
             mark("H polynomial");
             runHMsm(hpart);
             memcpy(sums + 320, hpart + 320, 64);
@@ -1123,16 +1175,16 @@ public:
             // the whole final round queued on the stream, ONE host wait: MSM1-3 (:201,214,227), the gather of the final
             // witnesses (:439-445) and MSM4 (:234), the FFT block (:243-320), MSM5 (:322)
             memset(sums, 0, sizeof sums);
-            buildSchedule(d_.sw, d_.w, wr_.lo, wr_.hi - wr_.lo, tableW_);
+            buildSchedule(d_.sw, wCur_, wr_.lo, wr_.hi - wr_.lo, tableW_);
             const ug_bases* sets[3] = {d_.A, d_.B1, d_.B2};
             void* outs[3] = {sums, sums + 64, sums + 128};
             ugCheck(ug_msm_batch_enqueue(d_.ctx, 3, sets, d_.sw, nullptr, outs));
-            ugCheck(ug_dvec_gather_index(d_.aux, d_.w, d_.finalIdx));
+            ugCheck(ug_dvec_gather_index(d_.aux, wCur_, d_.finalIdx));
             buildSchedule(d_.saux, d_.aux, 0, finalIdx_.size(), tableC2_);
             const ug_bases* setC[1] = {d_.C};
             void* outC[1] = {sums + 256};
             ugCheck(ug_msm_batch_enqueue(d_.ctx, 1, setC, d_.saux, nullptr, outC));
-            ugCheck(ug_hpoly_run(d_.hp, d_.w, d_.h));
+            ugCheck(ug_hpoly_run(d_.hp, wCur_, d_.h));
             buildSchedule(d_.sh, d_.h, hr_.lo, hr_.hi - hr_.lo, tableH_);
             const ug_bases* setH[1] = {d_.H};
             void* outH[1] = {sums + 320};
@@ -1142,6 +1194,7 @@ public:
         }
         finishWith(sums, r, s, terms.get(), proof, pub);
         totalMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (around) around(false);
     }
 
     unsigned long long proofBufferMinSize() const override { return PROOF_MIN_ULTRA; }
@@ -1167,7 +1220,7 @@ private:
         uint8_t randPlain[32];
         putPlain(randPlain, rand);
         ugCheck(ug_fr_lookup_table(d_.ctx, randPlain, freq.data(), L, table.data()));     // one lane per row on the device
-        ugCheck(ug_dvec_apply_lookup(d_.w, wIdx.data(), pIdx.data(), wIdx.size(), chunks.data(), Cn, table.data(), L));
+        ugCheck(ug_dvec_apply_lookup(wCur_, wIdx.data(), pIdx.data(), wIdx.size(), chunks.data(), Cn, table.data(), L));
         // the same writes for the public signals, in order (a later write overwrites an earlier one)
         for (size_t i = 0; i < wIdx.size(); i++) {
             if (wIdx[i] > hdr_.nPublic) continue;
@@ -1188,6 +1241,8 @@ private:
     }
     std::vector<uint32_t> roundIdx_, finalIdx_;                    // this rank's slices of the zkey's two index lists
     std::vector<uint32_t> chunks_, freq_, wIdx_, pIdx_;            // uwtns sections 3-6 of the loaded witness
+    ug_dvec* wCur_ = nullptr;                                      // the witness the device part reads and patches (d_.w, d_.w2 own the two buffers)
+    WitnessBuffers witness_;
     std::vector<uint8_t> publicPart_;                              // signals 0..nPublic, patched by the lookup writes
     Range wr_{0, 0}, hr_{0, 0};
     uint8_t commitRec_[64] = {0};
