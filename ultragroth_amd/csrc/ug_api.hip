@@ -123,6 +123,17 @@ struct ug_ctx {
     hipEvent_t order_event = nullptr;      // ug_ctx_wait
     NttPlan raw_ntt;                       // cache for ug_fr_ntt
     u32* lookup_last = nullptr; u64 lookup_last_n = 0;   // zeroed scratch of ug_dvec_apply_lookup
+    u32* lookup_stage = nullptr; size_t lookup_stage_bytes = 0;   // staging of the lookup calls (kept: two allocations and
+                                                                  // two frees -- each a device-wide wait -- per proof otherwise)
+    u32* stage_for_lookup(size_t bytes) {
+        if (bytes > lookup_stage_bytes) {
+            if (lookup_stage) hipFree(lookup_stage);
+            lookup_stage = nullptr; lookup_stage_bytes = 0;
+            UG_HIP(hipMalloc(&lookup_stage, bytes));
+            lookup_stage_bytes = bytes;
+        }
+        return lookup_stage;
+    }
     u32* pinned_results = nullptr;         // MsmStats::SLOTS result blocks of queued MSMs (ug_msm_batch)
     void use() const { UG_HIP(hipSetDevice(device)); }
 };
@@ -237,6 +248,7 @@ void ug_ctx_destroy(ug_ctx* c) {
     hipStreamSynchronize(c->stream);
     c->ws_g1.release(); c->ws_g2.release(); c->raw_ntt.release(); c->uploader.release();
     if (c->lookup_last) hipFree(c->lookup_last);
+    if (c->lookup_stage) hipFree(c->lookup_stage);
     for (auto& sp : c->spans_free) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
     for (auto& sp : c->spans_pending) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
     if (c->order_event) hipEventDestroy(c->order_event);
@@ -364,6 +376,7 @@ int ug_ctx_trim(ug_ctx* c) {
     UG_HIP(hipStreamSynchronize(c->stream));
     c->ws_g1.release(); c->ws_g2.release(); c->raw_ntt.release();
     if (c->lookup_last) { hipFree(c->lookup_last); c->lookup_last = nullptr; c->lookup_last_n = 0; }
+    if (c->lookup_stage) { hipFree(c->lookup_stage); c->lookup_stage = nullptr; c->lookup_stage_bytes = 0; }
     UG_CATCH
 }
 int ug_ctx_mem_info(ug_ctx* c, uint64_t* free_bytes, uint64_t* total_bytes) {
@@ -509,8 +522,7 @@ int ug_dvec_apply_lookup(ug_dvec* dst, const uint32_t* w_idx, const uint32_t* p_
     }
     // one staging allocation: w_idx | p_idx | chunks | table
     const size_t tbytes = (size_t)(1 + 2 * lookup_size) * 32;
-    u32* stage = nullptr;
-    UG_HIP(hipMalloc(&stage, (size_t)(2 * n + n_chunks) * 4 + tbytes));
+    u32* stage = c->stage_for_lookup((size_t)(2 * n + n_chunks) * 4 + tbytes);
     u32 *d_w = stage, *d_p = stage + n, *d_c = stage + 2 * n, *d_t = stage + 2 * n + n_chunks;
     UG_HIP(hipMemcpyAsync(d_w, w_idx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     UG_HIP(hipMemcpyAsync(d_p, p_idx, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
@@ -518,7 +530,6 @@ int ug_dvec_apply_lookup(ug_dvec* dst, const uint32_t* w_idx, const uint32_t* p_
     UG_HIP(hipMemcpyAsync(d_t, table, tbytes, hipMemcpyHostToDevice, c->stream));
     apply_lookup(dst->data, c->lookup_last, d_w, d_p, n, d_c, n_chunks, d_t, c->stream);
     UG_HIP(hipStreamSynchronize(c->stream));
-    hipFree(stage);
     UG_CATCH
 }
 int ug_fr_lookup_table(ug_ctx* c, const void* rand_plain, const uint32_t* frequencies, uint64_t lookup_size, void* table_out) {
@@ -526,17 +537,13 @@ int ug_fr_lookup_table(ug_ctx* c, const void* rand_plain, const uint32_t* freque
     if (!c || !rand_plain || (!frequencies && lookup_size) || !table_out) throw std::invalid_argument("null argument");
     c->use();
     const size_t tbytes = (size_t)(1 + 2 * lookup_size) * 32;
-    u32 *table = nullptr, *freq = nullptr;
-    UG_HIP(hipMalloc(&table, tbytes));
-    UG_HIP(hipMalloc(&freq, lookup_size ? (size_t)lookup_size * 4 : 4));
-    try {
-        UG_HIP(hipMemcpyAsync(table, rand_plain, 32, hipMemcpyHostToDevice, c->stream));
-        if (lookup_size) UG_HIP(hipMemcpyAsync(freq, frequencies, (size_t)lookup_size * 4, hipMemcpyHostToDevice, c->stream));
-        lookup_table(table, freq, lookup_size, c->stream);
-        UG_HIP(hipMemcpyAsync(table_out, table, tbytes, hipMemcpyDeviceToHost, c->stream));
-        UG_HIP(hipStreamSynchronize(c->stream));
-    } catch (...) { hipFree(table); hipFree(freq); throw; }
-    hipFree(table); hipFree(freq);
+    u32* table = c->stage_for_lookup(tbytes + (lookup_size ? (size_t)lookup_size * 4 : 4));
+    u32* freq = table + tbytes / 4;
+    UG_HIP(hipMemcpyAsync(table, rand_plain, 32, hipMemcpyHostToDevice, c->stream));
+    if (lookup_size) UG_HIP(hipMemcpyAsync(freq, frequencies, (size_t)lookup_size * 4, hipMemcpyHostToDevice, c->stream));
+    lookup_table(table, freq, lookup_size, c->stream);
+    UG_HIP(hipMemcpyAsync(table_out, table, tbytes, hipMemcpyDeviceToHost, c->stream));
+    UG_HIP(hipStreamSynchronize(c->stream));
     UG_CATCH
 }
 uint64_t ug_dvec_size(const ug_dvec* v) { return v ? v->n : 0; }
