@@ -91,7 +91,7 @@ struct MsmWorkspace {
     u32* slot_pts = nullptr;     // two partial sums per segment of the accumulation
     u32* task_pts = nullptr;     // partial sums of the heavy-bucket tasks
     size_t bucket_bytes = 0, chunk_bytes = 0, slot_bytes = 0, task_bytes = 0;
-    void reserve(const MsmGeometry& g, bool g2, u64 n_segments, u32 n_heavy_tasks);
+    void reserve(const MsmGeometry& g, bool g2, u64 n_segments, u32 n_heavy_tasks, int sets = 1);
     void release();
     ~MsmWorkspace() { release(); }
 };
@@ -126,6 +126,12 @@ MsmPending msm_enqueue_g1(const MsmSchedule& s, MsmWorkspace& ws, const u32* bas
                           MsmStats* stats, u32* pinned_host);
 MsmPending msm_enqueue_g2(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta, hipStream_t stream,
                           MsmStats* stats, u32* pinned_host);
+// up to MSM_BATCH_MAX products over one schedule: one accumulation launch each, the latency-bound tail kernels once for all
+constexpr int MSM_BATCH_MAX = 4;
+void msm_enqueue_batch_g1(const MsmSchedule& s, MsmWorkspace& ws, int count, const u32* const* bases, const u64* n_bases, const int64_t* delta,
+                          hipStream_t stream, MsmStats* stats, u32* const* pinned_host, MsmPending* pend);
+void msm_enqueue_batch_g2(const MsmSchedule& s, MsmWorkspace& ws, int count, const u32* const* bases, const u64* n_bases, const int64_t* delta,
+                          hipStream_t stream, MsmStats* stats, u32* const* pinned_host, MsmPending* pend);
 G1XYZZ msm_collect_g1(const MsmPending& p);
 G2XYZZ msm_collect_g2(const MsmPending& p);
 

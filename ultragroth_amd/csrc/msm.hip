@@ -369,9 +369,11 @@ __device__ __forceinline__ XYZZ<typename Cfg::F> load_piece(const u32* slot_pts,
 template <class Cfg>
 __global__ __launch_bounds__(128) void bucket_fixup_kernel(const u32* __restrict__ small_list, const u32* __restrict__ meta,
                                                            const u32* __restrict__ start, const u32* __restrict__ count, int log_a, int log_b,
-                                                           const u32* __restrict__ slot_pts, u32* __restrict__ bucket_pts) {
+                                                           const u32* __restrict__ slot_pts, u32* __restrict__ bucket_pts,
+                                                           size_t slot_stride, size_t bucket_stride) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= meta[4]) return;
+    slot_pts += blockIdx.y * slot_stride; bucket_pts += blockIdx.y * bucket_stride;      // blockIdx.y: which product of the batch
     typedef typename Cfg::F F;
     const u32 b = small_list[t];
     const u32 st = start[b];
@@ -399,8 +401,10 @@ __device__ __forceinline__ XYZZ<typename Cfg::F> block_reduce(XYZZ<typename Cfg:
 // Medium buckets (FIX_MAX < pieces <= MEDIUM_MAX; the short top window of uniform scalars makes thousands of
 // them): one wave per bucket, lanes stride over the pieces, then a 6-step cross-lane butterfly of full additions.
 template <class Cfg>
-__global__ __launch_bounds__(256) void medium_bucket_kernel(const HeavyBucket* mb, const u32* meta, u32 cap, const u32* slot_pts, u32* bucket_pts) {
+__global__ __launch_bounds__(256) void medium_bucket_kernel(const HeavyBucket* mb, const u32* meta, u32 cap, const u32* slot_pts, u32* bucket_pts,
+                                                            size_t slot_stride, size_t bucket_stride) {
     typedef typename Cfg::F F;
+    slot_pts += blockIdx.y * slot_stride; bucket_pts += blockIdx.y * bucket_stride;
     const u32 lane = threadIdx.x & 63, n_waves = (gridDim.x * blockDim.x) >> 6;
     const u32 n_medium = meta[3] < cap ? meta[3] : cap;
     // the waves stride over the list: the host knows only an upper bound of its length (tens of thousands at 2^24, where
@@ -451,9 +455,10 @@ __global__ __launch_bounds__(1024) void heavy_plan_kernel(const HeavyBucket* hb,
 
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::BLOCK) void heavy_partial_kernel(const HeavyBucket* hb, const u32* offsets, const u32* meta, u32 cap,
-                                                                   const u32* slot_pts, u32* task_pts) {
+                                                                   const u32* slot_pts, u32* task_pts, size_t slot_stride, size_t task_stride) {
     __shared__ u32 lds[Cfg::PT_WORDS * Cfg::BLOCK / 2];
     typedef typename Cfg::F F;
+    slot_pts += blockIdx.y * slot_stride; task_pts += blockIdx.y * task_stride;
     const u32 task = blockIdx.x;
     const u32 n_heavy = meta[0] < cap ? meta[0] : cap;
     if (task >= meta[2]) return;                       // (uniform per workgroup: the grid is an upper bound)
@@ -470,9 +475,10 @@ __global__ __launch_bounds__(Cfg::BLOCK) void heavy_partial_kernel(const HeavyBu
 
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::BLOCK) void heavy_final_kernel(const HeavyBucket* hb, const u32* offsets, const u32* meta, u32 cap,
-                                                                 const u32* task_pts, u32* bucket_pts) {
+                                                                 const u32* task_pts, u32* bucket_pts, size_t task_stride, size_t bucket_stride) {
     __shared__ u32 lds[Cfg::PT_WORDS * Cfg::BLOCK / 2];
     typedef typename Cfg::F F;
+    task_pts += blockIdx.y * task_stride; bucket_pts += blockIdx.y * bucket_stride;
     if (blockIdx.x >= (meta[0] < cap ? meta[0] : cap)) return;
     HeavyBucket h = hb[blockIdx.x];
     u32 t0 = offsets[blockIdx.x], t1 = offsets[blockIdx.x + 1];
@@ -485,18 +491,21 @@ __global__ __launch_bounds__(Cfg::BLOCK) void heavy_final_kernel(const HeavyBuck
 // ---- 5. bucket reduction --------------------------------------------------------------------------------
 // thread = (window, chunk of `chunk` buckets): P = sum_k (k_global + 1) * bucket_k over the chunk
 template <class Cfg>
+// (w counts the bucket sets of ALL products of a batch, one after the other in `buckets`; the entry counts belong to the
+// schedule, which the products share: bucket set w of any product has the counts of set w mod windows)
 __global__ __launch_bounds__(128) void bucket_chunk_reduce_kernel(const u32* buckets, const u32* count, u32 per_window, int chunk,
-                                                                  u32 nchunks_total, int scalar_bits, u32* out) {
+                                                                  u32 nchunks_total, int scalar_bits, u32* out, u32 windows) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nchunks_total) return;
     typedef typename Cfg::F F;
     u32 chunks_per_window = per_window / chunk;
     u32 w = t / chunks_per_window, j = t % chunks_per_window;
     const size_t b0 = (size_t)w * per_window + (size_t)j * chunk;
+    const size_t c0 = (size_t)(w % windows) * per_window + (size_t)j * chunk;
     const u32* base = buckets + b0 * Cfg::PT_WORDS;
     XYZZ<F> run = xyzz_inf<F>(), acc = xyzz_inf<F>();
     for (int k = chunk - 1; k >= 0; k--) {
-        if (count[b0 + k]) run = xyzz_add(run, Cfg::from_words(base + (size_t)k * Cfg::PT_WORDS, 1));   // empty bucket = infinity
+        if (count[c0 + k]) run = xyzz_add(run, Cfg::from_words(base + (size_t)k * Cfg::PT_WORDS, 1));   // empty bucket = infinity
         acc = xyzz_add(acc, run);
     }
     u32 off = j * (u32)chunk;                  // weight offset of the chunk
@@ -627,9 +636,14 @@ __global__ __launch_bounds__(128) void synth_points_kernel(const u32* table, u64
 
 // buckets per thread of the reduction: a single lane's chain of dependent EC additions runs at ~5 us each, so the
 // kernel is latency-bound below ~2 waves/SIMD: halve the chunk (down to 8) until there are 2^17 threads
-int reduce_chunk(const MsmGeometry& g) {
+// (sets: the products of a batch are reduced together, so their chunks add up: three products over 2^21 buckets keep 32-bucket
+// chunks, i.e. half the per-chunk scalar multiples -- which are half of this kernel's work -- of a single product)
+int reduce_chunk(const MsmGeometry& g, int sets = 1, bool g2 = false) {
+    static const int g2_log = getenv("UG_REDUCE_G2_LOG") ? atoi(getenv("UG_REDUCE_G2_LOG")) : 16;      // tuning knobs
+    static const int g1_log = getenv("UG_REDUCE_G1_LOG") ? atoi(getenv("UG_REDUCE_G1_LOG")) : 17;
+    const u64 lanes = (u64)1 << (g2 ? g2_log : g1_log);
     int chunk = g.buckets < (u32)CHUNK ? (int)g.buckets : CHUNK;
-    while (chunk > 8 && (u64)g.bucket_windows() * (g.buckets / chunk) < ((u64)1 << 17)) chunk >>= 1;
+    while (chunk > 8 && (u64)sets * g.bucket_windows() * (g.buckets / chunk) < lanes) chunk >>= 1;
     return chunk;
 }
 
@@ -791,8 +805,8 @@ void MsmSchedule::release() {
 }
 
 // ---- workspace ------------------------------------------------------------------------------------------------
-void MsmWorkspace::reserve(const MsmGeometry& g, bool g2, u64 n_segments, u32 n_heavy_tasks) {
-    size_t ptw = g2 ? G2Cfg::PT_WORDS : G1Cfg::PT_WORDS;
+void MsmWorkspace::reserve(const MsmGeometry& g, bool g2, u64 n_segments, u32 n_heavy_tasks, int sets) {
+    size_t ptw = (size_t)(g2 ? G2Cfg::PT_WORDS : G1Cfg::PT_WORDS) * (size_t)sets;      // the products of a batch lie one after the other
     size_t need = (size_t)g.total_buckets() * ptw * 4;
     if (need > bucket_bytes) { dev_alloc(bucket_pts, need); bucket_bytes = need; }
     int chunk = reduce_chunk(g);
@@ -810,17 +824,32 @@ void MsmWorkspace::release() {
 
 // ---- driver -------------------------------------------------------------------------------------------------------
 namespace {
+// A batch of products over ONE schedule (A, B1 and C of a Groth16 proof share the witness schedule): the accumulation kernel is
+// launched once per product, each into its own bucket and slot arrays, and everything after it -- fix-up of cut buckets,
+// bucket reduction, tree sums: low-occupancy kernels that wait on dependent EC additions -- once for the whole batch, the
+// products side by side in the grid (blockIdx.y, or extra bucket sets for the reduction). Measured at 2^24: the fix-up,
+// medium-bucket and tree-sum launches of A, B1, C become one launch each (- 0.3 ms per proof); the bucket reduction itself
+// is bound by its arithmetic (two full additions per bucket and a scalar multiple per chunk), not by latency, and gains
+// only through the longer chunks a batch allows (reduce_chunk).
+constexpr int MSM_MAX_BATCH = 4;
 template <class Cfg>
-MsmPending msm_enqueue(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta,
-                       hipStream_t stream, MsmStats* stats, u32* pinned_host) {
+void msm_enqueue_multi(const MsmSchedule& s, MsmWorkspace& ws, int count, const u32* const* bases, const u64* n_bases, const int64_t* delta,
+                       hipStream_t stream, MsmStats* stats, u32* const* pinned_host, MsmPending* pend) {
     typedef typename Cfg::F F;
     const MsmGeometry& g = s.geo;
-    MsmPending pend;
-    pend.g2 = Cfg::PT_WORDS == G2Cfg::PT_WORDS;
-    pend.c = g.c; pend.bucket_windows = g.bucket_windows(); pend.host = pinned_host;
-    if (g.n == 0 || n_bases == 0) return pend;
-    if ((size_t)pend.bucket_windows * Cfg::PT_WORDS > MSM_PENDING_WORDS) throw std::logic_error("msm: result block too large");
-    pend.empty = false;
+    if (count < 1 || count > MSM_MAX_BATCH) throw std::logic_error("msm: batch size");
+    // products without points (or an empty schedule) are the point at infinity and take no part
+    int live[MSM_MAX_BATCH], k = 0;
+    for (int j = 0; j < count; j++) {
+        pend[j] = MsmPending();
+        pend[j].g2 = Cfg::PT_WORDS == G2Cfg::PT_WORDS;
+        pend[j].c = g.c; pend[j].bucket_windows = g.bucket_windows(); pend[j].host = pinned_host[j];
+        if (g.n == 0 || n_bases[j] == 0) continue;
+        if ((size_t)pend[j].bucket_windows * Cfg::PT_WORDS > MSM_PENDING_WORDS) throw std::logic_error("msm: result block too large");
+        pend[j].empty = false;
+        live[k++] = j;
+    }
+    if (!k) return;
     // upper bounds of what the schedule holds (the true counts stay on the device, MsmSchedule::meta):
     // segments; heavy buckets (each spans more than MEDIUM_MAX segments); their 1024-piece tasks; medium buckets
     const u64 total = g.n * g.windows;
@@ -828,39 +857,50 @@ MsmPending msm_enqueue(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases,
     const u32 heavy_max = (u32)std::min<u64>(s.heavy_cap, nseg / MEDIUM_MAX + 1);
     const u32 tasks_max = (u32)((nseg + heavy_max) / HEAVY_TASK + heavy_max + 1);
     const u32 medium_max = (u32)std::min<u64>(s.heavy_cap, nseg / (FIX_MAX - 1) + 1);
-    ws.reserve(g, Cfg::PT_WORDS == G2Cfg::PT_WORDS, nseg, tasks_max);
-    int slot = stats ? stats->begin(stream, g.n * g.windows) : -1;
-    if (nseg) {
-        hipLaunchKernelGGL(segment_accumulate_kernel<Cfg>, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, stream,
-                           bases, n_bases, delta, s.keys, s.tkeys, s.tvals, s.meta, s.log_seg, s.log_seg_tail, ws.bucket_pts, ws.slot_pts);
-        UG_KERNEL_CHECK();
+    ws.reserve(g, Cfg::PT_WORDS == G2Cfg::PT_WORDS, nseg, tasks_max, k);
+    // word strides between the arrays of consecutive products
+    const size_t bucket_stride = (size_t)g.total_buckets() * Cfg::PT_WORDS, slot_stride = (size_t)nseg * 2 * Cfg::PT_WORDS,
+                 task_stride = (size_t)tasks_max * Cfg::PT_WORDS;
+    for (int q = 0; q < k; q++) {
+        const int j = live[q];
+        int slot = stats ? stats->begin(stream, g.n * g.windows) : -1;
+        if (nseg) {
+            hipLaunchKernelGGL(segment_accumulate_kernel<Cfg>, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, stream,
+                               bases[j], n_bases[j], delta[j], s.keys, s.tkeys, s.tvals, s.meta, s.log_seg, s.log_seg_tail,
+                               ws.bucket_pts + q * bucket_stride, ws.slot_pts + q * slot_stride);
+            UG_KERNEL_CHECK();
+        }
+        if (stats) stats->end(slot, stream);
     }
-    if (stats) stats->end(slot, stream);
     if (nseg > 1) {
         const u64 small_max = std::min<u64>(g.total_buckets(), nseg);       // a listed bucket crosses a segment boundary of its own
-        hipLaunchKernelGGL(bucket_fixup_kernel<Cfg>, dim3((unsigned)((small_max + 127) / 128)), dim3(128), 0, stream,
-                           s.small_list, s.meta, s.bucket_start, s.bucket_count, s.log_seg, s.log_seg_tail, ws.slot_pts, ws.bucket_pts);
+        hipLaunchKernelGGL(bucket_fixup_kernel<Cfg>, dim3((unsigned)((small_max + 127) / 128), k), dim3(128), 0, stream,
+                           s.small_list, s.meta, s.bucket_start, s.bucket_count, s.log_seg, s.log_seg_tail, ws.slot_pts, ws.bucket_pts,
+                           slot_stride, bucket_stride);
         UG_KERNEL_CHECK();
         if (nseg > FIX_MAX) {
-            hipLaunchKernelGGL(medium_bucket_kernel<Cfg>, dim3(std::min<u32>((medium_max + 3) / 4, 2048)), dim3(256), 0, stream,
-                               (const HeavyBucket*)s.medium_list, s.meta, medium_max, ws.slot_pts, ws.bucket_pts);
+            hipLaunchKernelGGL(medium_bucket_kernel<Cfg>, dim3(std::min<u32>((medium_max + 3) / 4, 2048), k), dim3(256), 0, stream,
+                               (const HeavyBucket*)s.medium_list, s.meta, medium_max, ws.slot_pts, ws.bucket_pts, slot_stride, bucket_stride);
             UG_KERNEL_CHECK();
         }
         if (nseg > MEDIUM_MAX) {
-            hipLaunchKernelGGL(heavy_partial_kernel<Cfg>, dim3(tasks_max), dim3(Cfg::BLOCK), 0, stream,
-                               (const HeavyBucket*)s.heavy_list, s.heavy_offsets, s.meta, heavy_max, ws.slot_pts, ws.task_pts);
+            hipLaunchKernelGGL(heavy_partial_kernel<Cfg>, dim3(tasks_max, k), dim3(Cfg::BLOCK), 0, stream,
+                               (const HeavyBucket*)s.heavy_list, s.heavy_offsets, s.meta, heavy_max, ws.slot_pts, ws.task_pts,
+                               slot_stride, task_stride);
             UG_KERNEL_CHECK();
-            hipLaunchKernelGGL(heavy_final_kernel<Cfg>, dim3(heavy_max), dim3(Cfg::BLOCK), 0, stream,
-                               (const HeavyBucket*)s.heavy_list, s.heavy_offsets, s.meta, heavy_max, ws.task_pts, ws.bucket_pts);
+            hipLaunchKernelGGL(heavy_final_kernel<Cfg>, dim3(heavy_max, k), dim3(Cfg::BLOCK), 0, stream,
+                               (const HeavyBucket*)s.heavy_list, s.heavy_offsets, s.meta, heavy_max, ws.task_pts, ws.bucket_pts,
+                               task_stride, bucket_stride);
             UG_KERNEL_CHECK();
         }
     }
-    int chunk = reduce_chunk(g);
-    const int bw = g.bucket_windows();                 // bucket sets: one per window, or one in all with window tables
+    int chunk = reduce_chunk(g, k, Cfg::PT_WORDS == G2Cfg::PT_WORDS);
+    const int windows = g.bucket_windows();            // bucket sets per product: one per window, or one in all with window tables
+    const int bw = windows * k;                        // ... of the whole batch, product after product
     u32 cpw = g.buckets / chunk;                       // chunks per bucket set
     u32 nchunks = cpw * bw;
     hipLaunchKernelGGL(bucket_chunk_reduce_kernel<Cfg>, dim3((nchunks + 127) / 128), dim3(128), 0, stream,
-                       ws.bucket_pts, s.bucket_count, g.buckets, chunk, nchunks, g.c, ws.chunk_pts);
+                       ws.bucket_pts, s.bucket_count, g.buckets, chunk, nchunks, g.c, ws.chunk_pts, (u32)windows);
     UG_KERNEL_CHECK();
     u32* cur = ws.chunk_pts; u32* nxt = ws.chunk_pts2;
     while (cpw > 1) {
@@ -879,7 +919,15 @@ MsmPending msm_enqueue(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases,
         UG_KERNEL_CHECK();
         std::swap(cur, nxt);
     }
-    UG_HIP(hipMemcpyAsync(pinned_host, cur, (size_t)bw * Cfg::PT_WORDS * 4, hipMemcpyDeviceToHost, stream));
+    for (int q = 0; q < k; q++)
+        UG_HIP(hipMemcpyAsync(pinned_host[live[q]], cur + (size_t)q * windows * Cfg::PT_WORDS, (size_t)windows * Cfg::PT_WORDS * 4,
+                              hipMemcpyDeviceToHost, stream));
+}
+template <class Cfg>
+MsmPending msm_enqueue(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta,
+                       hipStream_t stream, MsmStats* stats, u32* pinned_host) {
+    MsmPending pend;
+    msm_enqueue_multi<Cfg>(s, ws, 1, &bases, &n_bases, &delta, stream, stats, &pinned_host, &pend);
     return pend;
 }
 
@@ -947,6 +995,14 @@ MsmPending msm_enqueue_g1(const MsmSchedule& s, MsmWorkspace& ws, const u32* bas
                           MsmStats* stats, u32* pinned_host) { return msm_enqueue<G1Cfg>(s, ws, bases, n_bases, delta, stream, stats, pinned_host); }
 MsmPending msm_enqueue_g2(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta, hipStream_t stream,
                           MsmStats* stats, u32* pinned_host) { return msm_enqueue<G2Cfg>(s, ws, bases, n_bases, delta, stream, stats, pinned_host); }
+void msm_enqueue_batch_g1(const MsmSchedule& s, MsmWorkspace& ws, int count, const u32* const* bases, const u64* n_bases, const int64_t* delta,
+                          hipStream_t stream, MsmStats* stats, u32* const* pinned_host, MsmPending* pend) {
+    msm_enqueue_multi<G1Cfg>(s, ws, count, bases, n_bases, delta, stream, stats, pinned_host, pend);
+}
+void msm_enqueue_batch_g2(const MsmSchedule& s, MsmWorkspace& ws, int count, const u32* const* bases, const u64* n_bases, const int64_t* delta,
+                          hipStream_t stream, MsmStats* stats, u32* const* pinned_host, MsmPending* pend) {
+    msm_enqueue_multi<G2Cfg>(s, ws, count, bases, n_bases, delta, stream, stats, pinned_host, pend);
+}
 G1XYZZ msm_collect_g1(const MsmPending& p) { return msm_collect<G1Cfg>(p); }
 G2XYZZ msm_collect_g2(const MsmPending& p) { return msm_collect<G2Cfg>(p); }
 

@@ -669,16 +669,39 @@ int ug_msm_batch_enqueue(ug_ctx* c, int count, const ug_bases* const* bases, con
     }
     c->use();
     ScopedTimer tm(c, &c->msm_ms);
+    // the G1 products of the call form one batch, the G2 products another (msm.hip: msm_enqueue_multi): one accumulation
+    // launch per product, the tail kernels once per batch; within a curve the caller's order is kept
+    const size_t first_slot = c->pending_msm.size();
     for (int k = 0; k < count; k++) {
-        const ug_bases* b = bases[k];
-        int64_t delta = (int64_t)s->first - (index_shifts ? index_shifts[k] : 0) - (int64_t)b->global_first;
-        u32* host = c->pinned_results + c->pending_msm.size() * MSM_PENDING_WORDS;
         ug_ctx::QueuedMsm q;
-        q.g2 = b->g2; q.out = outs[k];
-        q.pend = b->g2 ? msm_enqueue_g2(s->sched, c->ws_g2, b->pts, b->n, delta, c->stream, &c->stats[1], host)
-                       : msm_enqueue_g1(s->sched, c->ws_g1, b->pts, b->n, delta, c->stream, &c->stats[0], host);
+        q.g2 = bases[k]->g2; q.out = outs[k];
         c->pending_msm.push_back(q);
     }
+    try {
+    for (int g2 = 0; g2 < 2; g2++) {
+        int idx[MSM_BATCH_MAX], n = 0;
+        auto flush = [&] {
+            if (!n) return;
+            const u32* pts[MSM_BATCH_MAX]; u64 nb[MSM_BATCH_MAX]; int64_t delta[MSM_BATCH_MAX]; u32* host[MSM_BATCH_MAX]; MsmPending pend[MSM_BATCH_MAX];
+            for (int q = 0; q < n; q++) {
+                const ug_bases* b = bases[idx[q]];
+                pts[q] = b->pts; nb[q] = b->n;
+                delta[q] = (int64_t)s->first - (index_shifts ? index_shifts[idx[q]] : 0) - (int64_t)b->global_first;
+                host[q] = c->pinned_results + (first_slot + idx[q]) * MSM_PENDING_WORDS;
+            }
+            if (g2) msm_enqueue_batch_g2(s->sched, c->ws_g2, n, pts, nb, delta, c->stream, &c->stats[1], host, pend);
+            else msm_enqueue_batch_g1(s->sched, c->ws_g1, n, pts, nb, delta, c->stream, &c->stats[0], host, pend);
+            for (int q = 0; q < n; q++) c->pending_msm[first_slot + idx[q]].pend = pend[q];
+            n = 0;
+        };
+        for (int k = 0; k < count; k++) {
+            if ((bases[k]->g2 ? 1 : 0) != g2) continue;
+            idx[n++] = k;
+            if (n == MSM_BATCH_MAX) flush();
+        }
+        flush();
+    }
+    } catch (...) { c->pending_msm.resize(first_slot); throw; }      // nothing of a failed call stays queued
     tm.stop();
     UG_CATCH
 }
