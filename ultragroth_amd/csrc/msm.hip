@@ -5,16 +5,22 @@
 // UltraGroth twins src/ultra_groth.cpp:168,201,214,227,234,322). Scalars are 32-byte plain integers.
 //
 // Pipeline (one "schedule" per scalar vector, shared by every base set multiplied by it):
-//   1. msm_digits_kernel     scalar -> signed c-bit digits (carry recoding), one (key,val) pair per
-//                            window: key = window * 2^(c-1) + |digit| - 1, val = index | sign << 31;
-//                            zero digits get a sentinel key and fall off the end of the sort
+//   1. msm_digits_kernel     scalar -> signed c-bit digits (carry recoding), one (key, val) pair per window:
+//                            key = bucket id (one bucket set for all windows when the base set has window tables, else
+//                            window * 2^(c-1) + |digit| - 1), val = index | table << 27 | sign << 31; zero digits get a
+//                            sentinel key and fall off the end of the sort
 //   2. hipcub radix sort     groups pairs by bucket                (coalesced, no atomics)
-//   3. bucket_bounds_kernel  first entry and entry count of every bucket; heavy buckets are listed
-//   4. bucket_accumulate     one lane per bucket: gather affine bases, mixed-add into XYZZ registers
-//      heavy_partial/final   buckets with more than HEAVY entries (witnesses are full of 0/1 values)
-//                            are cut into block-sized tasks and tree-reduced through LDS
-//   5. bucket_chunk_reduce   running-sum trick on chunks of 32 buckets + ec_sum_groups tree
-//   6. host                  Horner over the <= 64 window sums (c doublings each)
+//   3. bucket_bounds / bucket_counts   first entry and entry count of every bucket; buckets cut by segment boundaries are
+//                            listed by size class. Counts stay on the device (meta): no host read-back
+//   4. transpose_entries     lane-transposed copy of the entries: the sorted list is cut into segments (segmap.hpp), one
+//                            lane each, so that every lane of a wave does the same number of additions
+//   5. segment_accumulate    the dominant kernel: gather affine bases, mixed-add into XYZZ registers; whole buckets go to
+//                            bucket_pts, runs cut by a segment boundary to two slots per lane
+//      bucket_fixup / medium_bucket / heavy_partial + heavy_final   add the pieces of cut buckets (a lane, a wave or
+//                            workgroup tasks per bucket: witnesses are full of 0/1 values, i.e. million-entry buckets)
+//   6. bucket_chunk_reduce   running-sum trick on chunks of up to 32 buckets + ec_sum_groups / ec_sum_wave tree
+//   7. host                  Horner over the window sums (none with window tables), affine conversion
+// Steps 5b-6 run once for all products of a curve queued together (msm_enqueue_multi).
 //
 // Arithmetic volume dominates: each of the n * windows gathered bases costs one mixed addition
 // (G1: 8 mul + 2 sqr in Fq, G2: the same in Fq2). Algorithmic HBM bytes: 96 n (G1) / 160 n (G2).
