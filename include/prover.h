@@ -172,7 +172,8 @@ int ug_groth16_prover_create_sharded_range(void **prover_object, const void *zke
  * zkey_header = the bytes of zkey section 2; coefs = section 4 without its 4-byte count (NULL: this rank will run no
  * H-polynomial chain and keeps no coefficient matrix); points_* = this rank's slice of sections 5..9, starting at the
  * first point of the ranges ug_groth16_shard_ranges reports: out[6] = {witness first, end, C first, end, H first, end}
- * (witness_range: two values as in _create_sharded_range, or NULL for the even split). */
+ * (witness_range: two values as in _create_sharded_range, or NULL for the even split). slice_bytes = the byte counts of the
+ * caller's points_a .. points_h buffers: a slice shorter than the rank's range is refused instead of read past its end. */
 int ug_groth16_shard_ranges(unsigned long long n_vars, unsigned long long n_public, unsigned long long domain_size,
                             int shard_rank, int shard_count, const unsigned long long *witness_range,
                             unsigned long long out[6]);
@@ -180,6 +181,7 @@ int ug_groth16_prover_create_sharded_slices(void **prover_object, const void *zk
                                             const void *coefs, unsigned long long n_coefs,
                                             const void *points_a, const void *points_b1, const void *points_b2,
                                             const void *points_c, const void *points_h,
+                                            const unsigned long long slice_bytes[5],
                                             int device, int shard_rank, int shard_count,
                                             const unsigned long long *witness_range,
                                             char *error_msg, unsigned long long error_msg_maxsize);

@@ -156,6 +156,14 @@ int  ug_msm_batch_enqueue(ug_ctx* ctx, int count, const ug_bases* const* bases, 
                           const int64_t* index_shifts, void* const* outs);
 int  ug_ctx_collect(ug_ctx* ctx);
 int  ug_ctx_wait(ug_ctx* waiter, ug_ctx* signal);
+/* For a caller that queued work and then failed before ug_ctx_collect: waits for what is still running on the context (the
+ * kernels read the caller's buffers) and forgets the queued products, whose `outs` may no longer exist. Never fails. */
+void ug_ctx_abandon(ug_ctx* ctx);
+/* Test hook, honoured only in processes started with ULTRAGROTH_TEST_HOOKS=1 (UG_ERROR otherwise): the `after`-th next call
+ * that passes fault point `site` fails with "injected fault". Lets the tests take the error paths of a running proof. */
+#define UG_FAULT_HPOLY_RUN 1
+#define UG_FAULT_SCHEDULE_BUILD 2
+int  ug_test_inject_fault(int site, int after);
 
 /* coefs: n_coefs packed 44-byte records {u32 m, u32 c, u32 s, Fr coef} (zkey section 4 past its 4-byte
  * count, src/groth16.cpp:38). Builds the row-sorted matrix and the NTT tables for domain_size. */

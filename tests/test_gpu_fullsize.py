@@ -122,19 +122,155 @@ def test_piecewise_ranges_at_full_size(full_zkey, full_prover, monkeypatch):
         assert _prove(p, wtns) == _expected(zkey, wtns, FULL_LOG)
 
 
-@pytest.mark.skipif(HUGE_LOG == 0, reason="UG_HUGE_LOG=0")
-def test_whole_proof_at_configs3_size(device):
-    """BASELINE.json configs[3]'s circuit, 2^26 constraints, on ONE GPU (classic windows; 2^28 coefficient records)"""
-    import ultragroth_amd as ug
+@pytest.fixture(scope="module")
+def huge(device):
+    """BASELINE.json configs[3]'s circuit (2^HUGE_LOG constraints) with its expected proof, made once for the single-GPU
+    and the 8-rank tests below (the oracle's H polynomial at this size is most of the cost of either)"""
     from ultragroth_amd import synth
+    if HUGE_LOG == 0:
+        pytest.skip("UG_HUGE_LOG=0")
     free, total = device.mem_info()
     if total < (200 << 30):
         pytest.skip("needs a 288 GB device")
     _progress("2^%d: building the circuit" % HUGE_LOG)
     zkey, wtns, info = synth.build_circuit(device, HUGE_LOG, mix="U")
+    _progress("2^%d: expected proof" % HUGE_LOG)
+    return zkey, wtns, info, _expected(zkey, wtns, HUGE_LOG)
+
+
+def test_whole_proof_at_configs3_size(huge):
+    """BASELINE.json configs[3]'s circuit, 2^26 constraints, on ONE GPU (classic windows; 2^28 coefficient records)"""
+    import ultragroth_amd as ug
+    zkey, wtns, info, exp = huge
     _progress("2^%d: creating the prover" % HUGE_LOG)
     with ug.Groth16Prover(zkey) as p:
         _progress("2^%d: proving" % HUGE_LOG)
         got = _prove(p, wtns)
-    assert got == _expected(zkey, wtns, HUGE_LOG)
+    assert got == exp
     _progress("2^%d: done" % HUGE_LOG)
+
+
+def test_eight_sliced_ranks_at_configs3_size(device, huge, monkeypatch):
+    """BASELINE.json configs[3] as its text has it -- 2^26 constraints, base points sharded over EIGHT ranks -- rehearsed on
+    one device at full size, byte for byte against the same expected proof: every rank is created from ITS slices only
+    (ug_groth16_prover_create_sharded_slices, the witness ranges bench.py chooses: chain ranks get fewer points), the
+    witness travels in two parts, ranks 0-2 run the three iFFT/twist/FFT chains, every rank combines its slice of h
+    (ug_groth16_prover_hpoly_combine) and runs its H-MSM shard, the 384-byte partials are added and rank 0 finishes.
+    This puts under test what the small sharded tests cannot: slice offsets above 2^24, the C section's index shift inside
+    a slice, h ranges of 2^23 and the per-rank memory. Rank 0 runs the classic windows, the others fixed-base window
+    tables (the per-rank choice a many-GPU node makes from its free memory). Ranks 3-7 live one after the other: the
+    device holds the three chain ranks (26 GB of H-polynomial state each) and one more at a time."""
+    import ctypes as C
+    import torch
+    import ultragroth_amd as ug
+    import bench
+    zkey, wtns, info, exp = huge
+    world, n_dom, nv = 8, info["domainSize"], info["nVars"]
+    sl = n_dom // world
+    view = memoryview(zkey).cast("B")
+
+    def sec(sid, skip=0):
+        off, sz = O.section(zkey, "zkey", sid)
+        return off + skip, sz - skip
+    header = bytes(view[sec(2)[0]:sec(2)[0] + sec(2)[1]])
+    c_off, c_sz = sec(4, 4)
+    coefs = (C.c_char * c_sz).from_buffer(view[c_off:c_off + c_sz])
+
+    def part(sid, rec, lo, hi):
+        off, _ = sec(sid)
+        n = (hi - lo) * rec
+        return (C.c_char * n).from_buffer(view[off + lo * rec:off + lo * rec + n]) if n else (C.c_char * 0)()
+
+    def create(k):
+        wr = bench.witness_slice(info, k, world)
+        rg = ug.ShardedGroth16Prover.shard_ranges(nv, info["nPublic"], n_dom, k, world, wr)
+        assert rg[0] == wr and rg[2] == (k * sl, (k + 1) * sl)
+        (w0, w1), (c0, c1), (h0, h1) = rg
+        slices = (part(5, 64, w0, w1), part(6, 64, w0, w1), part(7, 128, w0, w1), part(8, 64, c0, c1), part(9, 64, h0, h1))
+        monkeypatch.setenv("ULTRAGROTH_TABLES", "0" if k == 0 else "1")
+        _progress("2^%d x8: creating rank %d (witness %d..%d)" % (HUGE_LOG, k, w0, w1))
+        return ug.ShardedGroth16Prover.from_slices(header, coefs if k < 3 else None, info["nCoefs"], slices, 0, k, world,
+                                                   witness_range=wr, public_size=82 * info["nPublic"] + 4)
+
+    def h_part(p, k, full):
+        assert p.h_range() == (k * sl, sl, n_dom)
+        bufs = [full[c, k * sl:(k + 1) * sl] for c in range(3)]          # contiguous views: no copy
+        p.hpoly_combine(*(b.data_ptr() for b in bufs))
+        return p.run_h_msm()[320:384]
+
+    full = torch.empty((3, n_dom, 32), dtype=torch.uint8, device="cuda")
+    total = None
+    chain_ranks, parts = [], []
+    try:
+        for k in range(3):
+            p = create(k)
+            chain_ranks.append(p)
+            p.load_witness_part(wtns, 0)
+            parts.append(p.run_witness_msm())
+            p.load_witness_part(wtns, 1)
+            p.hpoly_chain(k, full[k].data_ptr())
+        torch.cuda.synchronize()
+        for k, p in enumerate(chain_ranks):
+            blk = parts[k][:320] + h_part(p, k, full)
+            total = blk if total is None else ug.ShardedGroth16Prover.add_partials(total, blk)
+            if k:
+                p.close()
+        for k in range(3, world):
+            p = create(k)
+            try:
+                p.load_witness_part(wtns, 0)                 # a rank without a chain never sees the rest of the witness
+                blk = p.run_witness_msm()[:320] + h_part(p, k, full)
+            finally:
+                p.close()
+            total = ug.ShardedGroth16Prover.add_partials(total, blk)
+        _progress("2^%d x8: finishing on rank 0" % HUGE_LOG)
+        r, s = fixed_rs()
+        ug.set_test_blinding(r + s)
+        try:
+            got = chain_ranks[0].finish(total)
+        finally:
+            ug.set_test_blinding(b"")
+    finally:
+        for p in chain_ranks:
+            p.close()
+        del coefs, view
+    assert got == exp
+    _progress("2^%d x8: done" % HUGE_LOG)
+
+
+def test_ultragroth_at_configs4_size(device):
+    """BASELINE.json configs[4]'s circuit on one GPU inside the suite: UltraGroth, 2^22 constraints, lookup table 2^16
+    (SURVEY.md section 8d cfg 5), a CREATED prover (window tables), two proofs on the one object; == the oracle (parity of the
+    UltraGroth whole proof is unpinned upstream: no fixture exists there; the oracle's pieces are pinned)"""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    log_domain = int(os.environ.get("UG_ULTRA_LOG", "22"))
+    _progress("ultragroth 2^%d: building the circuit" % log_domain)
+    zkey, uwtns, info = synth.build_ultra_circuit(device, log_domain, mix="C", lookup_log=16)
+    rk, r, s = bytes(range(1, 32)), bytes(range(40, 71)), bytes(range(80, 111))
+    _progress("ultragroth 2^%d: oracle" % log_domain)
+    exp = O.ultra_groth_prove(zkey, uwtns, int.from_bytes(rk, "little"), int.from_bytes(r, "little"), int.from_bytes(s, "little"))
+    _progress("ultragroth 2^%d: proving" % log_domain)
+    with ug.UltraGrothProver(zkey) as p:
+        for _ in range(2):
+            ug.set_test_blinding(rk + r + s)
+            try:
+                assert p.prove(uwtns) == exp
+            finally:
+                ug.set_test_blinding(b"")
+
+
+def test_g1_only_created_prover_at_configs1_size(device):
+    """BASELINE.json configs[1] as written: 2^20 constraints, G1 MSM + Fr NTT only (the B1, B2 and C sections are all-infinity
+    sets of the right size), through a created prover; == the oracle's whole proof and == the closed-form assembly"""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, wtns, info = synth.build_circuit(device, 20, mix="U", g1_only=True)
+    r, s = fixed_rs()
+    ri, si = int.from_bytes(r, "little"), int.from_bytes(s, "little")
+    with ug.Groth16Prover(zkey) as p:
+        got = _prove(p, wtns)
+    exp = O.groth16_prove(zkey, wtns, ri, si)
+    assert got == (exp[0], exp[1])
+    assert got == closed_form.groth16_expected(zkey, wtns, synth.SEEDS, synth.g1_generator_record(), synth.g2_generator_record(),
+                                               ri, si, g1_only=True)

@@ -53,6 +53,15 @@ def set_test_blinding(data):
         raise ProverError(PROVER_ERROR, "test hooks are off: start the process with ULTRAGROTH_TEST_HOOKS=1")
 
 
+FAULT_HPOLY_RUN, FAULT_SCHEDULE_BUILD = 1, 2
+
+
+def inject_fault(site, after=1):
+    """ug_test_inject_fault: the `after`-th next pass through fault point `site` fails (test processes only)"""
+    if load().ug_test_inject_fault(site, after) != 0:
+        raise ProverError(PROVER_ERROR, "test hooks are off: start the process with ULTRAGROTH_TEST_HOOKS=1")
+
+
 def _buf(b):
     return (C.c_char * len(b)).from_buffer_copy(b) if not isinstance(b, C.Array) else b
 
@@ -291,7 +300,8 @@ class ShardedGroth16Prover:
         self._h = C.c_void_p()
         err = C.create_string_buffer(1024)
         wr = (C.c_ulonglong * 2)(*witness_range) if witness_range is not None else None
-        rc = load().ug_groth16_prover_create_sharded_slices(C.byref(self._h), header, len(header), coefs, n_coefs, *slices,
+        sizes = (C.c_ulonglong * 5)(*[len(x) for x in slices])
+        rc = load().ug_groth16_prover_create_sharded_slices(C.byref(self._h), header, len(header), coefs, n_coefs, *slices, sizes,
                                                             device, rank, world, wr, err, len(err) - 1)
         if rc != PROVER_OK:
             self._h = None

@@ -19,7 +19,7 @@ INNER_SYMBOLS = [
     "ug_schedule_create", "ug_schedule_build", "ug_schedule_destroy",
     "ug_msm_g1", "ug_msm_g2", "ug_msm_batch", "ug_msm_batch_enqueue", "ug_ctx_collect", "ug_ctx_wait",
     "ug_hpoly_create", "ug_hpoly_run", "ug_hpoly_chain", "ug_hpoly_combine", "ug_hpoly_debug_abc", "ug_hpoly_destroy",
-    "ug_fr_ntt", "ug_field_op", "ug_synth_points", "ug_ctx_timings", "ug_ctx_kernel_stats",
+    "ug_fr_ntt", "ug_field_op", "ug_synth_points", "ug_ctx_timings", "ug_ctx_kernel_stats", "ug_ctx_abandon", "ug_test_inject_fault",
     "ug_bases_drop_tables", "ug_bases_table_window", "ug_schedule_trim", "ug_ctx_trim",
 ]
 VERIFIER_SYMBOLS = ["groth16_verify", "ultra_groth_verify"]        # include/verifier.h
@@ -73,6 +73,8 @@ def load():
     L.ug_ctx_create.argtypes = [pp, C.c_int]
     L.ug_ctx_destroy.argtypes = [vp]; L.ug_ctx_destroy.restype = None
     L.ug_ctx_sync.argtypes = [vp]
+    L.ug_ctx_abandon.argtypes = [vp]; L.ug_ctx_abandon.restype = None
+    L.ug_test_inject_fault.argtypes = [C.c_int, C.c_int]
     for n in ("ug_bases_create_g1", "ug_bases_create_g2"):
         getattr(L, n).argtypes = [vp, vp, u64, u64, pp]
     L.ug_bases_destroy.argtypes = [vp]; L.ug_bases_destroy.restype = None
@@ -153,7 +155,7 @@ def load():
     L.ug_groth16_prover_load_witness.argtypes = [vp, vp, ull, vp, ull]
     L.ug_groth16_prover_load_witness_part.argtypes = [vp, vp, ull, C.c_int, vp, ull]
     L.ug_groth16_shard_ranges.argtypes = [ull, ull, ull, C.c_int, C.c_int, vp, vp]
-    L.ug_groth16_prover_create_sharded_slices.argtypes = [pp, vp, ull, vp, ull, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, ull]
+    L.ug_groth16_prover_create_sharded_slices.argtypes = [pp, vp, ull, vp, ull, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, ull]
     L.ug_dvec_upload_range.argtypes = [vp, vp, u64, u64, vp]
     L.ug_fr_lookup_table.argtypes = [vp, vp, vp, u64, vp]
     L.ug_groth16_prover_run.argtypes = [vp, vp, vp, ull]

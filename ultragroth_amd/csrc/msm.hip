@@ -755,6 +755,9 @@ void MsmSchedule::reserve(const MsmGeometry& g) {
 }
 
 void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_t stream) {
+    // limits first: reserve() hands `total` to the sort as an int
+    if (g.n * (u64)g.windows >= ((u64)1 << 31)) throw std::invalid_argument("msm: n * windows exceeds 2^31 entries");
+    if (g.n > ((u64)1 << TABLE_INDEX_BITS)) throw std::invalid_argument("msm: more than 2^27 scalars in one schedule");
     geo = g;
     reserve(g);
     log_seg = segment_log(g.n * g.windows);
@@ -764,8 +767,6 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
     log_seg_tail = (taper && log_seg == LOG_SEG && ((g.n * g.windows) >> log_seg) >= ((u64)1 << 16)) ? log_seg - 2 : log_seg;
     if (g.n == 0) return;
     u64 total = g.n * g.windows;
-    if (total >= ((u64)1 << 31)) throw std::invalid_argument("msm: n * windows exceeds 2^31 entries");
-    if (g.n > ((u64)1 << TABLE_INDEX_BITS)) throw std::invalid_argument("msm: more than 2^27 scalars in one schedule");
     u32 nb = (u32)g.total_buckets();
     u32 sentinel = nb;
     hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, stream,
@@ -815,7 +816,7 @@ void MsmWorkspace::reserve(const MsmGeometry& g, bool g2, u64 n_segments, u32 n_
     size_t ptw = (size_t)(g2 ? G2Cfg::PT_WORDS : G1Cfg::PT_WORDS) * (size_t)sets;      // the products of a batch lie one after the other
     size_t need = (size_t)g.total_buckets() * ptw * 4;
     if (need > bucket_bytes) { dev_alloc(bucket_pts, need); bucket_bytes = need; }
-    int chunk = reduce_chunk(g);
+    const int chunk = reduce_chunk(g, sets, g2);           // the chunk the launch uses (msm_enqueue_multi): same arguments, same value
     size_t cneed = (size_t)g.bucket_windows() * (g.buckets / chunk) * ptw * 4;
     if (cneed > chunk_bytes) { dev_alloc(chunk_pts, cneed); dev_alloc(chunk_pts2, cneed); chunk_bytes = cneed; }
     size_t sneed = (size_t)n_segments * 2 * ptw * 4;

@@ -51,6 +51,28 @@ void ugCheck(int rc) {
     if (rc != UG_OK) throw std::runtime_error(ug_last_error());
 }
 
+// Work queued on the prover's contexts must not outlive a failing call: the queued MSMs hold pointers into the caller's
+// stack frame and the kernels read the leased witness buffer. Armed while a call has work in flight; on unwind it waits
+// for the device and drops what was queued (ug_ctx_abandon), before the witness lease and the turn are given back.
+struct QueueGuard {
+    ug_ctx *a, *b;
+    bool armed = true;
+    QueueGuard(ug_ctx* a_, ug_ctx* b_ = nullptr) : a(a_), b(b_) {}
+    ~QueueGuard() { if (armed) { ug_ctx_abandon(a); ug_ctx_abandon(b); } }
+    void done() { armed = false; }
+    QueueGuard(const QueueGuard&) = delete;
+    QueueGuard& operator=(const QueueGuard&) = delete;
+};
+// `around(false)` of ProverBase::proveTurn is owed once `around(true)` has been called, also when the proof throws
+struct AroundGuard {
+    const std::function<void(bool)>& fn;
+    bool open = false;
+    explicit AroundGuard(const std::function<void(bool)>& f) : fn(f) {}
+    void begin() { if (fn) { fn(true); open = true; } }
+    void end() { if (open) { open = false; fn(false); } }
+    ~AroundGuard() { if (open) { try { fn(false); } catch (...) {} } }
+};
+
 constexpr unsigned long long PROOF_MIN_GROTH16 = 810, PROOF_MIN_ULTRA = 1400;
 unsigned long long publicMin(unsigned long long count) { return count * 82 + 4; }
 
@@ -385,9 +407,10 @@ struct ProverBase {        // what the extern "C" layer stores behind the opaque
         std::unique_lock<std::mutex> card;
         if (device) card = std::unique_lock<std::mutex>(*device);
         std::lock_guard<std::mutex> turn(proveMutex);
-        if (around) around(true);
+        AroundGuard bracket(around);
+        bracket.begin();
         prove(wtns, wtnsSize, proof, pub);
-        if (around) around(false);
+        bracket.end();
     }
     virtual unsigned long long proofBufferMinSize() const = 0;
     virtual unsigned long long publicBufferMinSize() const = 0;
@@ -458,6 +481,7 @@ public:
         bool sliced = false;
         const uint8_t* coefs = nullptr; uint64_t nCoefs = 0; bool haveCoefs = true;     // !haveCoefs: this rank runs no NTT chain
         const uint8_t *pA = nullptr, *pB1 = nullptr, *pB2 = nullptr, *pC = nullptr, *pH = nullptr;
+        const unsigned long long* sliceBytes = nullptr;       // sliced: the caller's byte counts of pA .. pH, checked against the ranges
     };
     struct Ranges { Range w, c, h; };
     // the slices of rank `rank` of `count` (witnessRange: chosen by the caller, else the even split); C follows the witness slice
@@ -540,6 +564,17 @@ private:
         const uint64_t cLo = rg.c.lo, cHi = rg.c.hi;
         if (!src.sliced) {                       // whole sections: step to this rank's slice
             pA += wr_.lo * 64; pB1 += wr_.lo * 64; pB2 += wr_.lo * 128; pC += cLo * 64; pH += hr_.lo * 64;
+        } else {                                 // slices: each must hold the points of this rank's range (a short buffer would be read past its end)
+            const uint64_t need[5] = {(wr_.hi - wr_.lo) * 64, (wr_.hi - wr_.lo) * 64, (wr_.hi - wr_.lo) * 128, (cHi - cLo) * 64, (hr_.hi - hr_.lo) * 64};
+            const uint8_t* ptr[5] = {pA, pB1, pB2, pC, pH};
+            static const char* const what[5] = {"points_a", "points_b1", "points_b2", "points_c", "points_h"};
+            for (int k = 0; k < 5; k++) {
+                if (need[k] && !ptr[k]) throw std::invalid_argument(std::string("Null ") + what[k] + " slice");
+                if (src.sliceBytes && src.sliceBytes[k] < need[k])
+                    throw std::invalid_argument(std::string(what[k]) + " slice is shorter than this rank's range: " + std::to_string(src.sliceBytes[k]) +
+                                                " bytes, needed " + std::to_string(need[k]));
+            }
+            if (src.haveCoefs && !src.coefs && src.nCoefs) throw std::invalid_argument("Null coefficient records");
         }
 
         ugCheck(ug_ctx_create(&d_.ctx, device));
@@ -665,13 +700,14 @@ public:
         if (device) card = std::unique_lock<std::mutex>(*device);
         std::unique_lock<std::mutex> turn(proveMutex);
         traceStep("turn on the device");
-        if (around) around(true);
+        AroundGuard bracket(around);
+        bracket.begin();
         adopt(*lease);
         // the turn ends with the device part: blinding and JSON of this proof run on the host while the next caller's
         // kernels start (0.7 ms of idle device per proof otherwise)
         proveLoaded(proof, pub, [&] {
             totalMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            if (around) around(false);
+            bracket.end();
             turn.unlock();
             if (card.owns_lock()) card.unlock();
         });
@@ -710,6 +746,7 @@ public:
         // reference's largest legal domain, 2^27, needs it) are proved in pieces whose partial sums are added.
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
         uint8_t part[UG_GROTH16_PARTIALS_SIZE];
+        QueueGuard inFlight(d_.ctx);
         for (uint64_t lo = wr_.lo; lo < wr_.hi; lo += maxRange_) {
             uint64_t n = std::min<uint64_t>(maxRange_, wr_.hi - lo);
             uint8_t* out = (lo == wr_.lo) ? partials : part;
@@ -722,6 +759,7 @@ public:
             ugCheck(ug_msm_batch(d_.ctx, 4, sets, d_.sw, shifts, outs));
             if (out == part && ug_groth16_partials_add(partials, part) != PROVER_OK) throw std::runtime_error("partial sum failed");
         }
+        inFlight.done();
         if (standalone) collectTimings(1);
     }
     // S10 on this rank's slice of h (which must be in d_.h); only the H record of partials is written
@@ -729,6 +767,7 @@ public:
     void runHMsmImpl(uint8_t* partials, bool standalone) {
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
         uint8_t part[UG_GROTH16_PARTIALS_SIZE];
+        QueueGuard inFlight(d_.ctx2);
         for (uint64_t lo = hr_.lo; lo < hr_.hi; lo += maxRange_) {
             uint64_t n = std::min<uint64_t>(maxRange_, hr_.hi - lo);
             uint8_t* out = (lo == hr_.lo) ? partials : part;
@@ -739,6 +778,7 @@ public:
             ugCheck(ug_msm_batch(d_.ctx2, 1, sets, d_.sh, nullptr, outs));                     // S10 :154
             if (out == part && ug_groth16_partials_add(partials, part) != PROVER_OK) throw std::runtime_error("partial sum failed");
         }
+        inFlight.done();
         if (standalone) collectTimings(2);
     }
     // device time per branch since the witness was loaded; each branch's figures are touched only by the host thread that
@@ -791,8 +831,10 @@ public:
         if (nw > maxRange_ || nh > maxRange_) {                 // proved in pieces: partial sums are added between them
             uint8_t hpart[UG_GROTH16_PARTIALS_SIZE];
             runWitnessMsm(partials, /*standalone*/ false);
+            QueueGuard hBranch(d_.ctx2);
             ugCheck(ug_hpoly_run(d_.hp, wCur_, d_.h));                                          // S5-S9 :66-148
             runHMsmImpl(hpart, false);                                                         // S10   :154
+            hBranch.done();
             memcpy(partials + 320, hpart + 320, 64);
             collectTimings(3);
             return;
@@ -803,6 +845,7 @@ public:
         const char* ov = getenv("ULTRAGROTH_OVERLAP");
         const int overlap = ov ? atoi(ov) : 0;
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
+        QueueGuard inFlight(d_.ctx, d_.ctx2);                   // from here to the collects below work is queued on both streams
         buildSchedule(d_.sw, wCur_, wr_.lo, nw, tableW_);
         {   // S1-S4 (src/groth16.cpp:55,58,61,64): A, B1, B2, C over the witness schedule, queued back to back
             const ug_bases* sets[4] = {d_.A, d_.B1, d_.B2, d_.C};
@@ -823,6 +866,7 @@ public:
         traceStep("device part fully queued");
         ugCheck(ug_ctx_collect(d_.ctx2));                       // the one host wait of the device part ...
         ugCheck(ug_ctx_collect(d_.ctx));                        // (... this one returns at once unless the streams overlap)
+        inFlight.done();
         collectTimings(3);
     }
     int kernelStats(int which, double* avgMs, unsigned long long* launches, unsigned long long* entries, int reset) override {
@@ -1149,10 +1193,12 @@ public:
         std::unique_lock<std::mutex> card;
         if (device) card = std::unique_lock<std::mutex>(*device);
         std::lock_guard<std::mutex> turn(proveMutex);
-        if (around) around(true);
+        AroundGuard bracket(around);
+        bracket.begin();
         // ULTRAGROTH_TRACE=1: host wall-clock per phase on stderr (where the non-MSM, non-FFT time of a proof goes)
         trace_ = getenv("ULTRAGROTH_TRACE") && atoi(getenv("ULTRAGROTH_TRACE")) != 0;
         adopt(*lease);
+        QueueGuard inFlight(d_.ctx);                     // (declared before `terms`: the host threads join first, then the device is drained)
         uint8_t part[64], commit[64];
         roundCommit(part);
         roundFinish(part, commit);
@@ -1192,9 +1238,10 @@ public:
             ugCheck(ug_ctx_collect(d_.ctx));
             ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
         }
+        inFlight.done();
         finishWith(sums, r, s, terms.get(), proof, pub);
         totalMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (around) around(false);
+        bracket.end();
     }
 
     unsigned long long proofBufferMinSize() const override { return PROOF_MIN_ULTRA; }
@@ -1285,12 +1332,14 @@ public:
             auto it = entries_.find(name);
             if (it != entries_.end() && it->second->busy) throw std::invalid_argument("circuit is proving, it cannot be replaced now: " + name);
         }
-        entries_.erase(name);
         // the header tells the protocol (1 = groth16, 1337 = ultragroth, src/zkey_utils.cpp:48-50,129-131)
         BinFile f(zkey, size, "zkey", 1);
         if (f.sectionSize(1) < 4) throw std::range_error("Invalid section size");
         uint32_t protocol;
         memcpy(&protocol, f.sectionData(1), 4);
+        // The replacement is built BESIDE the resident circuit of that name, which goes only once the new one exists: a bad or
+        // oversized zkey leaves the working circuit as it was. (Both must fit the device for that moment; a caller that
+        // replaces a circuit too large for that evicts it first.)
         const uint64_t before = used();
         std::unique_ptr<Entry> e(new Entry());
         e->name = name; e->path = path; e->ultra = protocol == 1337;
@@ -1302,8 +1351,16 @@ public:
         g_registryCreate = false;
         e->coreBytes = used() - before;
         e->lastUsed = ++tick_;
+        if (e->coreBytes > budget_) throw std::runtime_error("circuit " + name + " does not fit the HBM budget");
         Entry* raw = e.get();
+        std::unique_ptr<Entry> old;
+        {
+            auto it = entries_.find(name);
+            if (it != entries_.end()) { old = std::move(it->second); entries_.erase(it); }
+        }
+        old.reset();                                   // the circuit this one replaces gives its memory back first
         entries_[name] = std::move(e);
+        evictedPaths_.erase(name);                     // a stale path of an earlier, evicted circuit of that name must not come back
         if (!makeRoom(0, raw)) {
             entries_.erase(name);
             throw std::runtime_error("circuit " + name + " does not fit the HBM budget");
@@ -1334,8 +1391,9 @@ public:
             e = it->second.get();
             e->lastUsed = ++tick_;
             checkBufferSizes(e->prover->proofBufferMinSize(), proofSize, e->prover->publicBufferMinSize(), publicSize, "Minimum");
-            // room for the proof's workspaces (known after the circuit's first proof; a guess from its size before)
-            makeRoom(e->workBytes ? 0 : e->coreBytes / 2, e);
+            // room for the proof's workspaces (known after the circuit's first proof; a guess from its size before); when even
+            // that cannot be had the proof is still tried -- its own allocations decide, and a failure leaves nothing queued
+            (void)makeRoom(e->workBytes ? 0 : e->coreBytes / 2, e);
             e->busy++;                                                     // from here on nobody may take it away
         }
         std::exception_ptr failure;
@@ -1347,8 +1405,8 @@ public:
                 e->prover->proveTurn(wtns, wtnsSize, proof, pub, &deviceMutex_, [&](bool begin) {
                     if (begin) { before = used(); return; }
                     const uint64_t after = used();
-                    if (after > before) e->workBytes += after - before;
-                    e->proofs++;
+                    if (after > before) e->workBytes += after - before;      // (atomics: info() reads them under mutex_, which this
+                    e->proofs++;                                             //  callback -- it runs inside the prover's turn -- must not take)
                     proofsTotal_++;
                 });
             } catch (...) { failure = std::current_exception(); }
@@ -1363,7 +1421,8 @@ public:
         std::lock_guard<std::mutex> lock(mutex_);
         auto it = entries_.find(name);
         if (it != entries_.end() && it->second->busy) throw std::invalid_argument("circuit is proving, it cannot be evicted now: " + name);
-        if (!entries_.erase(name) && !evictedPaths_.erase(name)) throw std::invalid_argument("circuit not loaded: " + name);
+        const size_t resident = entries_.erase(name), remembered = evictedPaths_.erase(name);      // both, unconditionally
+        if (!resident && !remembered) throw std::invalid_argument("circuit not loaded: " + name);
     }
     // name empty: totals. state: 0 not loaded, 1 resident without tables, 2 resident with tables, 3 evicted (reloadable)
     void info(const std::string& name, unsigned long long* bytes, int* state, unsigned long long* proofs) {
@@ -1392,7 +1451,8 @@ private:
         std::string name, path;
         bool ultra = false;
         std::unique_ptr<ProverBase> prover;
-        uint64_t coreBytes = 0, workBytes = 0, lastUsed = 0, proofs = 0;
+        uint64_t coreBytes = 0, lastUsed = 0;
+        std::atomic<uint64_t> workBytes{0}, proofs{0};       // written by the proof's bracket callback, outside mutex_
         uint64_t tablesDroppedAt = 0;      // tick at which its tables were taken away (it gets them back only after it was used again)
         int busy = 0;                      // proofs in flight on it: a busy circuit is never trimmed, evicted or replaced
     };
@@ -1727,13 +1787,16 @@ int ug_groth16_shard_ranges(unsigned long long n_vars, unsigned long long n_publ
 }
 int ug_groth16_prover_create_sharded_slices(void** prover_object, const void* zkey_header, unsigned long long zkey_header_size,
                                             const void* coefs, unsigned long long n_coefs, const void* points_a, const void* points_b1,
-                                            const void* points_b2, const void* points_c, const void* points_h, int device, int shard_rank,
+                                            const void* points_b2, const void* points_c, const void* points_h,
+                                            const unsigned long long slice_bytes[5], int device, int shard_rank,
                                             int shard_count, const unsigned long long* witness_range, char* error_msg,
                                             unsigned long long error_msg_maxsize) {
     API_TRY
     if (prover_object == NULL) throw std::invalid_argument("Null prover object");
     if (zkey_header == NULL) throw std::invalid_argument("Null zkey buffer");
+    if (slice_bytes == NULL) throw std::invalid_argument("Null slice sizes");
     Groth16Prover::Sources src;
+    src.sliceBytes = slice_bytes;
     src.coefs = static_cast<const uint8_t*>(coefs); src.nCoefs = coefs ? n_coefs : 0; src.haveCoefs = coefs != NULL;
     src.pA = static_cast<const uint8_t*>(points_a); src.pB1 = static_cast<const uint8_t*>(points_b1);
     src.pB2 = static_cast<const uint8_t*>(points_b2); src.pC = static_cast<const uint8_t*>(points_c);

@@ -1,6 +1,7 @@
 // ug_api.hip -- implementation of the inner C-ABI declared in include/ultragroth_hip.h.
 // Owns device memory, the stream and the reusable workspaces; translates between the reference's byte
 // formats and the device forms; catches every exception at the boundary.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -170,8 +171,24 @@ void host_to_device(ug_ctx* c, void* dst, const void* src, size_t bytes, const S
     if (after) after(0, bytes, c->stream);
     UG_HIP(hipStreamSynchronize(c->stream));
 }
+// Test hook (ug_test_inject_fault): the `after`-th next pass through fault point `site` throws. Only in processes started
+// with ULTRAGROTH_TEST_HOOKS=1 (the same gate as the blinding hook); otherwise fault_point() is one relaxed load.
+std::atomic<int> g_fault_site{0}, g_fault_after{0};
+bool test_hooks_on() {
+    static const bool on = [] { const char* e = getenv("ULTRAGROTH_TEST_HOOKS"); return e && e[0] == '1' && !e[1]; }();
+    return on;
+}
+void fault_point(int site) {
+    if (g_fault_site.load(std::memory_order_relaxed) != site) return;
+    if (g_fault_after.fetch_sub(1) != 1) return;
+    g_fault_site.store(0);
+    throw std::runtime_error("injected fault (test hook) at site " + std::to_string(site));
+}
 struct ScopedTimer {       // stream time between construction and stop() goes to *acc -- later: see ug_ctx::Span
-    ug_ctx* c; ug_ctx::Span span;
+    ug_ctx* c; ug_ctx::Span span; bool stopped = false;
+    ScopedTimer(const ScopedTimer&) = delete;
+    ScopedTimer& operator=(const ScopedTimer&) = delete;
+    ~ScopedTimer() { if (!stopped) c->spans_free.push_back(span); }      // the timed section threw: the event pair goes back unused
     ScopedTimer(ug_ctx* c_, double* acc_) : c(c_) {
         if (c->spans_pending.size() >= 64) {        // a caller that never waits: account what has finished, without waiting
             std::vector<ug_ctx::Span> still;
@@ -188,13 +205,15 @@ struct ScopedTimer {       // stream time between construction and stop() goes t
             UG_HIP(hipEventCreate(&sp.e0)); UG_HIP(hipEventCreate(&sp.e1));
             c->spans_free.push_back(sp);
         }
-        span = c->spans_free.back(); c->spans_free.pop_back();
+        span = c->spans_free.back();
         span.acc = acc_;
         UG_HIP(hipEventRecord(span.e0, c->stream));
+        c->spans_free.pop_back();
     }
     void stop() {
         UG_HIP(hipEventRecord(span.e1, c->stream));
         c->spans_pending.push_back(span);
+        stopped = true;
     }
 };
 // after the stream has been synchronised: account the finished spans and the kernel statistics
@@ -574,6 +593,7 @@ int ug_schedule_build(ug_schedule* s, const ug_dvec* scalars, uint64_t first, ui
     if (first + count > scalars->n) throw std::invalid_argument("schedule range outside the scalar vector");
     ug_ctx* c = s->ctx;
     c->use();
+    fault_point(UG_FAULT_SCHEDULE_BUILD);
     ScopedTimer tm(c, &c->msm_ms);
     s->first = first;
     s->sched.build(scalars->data + first * 8, MsmGeometry::choose(count), c->stream);
@@ -586,6 +606,7 @@ int ug_schedule_build_tables(ug_schedule* s, const ug_dvec* scalars, uint64_t fi
     if (first + count > scalars->n) throw std::invalid_argument("schedule range outside the scalar vector");
     ug_ctx* ctx = s->ctx;
     ctx->use();
+    fault_point(UG_FAULT_SCHEDULE_BUILD);
     MsmGeometry g = MsmGeometry::choose_tables(count, c);
     ScopedTimer tm(ctx, &ctx->msm_ms);
     s->first = first;
@@ -711,18 +732,32 @@ int ug_ctx_collect(ug_ctx* c) {
     UG_TRY
     if (!c) throw std::invalid_argument("null argument");
     c->use();
-    sync_and_resolve(c);
     std::vector<ug_ctx::QueuedMsm> done;
-    done.swap(c->pending_msm);
+    done.swap(c->pending_msm);                                  // whatever happens below, nothing stays queued
+    sync_and_resolve(c);
     for (auto& q : done) {
         if (q.g2) affine_out_g2((uint8_t*)q.out, msm_collect_g2(q.pend));
         else affine_out_g1((uint8_t*)q.out, msm_collect_g1(q.pend));
     }
     UG_CATCH
 }
-// Several MSMs over one schedule, queued back to back on the stream with ONE host synchronisation at the end: the
-// latency-bound tail of one product (bucket reduction, tree sums, result copy) no longer leaves the device idle while the
-// host converts the previous result (A, B1, B2, C of src/groth16.cpp:55-64 share the witness schedule).
+// A caller that queued work (ug_msm_batch_enqueue, schedules, ug_hpoly_run) and then failed before ug_ctx_collect: waits for
+// whatever is still running on the context -- the kernels read the caller's witness buffer and write the pinned result
+// blocks -- and forgets the queued products, whose `out` pointers may be gone with the caller's stack frame. Never throws.
+void ug_ctx_abandon(ug_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipGetLastError();
+    c->pending_msm.clear();
+    try { resolve_spans(c); } catch (...) { c->spans_pending.clear(); }
+}
+int ug_test_inject_fault(int site, int after) {
+    if (!test_hooks_on()) return UG_ERROR;
+    g_fault_after.store(after < 1 ? 1 : after);
+    g_fault_site.store(site);
+    return UG_OK;
+}
 int ug_msm_batch(ug_ctx* c, int count, const ug_bases* const* bases, const ug_schedule* s, const int64_t* index_shifts,
                  void* const* outs) {
     int rc = ug_msm_batch_enqueue(c, count, bases, s, index_shifts, outs);
@@ -762,6 +797,7 @@ int ug_hpoly_run(ug_hpoly* hp, const ug_dvec* w, ug_dvec* h_out) {
     if (h_out->n < hp->domain) throw std::invalid_argument("h vector shorter than the domain");
     ug_ctx* c = hp->ctx;
     c->use();
+    fault_point(UG_FAULT_HPOLY_RUN);
     ScopedTimer tm(c, &c->fft_ms);
     hipStream_t st = c->stream;
     u64 n = hp->domain;
