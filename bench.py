@@ -479,7 +479,7 @@ def main():
     out = None
     for _ in range(args.warmup):
         out = step()
-    for which in range(3):
+    for which in range(4):
         prover.kernel_stats(which=which, reset=True)
     msm_ms = fft_ms = upload_ms = 0.0
     host_threads = max(1, args.host_threads) if world == 1 else 1
@@ -549,11 +549,14 @@ def main():
         acc_ms, launches, entries = prover.kernel_stats(which=0)
         g2_ms, g2_launches, g2_entries = prover.kernel_stats(which=1)
         ntt_ms, ntt_launches, ntt_points = prover.kernel_stats(which=2)
+        grp_ms, grp_launches, grp_entries = prover.kernel_stats(which=3)       # A | B1 | C in one launch (three products per entry)
         ws = witness_slice(info, 0, world)
         n_local = (ws[1] - ws[0]) if ws else info["nVars"] // world
         # Algorithmic bytes per launch (restated in DESIGN.md): G1 accumulation 96 B per point of
         # the slice (64 B affine base + 32 B scalar, each read once), G2 160 B per point, one NTT pass 64 B per point
         g1_bytes, g2_bytes, ntt_bytes = 96.0 * n_local, 160.0 * n_local, 64.0 * info["domainSize"]
+        # the group launch reads three 64-byte bases and one 32-byte scalar per point: 224 B per point
+        grp_bytes = 224.0 * n_local
 
         def gbs(nbytes, ms):
             return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -609,6 +612,11 @@ def main():
                                  "frac": gbs(g2_bytes, g2_ms) / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": g2_bytes,
                                  "avg_launch_ms": g2_ms, "launches": g2_launches,
                                  "issue_bound_frac": mads(4470.0, g2_entries, g2_launches, g2_ms) / 29.0},
+                             "segment_accumulate_group_kernel<3>": {
+                                 "bound": "hbm", "achieved": gbs(grp_bytes, grp_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": gbs(grp_bytes, grp_ms) / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": grp_bytes,
+                                 "avg_launch_ms": grp_ms, "launches": grp_launches, "products_per_launch": 3,
+                                 "issue_bound_frac": mads(1467.0, grp_entries, grp_launches, grp_ms) / 29.0},
                              "ntt_pass_kernel": {
                                  "bound": "hbm", "achieved": gbs(ntt_bytes, ntt_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": gbs(ntt_bytes, ntt_ms) / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ntt_bytes,

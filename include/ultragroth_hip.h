@@ -154,6 +154,18 @@ int  ug_msm_batch(ug_ctx* ctx, int count, const ug_bases* const* bases, const ug
  * the device: what is queued on `waiter` afterwards starts when what was queued on `signal` before has finished. */
 int  ug_msm_batch_enqueue(ug_ctx* ctx, int count, const ug_bases* const* bases, const ug_schedule* schedule,
                           const int64_t* index_shifts, void* const* outs);
+/* A GROUP of 2 or 3 G1 base sets that are always multiplied by the same scalars -- A, B1 and C of a Groth16 proof
+ * (src/groth16.cpp:55,58,64 all read the witness; C with its index shift), A and B1 of an UltraGroth one -- kept as ONE array
+ * of K-point records, so that the accumulation kernel reads the entry list once and gathers the K points of an entry from
+ * adjacent memory. Member m brings n[m] points (zkey format), the first of which belongs to the scalar with global index
+ * first[m]; the group covers scalars [group_first, group_first + slots), a slot a member has no point for is infinity.
+ * table_c != 0: with fixed-base window tables of that width (as ug_bases_create_tables_g1). ug_msm_group_enqueue queues the K
+ * products over a schedule (results in outs[m], 64 bytes each, after ug_ctx_collect); the schedule's range must lie in the
+ * group's. ug_bases_destroy / _precompute / _drop_tables / _table_window accept a group. */
+int  ug_bases_create_group_g1(ug_ctx* ctx, int members, const void* const* host_points, const uint64_t* n, const uint64_t* first,
+                              uint64_t group_first, uint64_t slots, int table_c, ug_bases** out);
+int  ug_bases_members(const ug_bases* bases);
+int  ug_msm_group_enqueue(ug_ctx* ctx, const ug_bases* group, const ug_schedule* schedule, void* const* outs);
 int  ug_ctx_collect(ug_ctx* ctx);
 int  ug_ctx_wait(ug_ctx* waiter, ug_ctx* signal);
 /* For a caller that queued work and then failed before ug_ctx_collect: waits for what is still running on the context (the

@@ -41,6 +41,35 @@ def fixed_rs():
     return r, s
 
 
+def _cpu_share():
+    """CPU threads this process may really use: the affinity mask capped by the cgroup CPU quota (as bench.py's cpu_share)"""
+    cores = len(os.sched_getaffinity(0))
+    for quota_file, period_file in (("/sys/fs/cgroup/cpu.max", None),
+                                    ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:
+            if period_file is None:
+                quota, period = open(quota_file).read().split()
+            else:
+                quota, period = open(quota_file).read().strip(), open(period_file).read().strip()
+            if quota not in ("max", "-1"):
+                cores = max(1, min(cores, int(quota) // int(period)))
+        except (OSError, ValueError):
+            pass
+    return cores
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_threads():
+    """the oracle's OpenMP loops with as many threads as this process may use and no more: a GPU box shows every core of the
+    host, and its default -- one thread per visible core under a 16-core quota -- made the full-size H polynomials 3x slower"""
+    try:
+        import oracle as O
+        O.lib.ugo_set_num_threads(max(1, min(_cpu_share(), 32)))
+    except Exception:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def device():
     # torch bundles its own HIP runtime: when a test uses both, torch must initialise first (as bench.py does),

@@ -226,6 +226,45 @@ def test_msm_batch_equals_single_products(device, zkey, wtns):
         assert device.msm_batch([(b2, True)], s) == [got[2]]
 
 
+@pytest.mark.parametrize("rotate", ["0", "1"])
+def test_msm_group_equals_single_products(device, zkey, wtns, rotate, monkeypatch):
+    """ug_bases_create_group_g1 + ug_msm_group_enqueue: A, B1 and C of the fixture as ONE interleaved array of three-point
+    records (C with its index shift folded into the slots: the first nPublic + 1 slots hold infinity for it), one
+    accumulation launch with three accumulators per lane == the three separate products == the oracle; with and without
+    window tables, on sub-ranges (a sharded rank's slice, C cut by the slice), the two-member form (UltraGroth's A, B1), and
+    both code shapes of the kernel (UG_GROUP_ROTATE)"""
+    import ultragroth_amd as ug
+    monkeypatch.setenv("UG_GROUP_ROTATE", rotate)
+    info = O.zkey_info(zkey)
+    n, shift = info["nVars"], info["nPublic"] + 1
+    A, B1, Cs = _sec(zkey, "zkey", 5), _sec(zkey, "zkey", 6), _sec(zkey, "zkey", 8)
+    wb = _sec(wtns, "wtns", 2)
+    w = device.dvec(n, wb)
+    exp = [O.g1_msm(A, wb, n), O.g1_msm(B1, wb, n), O.g1_msm(Cs, wb[shift * 32:], n - shift)]
+    for c in (0, 16, 18):
+        g = device.bases_group([(A, n, 0), (B1, n, 0), (Cs, n - shift, shift)], 0, n, table_c=c)
+        s = device.schedule(w, 0, n, table_c=c)
+        assert device.msm_group(g, s) == exp, c
+        assert device.msm_group(g, s) == exp                               # the workspace is reused
+        g2 = device.bases_group([(A, n, 0), (B1, n, 0)], 0, n, table_c=c)
+        assert device.msm_group(g2, s) == exp[:2]
+        with pytest.raises(ug.DeviceError, match="ug_msm_group_enqueue"):
+            device.msm(g, s)
+    # a slice [lo, hi) of the scalars, as a sharded rank holds it: the group starts at lo, C's slice is cut by the shift
+    for lo, hi in ((0, 1), (1, 500), (500, n), (0, 2), (3, 3)):
+        c_lo, c_hi = max(lo - shift, 0), max(hi - shift, 0)
+        g = device.bases_group([(A[lo * 64:hi * 64], hi - lo, lo), (B1[lo * 64:hi * 64], hi - lo, lo),
+                                (Cs[c_lo * 64:c_hi * 64], c_hi - c_lo, c_lo + shift)], lo, hi - lo)
+        s = device.schedule(w, lo, hi - lo)
+        sl = wb[lo * 32:hi * 32]
+        assert device.msm_group(g, s) == [O.g1_msm(A[lo * 64:hi * 64], sl, hi - lo), O.g1_msm(B1[lo * 64:hi * 64], sl, hi - lo),
+                                          O.g1_msm(Cs[c_lo * 64:c_hi * 64], wb[(c_lo + shift) * 32:(c_hi + shift) * 32], c_hi - c_lo)], (lo, hi)
+    with pytest.raises(ug.DeviceError, match="outside the group"):
+        device.bases_group([(A, n, 0), (B1, n, 1)], 0, n)
+    with pytest.raises(ug.DeviceError, match="2 or 3 members"):
+        device.bases_group([(A, n, 0)], 0, n)
+
+
 def test_hpoly_matches_oracle_and_known_answers(device, zkey, wtns):
     info = O.zkey_info(zkey)
     coefs = _sec(zkey, "zkey", 4)[4:]

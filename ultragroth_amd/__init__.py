@@ -495,6 +495,27 @@ class Device:
             _check(self._L.ug_bases_precompute(h, table_c))
         return b
 
+    def bases_group(self, members, group_first, slots, table_c=0):
+        """ug_bases_create_group_g1: members = [(points bytes, n, first scalar index), ...] (2 or 3 G1 sets sharing their scalars)"""
+        k = len(members)
+        keep = [_buf(bytes(p)) if not isinstance(p, C.Array) else p for p, _, _ in members]
+        hosts = (C.c_void_p * k)(*[C.cast(b, C.c_void_p) for b in keep])
+        ns = (C.c_uint64 * k)(*[n for _, n, _ in members])
+        firsts = (C.c_uint64 * k)(*[f for _, _, f in members])
+        h = C.c_void_p()
+        _check(self._L.ug_bases_create_group_g1(self._h, k, hosts, ns, firsts, group_first, slots, table_c, C.byref(h)))
+        g = _Handle(h, self._L.ug_bases_destroy, self)
+        g.members = k
+        return g
+
+    def msm_group(self, group, schedule):
+        """the K sums of a base group over a schedule (ug_msm_group_enqueue + ug_ctx_collect): K affine records"""
+        outs = [C.create_string_buffer(64) for _ in range(group.members)]
+        arr = (C.c_void_p * group.members)(*[C.cast(o, C.c_void_p) for o in outs])
+        _check(self._L.ug_msm_group_enqueue(self._h, group.h, schedule.h, arr))
+        _check(self._L.ug_ctx_collect(self._h))
+        return [o.raw for o in outs]
+
     def dvec(self, n, data=None):
         h = C.c_void_p()
         _check(self._L.ug_dvec_create(self._h, n, C.byref(h)))

@@ -250,6 +250,17 @@ __global__ __launch_bounds__(1024) void bucket_counts_kernel(u32* start, u32* co
     }
 }
 
+// compile-time loop: the bodies below are far above the compiler's pragma-unroll budget, and a rolled loop would
+// index the per-point arrays dynamically, i.e. keep them in scratch memory
+template <int I, int N> struct StaticFor {
+    template <class Fn> static __device__ __forceinline__ void up(Fn&& f) { f(std::integral_constant<int, I>()); StaticFor<I + 1, N>::up(f); }
+    template <class Fn> static __device__ __forceinline__ void down(Fn&& f) { StaticFor<I + 1, N>::down(f); f(std::integral_constant<int, I>()); }
+};
+template <int N> struct StaticFor<N, N> {
+    template <class Fn> static __device__ __forceinline__ void up(Fn&&) {}
+    template <class Fn> static __device__ __forceinline__ void down(Fn&&) {}
+};
+
 // ---- 4. bucket accumulation -----------------------------------------------------------------------------
 // Balanced, segmented form: the sorted entry list is cut into equal segments of 2^log_seg entries, one
 // lane per segment, so every lane of a wave performs the same number of mixed additions whatever the
@@ -358,6 +369,102 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Cfg::ACC_WA
     else if (end_open) dst = slot_pts + (size_t)(2 * t + 1) * Cfg::PT_WORDS;
     else dst = bucket_pts + (size_t)cur * Cfg::PT_WORDS;
     Cfg::to_words(dst, acc, 1);
+}
+
+// The same walk for a GROUP of K G1 base sets that are multiplied by the same scalars (A, B1 and C of a Groth16 proof, A and
+// B1 of an UltraGroth one: src/groth16.cpp:55,58,64 all read the witness), stored as ONE array of K-point records
+// [set0_i | set1_i | ...] (K * 64 bytes; a slot without a point holds the all-zero record, infinity; window table j starts
+// j * n_slots records in). One lane keeps K accumulators and adds the K points of every entry, so the entry list is read
+// once instead of K times, run boundaries and loop control are paid once, and a gather touches K adjacent 64-byte pieces --
+// a third (half) of the DRAM row activations that K separate tables cost (1.9 ms of a 15 ms launch are
+// the row rate of random 64-byte reads). 3 * 36 accumulator registers put the kernel at two waves per SIMD, where the bare
+// addition runs as fast as at three (profiles/r02_ubench_madd.txt). Only ONE 16-register record is in flight: the loads
+// rotate through the members -- while member m is added, member m + 1 (or member 0 of the next entry) is on its way, a whole
+// mixed addition (3 us) ahead of its use.
+// ROTATE: the K additions are one rolled loop over accumulator 0 with the accumulators rotated between turns (one
+// addition's code instead of K copies of it in the loop body).
+template <int K, bool ROTATE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void segment_accumulate_group_kernel(
+        const u32* __restrict__ bases, u64 n_slots, int64_t delta, const u32* __restrict__ keys, const u32* __restrict__ tkeys,
+        const u32* __restrict__ tvals, const u32* __restrict__ meta, int log_a, int log_b, u32* __restrict__ bucket_pts,
+        u32* __restrict__ slot_pts, size_t bucket_stride, size_t slot_stride) {
+    typedef G1Cfg Cfg;
+    typedef Fq F;
+    const u32 n_valid = meta[1];
+    const SegMap map = SegMap::make(n_valid, log_a, log_b);
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u64 lo = map.first_entry(t);
+    if (lo >= n_valid) return;
+    u64 hi = lo + ((u64)1 << map.log_len(t));
+    if (hi > n_valid) hi = n_valid;
+    const u32 cnt = (u32)(hi - lo);
+    const u64 tbase = map.transposed(t, 0);
+    u32 cur = tkeys[tbase];
+    bool first_run = true;
+    const bool start_open = lo > 0 && keys[lo - 1] == cur;
+    XYZZ<F> acc[K];
+    StaticFor<0, K>::up([&](auto m) { acc[m] = xyzz_inf<F>(); });
+    const u32 IDX_MASK = (1u << TABLE_INDEX_BITS) - 1;
+    auto record = [&](u32 val, int64_t idx, int m) -> const u32* {
+        return bases + (((u64)((val >> TABLE_INDEX_BITS) & 15u) * n_slots + (u64)idx) * K + (u64)m) * Cfg::AFF_WORDS;
+    };
+    auto flush = [&](bool to_slot, size_t slot, u32 bucket) {
+        StaticFor<0, K>::up([&](auto m) {
+            u32* dst = to_slot ? slot_pts + (size_t)m * slot_stride + slot * Cfg::PT_WORDS
+                               : bucket_pts + (size_t)m * bucket_stride + (size_t)bucket * Cfg::PT_WORDS;
+            Cfg::to_words(dst, acc[m], 1);
+            acc[m] = xyzz_inf<F>();
+        });
+    };
+    u32 raw[Cfg::AFF_WORDS];
+    u32 nkey = cur, nval = tvals[tbase];
+    int64_t nidx = (int64_t)(nval & IDX_MASK) + delta;
+    bool nin = nidx >= 0 && (u64)nidx < n_slots;
+    if (nin) Cfg::load_raw(raw, record(nval, nidx, 0));
+    for (u32 k = 0; k < cnt; k++) {
+        const u32 key = nkey, val = nval;
+        const int64_t idx = nidx;
+        const bool in = nin;
+        const bool more = k + 1 < cnt;
+        if (more) {
+            nkey = tkeys[tbase + ((u64)(k + 1) << 6)];
+            nval = tvals[tbase + ((u64)(k + 1) << 6)];
+            nidx = (int64_t)(nval & IDX_MASK) + delta;
+            nin = nidx >= 0 && (u64)nidx < n_slots;
+        }
+        if (key != cur) {                          // the previous run ended inside the segment
+            flush(first_run && start_open, (size_t)2 * t, cur);
+            cur = key;
+            first_run = false;
+        }
+        if constexpr (ROTATE) {
+#pragma unroll 1
+            for (int m = 0; m < K; m++) {
+                F x, y;
+                const bool valid = in && Cfg::decode_affine(raw, x, y);
+                if (m + 1 < K) { if (in) Cfg::load_raw(raw, record(val, idx, m + 1)); }
+                else if (more && nin) Cfg::load_raw(raw, record(nval, nidx, 0));
+                if (valid && (val >> 31)) y = neg<1>(y);
+                if (valid) acc[0] = xyzz_madd(acc[0], x, y);
+                XYZZ<F> turn = acc[0];
+                StaticFor<0, K - 1>::up([&](auto q) { acc[q] = acc[q + 1]; });
+                acc[K - 1] = turn;
+            }
+        } else {
+            StaticFor<0, K>::up([&](auto m) {
+                F x, y;
+                const bool valid = in && Cfg::decode_affine(raw, x, y);
+                if (m + 1 < K) { if (in) Cfg::load_raw(raw, record(val, idx, m + 1)); }
+                else if (more && nin) Cfg::load_raw(raw, record(nval, nidx, 0));
+                if (valid && (val >> 31)) y = neg<1>(y);
+                if (valid) acc[m] = xyzz_madd(acc[m], x, y);
+            });
+        }
+    }
+    const bool end_open = hi < n_valid && keys[hi] == cur;
+    if (first_run && start_open) flush(true, (size_t)2 * t, 0);
+    else if (end_open) flush(true, (size_t)2 * t + 1, 0);
+    else flush(false, 0, cur);
 }
 
 // piece k of a bucket whose entries start in segment `first`: k = 0 is the end-cut run of `first`,
@@ -565,18 +672,15 @@ __global__ void convert_coords_kernel(u32* pts, u64 n_coords_groups, int coords_
     }
 }
 
-// ---- fixed-base window tables ------------------------------------------------------------------------------
-// compile-time loop: the bodies below are far above the compiler's pragma-unroll budget, and a rolled loop would
-// index the per-point arrays dynamically, i.e. keep them in scratch memory
-template <int I, int N> struct StaticFor {
-    template <class Fn> static __device__ __forceinline__ void up(Fn&& f) { f(std::integral_constant<int, I>()); StaticFor<I + 1, N>::up(f); }
-    template <class Fn> static __device__ __forceinline__ void down(Fn&& f) { StaticFor<I + 1, N>::down(f); f(std::integral_constant<int, I>()); }
-};
-template <int N> struct StaticFor<N, N> {
-    template <class Fn> static __device__ __forceinline__ void up(Fn&&) {}
-    template <class Fn> static __device__ __forceinline__ void down(Fn&&) {}
-};
+// records of one member set -> their places in a group array: dst record (slot0 + i) * members + member  (64-byte G1 records)
+__global__ void interleave_records_kernel(u32* __restrict__ dst, const u32* __restrict__ src, u64 n, int members, int member, u64 slot0) {
+    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;       // one 16-byte quarter of a record per lane
+    if (g >= n * 4) return;
+    const u64 i = g >> 2, part = g & 3;
+    reinterpret_cast<uint4*>(dst + ((slot0 + i) * (u64)members + (u64)member) * 16)[part] = reinterpret_cast<const uint4*>(src + i * 16)[part];
+}
 
+// ---- fixed-base window tables ------------------------------------------------------------------------------
 // pts holds `tables` tables of n affine records; table 0 is given, table j = 2^(c j) * table 0. A lane carries K
 // consecutive points through c doublings per table and shares one field inversion among them for the conversion
 // back to affine (Montgomery's trick); infinity stays (0,0) in every table.
@@ -839,9 +943,11 @@ namespace {
 // is bound by its arithmetic (two full additions per bucket and a scalar multiple per chunk), not by latency, and gains
 // only through the longer chunks a batch allows (reduce_chunk).
 constexpr int MSM_MAX_BATCH = 4;
+// group: 0 = `count` separate base arrays; K = bases[0] is ONE interleaved array of K-member records (n_bases[0] slots; count
+// == K): a single launch of segment_accumulate_group_kernel accumulates all K products
 template <class Cfg>
 void msm_enqueue_multi(const MsmSchedule& s, MsmWorkspace& ws, int count, const u32* const* bases, const u64* n_bases, const int64_t* delta,
-                       hipStream_t stream, MsmStats* stats, u32* const* pinned_host, MsmPending* pend) {
+                       hipStream_t stream, MsmStats* stats, u32* const* pinned_host, MsmPending* pend, int group = 0) {
     typedef typename Cfg::F F;
     const MsmGeometry& g = s.geo;
     if (count < 1 || count > MSM_MAX_BATCH) throw std::logic_error("msm: batch size");
@@ -851,7 +957,7 @@ void msm_enqueue_multi(const MsmSchedule& s, MsmWorkspace& ws, int count, const 
         pend[j] = MsmPending();
         pend[j].g2 = Cfg::PT_WORDS == G2Cfg::PT_WORDS;
         pend[j].c = g.c; pend[j].bucket_windows = g.bucket_windows(); pend[j].host = pinned_host[j];
-        if (g.n == 0 || n_bases[j] == 0) continue;
+        if (g.n == 0 || n_bases[group ? 0 : j] == 0) continue;
         if ((size_t)pend[j].bucket_windows * Cfg::PT_WORDS > MSM_PENDING_WORDS) throw std::logic_error("msm: result block too large");
         pend[j].empty = false;
         live[k++] = j;
@@ -868,7 +974,26 @@ void msm_enqueue_multi(const MsmSchedule& s, MsmWorkspace& ws, int count, const 
     // word strides between the arrays of consecutive products
     const size_t bucket_stride = (size_t)g.total_buckets() * Cfg::PT_WORDS, slot_stride = (size_t)nseg * 2 * Cfg::PT_WORDS,
                  task_stride = (size_t)tasks_max * Cfg::PT_WORDS;
-    for (int q = 0; q < k; q++) {
+    if constexpr (Cfg::PT_WORDS == G1Cfg::PT_WORDS) {
+        if (group) {                                 // (all K products are live, or none: they share the slot count)
+            const char* rot = getenv("UG_GROUP_ROTATE");                      // tuning knob, read per launch (the tests take both shapes)
+            const bool rotate = rot && atoi(rot) != 0;
+            int slot = stats ? stats->begin(stream, g.n * g.windows * (u64)group) : -1;
+            if (nseg) {
+                const dim3 grid((unsigned)((nseg + 255) / 256)), block(256);
+#define UG_GROUP_LAUNCH(K_, R_) hipLaunchKernelGGL((segment_accumulate_group_kernel<K_, R_>), grid, block, 0, stream, bases[0], n_bases[0], \
+                                                   delta[0], s.keys, s.tkeys, s.tvals, s.meta, s.log_seg, s.log_seg_tail, ws.bucket_pts, ws.slot_pts,   \
+                                                   bucket_stride, slot_stride)
+                if (group == 3) { if (rotate) UG_GROUP_LAUNCH(3, true); else UG_GROUP_LAUNCH(3, false); }
+                else if (group == 2) { if (rotate) UG_GROUP_LAUNCH(2, true); else UG_GROUP_LAUNCH(2, false); }
+                else throw std::logic_error("msm: group size");
+#undef UG_GROUP_LAUNCH
+                UG_KERNEL_CHECK();
+            }
+            if (stats) stats->end(slot, stream);
+        }
+    } else if (group) throw std::logic_error("msm: groups are G1 only");
+    for (int q = 0; q < (group ? 0 : k); q++) {
         const int j = live[q];
         int slot = stats ? stats->begin(stream, g.n * g.windows) : -1;
         if (nseg) {
@@ -1010,6 +1135,14 @@ void msm_enqueue_batch_g2(const MsmSchedule& s, MsmWorkspace& ws, int count, con
                           hipStream_t stream, MsmStats* stats, u32* const* pinned_host, MsmPending* pend) {
     msm_enqueue_multi<G2Cfg>(s, ws, count, bases, n_bases, delta, stream, stats, pinned_host, pend);
 }
+void msm_enqueue_group_g1(const MsmSchedule& s, MsmWorkspace& ws, int members, const u32* bases, u64 n_slots, int64_t delta, hipStream_t stream,
+                          MsmStats* stats, u32* const* pinned_host, MsmPending* pend) {
+    if (members < 2 || members > 3) throw std::invalid_argument("msm: a base group has 2 or 3 members");
+    const u32* b[MSM_MAX_BATCH] = {bases, bases, bases, bases};
+    const u64 n[MSM_MAX_BATCH] = {n_slots, n_slots, n_slots, n_slots};
+    const int64_t d[MSM_MAX_BATCH] = {delta, delta, delta, delta};
+    msm_enqueue_multi<G1Cfg>(s, ws, members, b, n, d, stream, stats, pinned_host, pend, members);
+}
 G1XYZZ msm_collect_g1(const MsmPending& p) { return msm_collect<G1Cfg>(p); }
 G2XYZZ msm_collect_g2(const MsmPending& p) { return msm_collect<G2Cfg>(p); }
 
@@ -1069,6 +1202,11 @@ void build_window_tables(bool g2, u32* pts, u64 n, int c, int tables, hipStream_
     UG_KERNEL_CHECK();
 }
 
+void interleave_points_g1(u32* dst, const u32* src, u64 n, int members, int member, u64 slot0, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(interleave_records_kernel, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, stream, dst, src, n, members, member, slot0);
+    UG_KERNEL_CHECK();
+}
 void convert_points_g1(u32* pts, u64 n, hipStream_t stream) {
     if (!n) return;
     hipLaunchKernelGGL(convert_coords_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pts, n, 2);

@@ -219,6 +219,9 @@ struct DeviceProver {
     ug_ctx* ctx = nullptr;
     ug_ctx* ctx2 = nullptr;      // second stream (Groth16): the H-polynomial branch runs beside the witness MSMs
     ug_bases *A = nullptr, *B1 = nullptr, *B2 = nullptr, *C = nullptr, *H = nullptr, *roundC = nullptr;
+    ug_bases* G = nullptr;       // the G1 sets that share the witness scalars as ONE interleaved group ([A | B1 | C] for Groth16,
+                                 // [A | B1] for UltraGroth; A, B1 (and C) are then null): one gather and one accumulation
+                                 // launch for all of them (ug_bases_create_group_g1). ULTRAGROTH_FUSED=0 keeps separate sets.
     ug_hpoly* hp = nullptr;
     ug_dvec *w = nullptr, *h = nullptr, *aux = nullptr;
     ug_dvec* w2 = nullptr;       // second witness buffer (Groth16): the next proof's witness is staged here while a proof runs
@@ -231,7 +234,7 @@ struct DeviceProver {
         ug_dvec_destroy(w); ug_dvec_destroy(w2); ug_dvec_destroy(h); ug_dvec_destroy(aux);
         ug_hpoly_destroy(hp);
         ug_bases_destroy(A); ug_bases_destroy(B1); ug_bases_destroy(B2); ug_bases_destroy(C); ug_bases_destroy(H);
-        ug_bases_destroy(roundC);
+        ug_bases_destroy(roundC); ug_bases_destroy(G);
         ug_ctx_destroy(ctx);
         ug_ctx_destroy(ctx2);
     }
@@ -385,6 +388,32 @@ std::vector<int> planTableWidthsAhead(ug_ctx* ctx, const std::vector<TableGroup>
     ugCheck(ug_ctx_mem_info(ctx, &freeB, &totalB));
     if (need + workspace + otherBytes > freeB) return none;
     return width;
+}
+bool fusedGroups() {
+    const char* e = getenv("ULTRAGROTH_FUSED");
+    return !(e && e[0] == '0');
+}
+// The witness products of one schedule, queued on ctx (results after ug_ctx_collect): the G1 sets -- as the interleaved group
+// d.G when the prover holds one (outC null: a two-member group), else d.A, d.B1 and, with outC, d.C shifted by shiftC --
+// and the G2 set d.B2; g2First queues the G2 product ahead of the G1 ones.
+void enqueueWitnessProducts(DeviceProver& d, ug_ctx* ctx, const ug_schedule* sw, uint8_t* outA, uint8_t* outB1, uint8_t* outB2, uint8_t* outC,
+                            int64_t shiftC, bool g2First) {
+    auto g2 = [&] {
+        const ug_bases* sets[1] = {d.B2};
+        void* outs[1] = {outB2};
+        ugCheck(ug_msm_batch_enqueue(ctx, 1, sets, sw, nullptr, outs));
+    };
+    if (g2First) g2();
+    if (d.G) {
+        void* outs[3] = {outA, outB1, outC};
+        ugCheck(ug_msm_group_enqueue(ctx, d.G, sw, outs));
+    } else {
+        const ug_bases* sets[3] = {d.A, d.B1, d.C};
+        const int64_t shifts[3] = {0, 0, shiftC};
+        void* outs[3] = {outA, outB1, outC};
+        ugCheck(ug_msm_batch_enqueue(ctx, outC ? 3 : 2, sets, sw, shifts, outs));
+    }
+    if (!g2First) g2();
 }
 void buildSchedule(ug_schedule* s, const ug_dvec* scalars, uint64_t first, uint64_t count, int tableC) {
     if (tableC) ugCheck(ug_schedule_build_tables(s, scalars, first, count, tableC));
@@ -601,17 +630,32 @@ private:
             }
             ugCheck(g2 ? ug_bases_create_g2(ctx, pts, n, first, out) : ug_bases_create_g1(ctx, pts, n, first, out));
         };
-        create(d_.ctx, false, pA, nw, wr_.lo, ahead[0], &d_.A);
-        create(d_.ctx, false, pB1, nw, wr_.lo, ahead[0], &d_.B1);
+        if (fusedGroups()) {
+            // A, B1 and C (with its index shift folded into the slot numbers) as one interleaved group
+            const void* hosts[3] = {pA, pB1, pC};
+            const uint64_t counts[3] = {nw, nw, cHi - cLo}, firsts[3] = {wr_.lo, wr_.lo, cLo + hdr_.nPublic + 1};
+            int rc = UG_ERROR;
+            if (ahead[0]) rc = ug_bases_create_group_g1(d_.ctx, 3, hosts, counts, firsts, wr_.lo, nw, ahead[0], &d_.G);
+            if (rc != UG_OK) {
+                if (ahead[0]) withTables = false;           // memory ran short after all
+                ugCheck(ug_bases_create_group_g1(d_.ctx, 3, hosts, counts, firsts, wr_.lo, nw, 0, &d_.G));
+            }
+        } else {
+            create(d_.ctx, false, pA, nw, wr_.lo, ahead[0], &d_.A);
+            create(d_.ctx, false, pB1, nw, wr_.lo, ahead[0], &d_.B1);
+        }
         create(d_.ctx, true, pB2, nw, wr_.lo, ahead[0], &d_.B2);
-        create(d_.ctx, false, pC, cHi - cLo, cLo, ahead[0], &d_.C);
+        if (!d_.G) create(d_.ctx, false, pC, cHi - cLo, cLo, ahead[0], &d_.C);
         const bool group0 = withTables && ahead[0];
         create(d_.ctx2, false, pH, nh, hr_.lo, ahead[1], &d_.H);
         const bool group1 = withTables && ahead[1];
-        if (ahead[0] && !group0) { ug_bases_drop_tables(d_.A); ug_bases_drop_tables(d_.B1); ug_bases_drop_tables(d_.B2); ug_bases_drop_tables(d_.C); }
+        if (ahead[0] && !group0) {
+            for (ug_bases* b : {d_.G, d_.A, d_.B1, d_.B2, d_.C}) if (b) ug_bases_drop_tables(b);
+        }
         tableW_ = group0 ? ahead[0] : 0;
         tableH_ = group1 ? ahead[1] : 0;
-        if (group0) tableBytes += ug_bases_tables_bytes(nw, 0, tableW_) * 2 + ug_bases_tables_bytes(nw, 1, tableW_) + ug_bases_tables_bytes(cHi - cLo, 0, tableW_);
+        if (group0) tableBytes += (d_.G ? ug_bases_tables_bytes(3 * nw, 0, tableW_) : ug_bases_tables_bytes(nw, 0, tableW_) * 2 + ug_bases_tables_bytes(cHi - cLo, 0, tableW_)) +
+                                  ug_bases_tables_bytes(nw, 1, tableW_);
         if (group1) tableBytes += ug_bases_tables_bytes(nh, 0, tableH_);
         if (haveHpoly_) ugCheck(ug_hpoly_create(d_.ctx2, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
         ugCheck(ug_dvec_create(d_.ctx, M, &d_.w));
@@ -627,7 +671,8 @@ private:
 public:
     std::vector<TableGroup> tableGroups() override {
         std::vector<TableGroup> groups(2);
-        groups[0].g1 = {d_.A, d_.B1, d_.C}; groups[0].n1 = {wr_.hi - wr_.lo, wr_.hi - wr_.lo, cHi_ - cLo_};
+        if (d_.G || (!d_.A && fusedGroups())) { groups[0].g1 = {d_.G}; groups[0].n1 = {3 * (wr_.hi - wr_.lo)}; }      // (also before the sets exist)
+        else { groups[0].g1 = {d_.A, d_.B1, d_.C}; groups[0].n1 = {wr_.hi - wr_.lo, wr_.hi - wr_.lo, cHi_ - cLo_}; }
         groups[0].g2 = {d_.B2}; groups[0].n2 = {wr_.hi - wr_.lo};
         groups[0].scalars = wr_.hi - wr_.lo; groups[0].c = &tableW_;
         if (wr_.hi - wr_.lo > maxRange_) groups[0].scalars = 0;          // proved in pieces: classic windows per piece
@@ -753,10 +798,8 @@ public:
             memset(part, 0, sizeof part);
             buildSchedule(d_.sw, wCur_, lo, n, tableW_);
             // S1-S4 (src/groth16.cpp:55,58,61,64): A, B1, B2, C over the witness schedule, queued back to back
-            const ug_bases* sets[4] = {d_.A, d_.B1, d_.B2, d_.C};
-            const int64_t shifts[4] = {0, 0, 0, (int64_t)hdr_.nPublic + 1};
-            void* outs[4] = {out, out + 64, out + 128, out + 256};
-            ugCheck(ug_msm_batch(d_.ctx, 4, sets, d_.sw, shifts, outs));
+            enqueueWitnessProducts(d_, d_.ctx, d_.sw, out, out + 64, out + 128, out + 256, (int64_t)hdr_.nPublic + 1, false);
+            ugCheck(ug_ctx_collect(d_.ctx));
             if (out == part && ug_groth16_partials_add(partials, part) != PROVER_OK) throw std::runtime_error("partial sum failed");
         }
         inFlight.done();
@@ -847,13 +890,8 @@ public:
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
         QueueGuard inFlight(d_.ctx, d_.ctx2);                   // from here to the collects below work is queued on both streams
         buildSchedule(d_.sw, wCur_, wr_.lo, nw, tableW_);
-        {   // S1-S4 (src/groth16.cpp:55,58,61,64): A, B1, B2, C over the witness schedule, queued back to back
-            const ug_bases* sets[4] = {d_.A, d_.B1, d_.B2, d_.C};
-            const int64_t shifts[4] = {0, 0, 0, (int64_t)hdr_.nPublic + 1};
-            void* outs[4] = {partials, partials + 64, partials + 128, partials + 256};
-            if (overlap == 2) { std::swap(sets[0], sets[2]); std::swap(outs[0], outs[2]); }        // B2, B1, A, C
-            ugCheck(ug_msm_batch_enqueue(d_.ctx, 4, sets, d_.sw, shifts, outs));
-        }
+        // S1-S4 (src/groth16.cpp:55,58,61,64): A, B1, B2, C over the witness schedule, queued back to back
+        enqueueWitnessProducts(d_, d_.ctx, d_.sw, partials, partials + 64, partials + 128, partials + 256, (int64_t)hdr_.nPublic + 1, overlap == 2);
         if (overlap == 0) ugCheck(ug_ctx_wait(d_.ctx2, d_.ctx));
         ugCheck(ug_hpoly_run(d_.hp, wCur_, d_.h));                                              // S5-S9 :66-148
         buildSchedule(d_.sh, d_.h, hr_.lo, nh, tableH_);
@@ -976,8 +1014,14 @@ public:
         for (uint32_t i : finalIdx_) if (i >= M) throw std::range_error("final round index outside the witness");
 
         ugCheck(ug_ctx_create(&d_.ctx, device));
-        ugCheck(ug_bases_create_g1(d_.ctx, pA + wr_.lo * 64, wr_.hi - wr_.lo, wr_.lo, &d_.A));
-        ugCheck(ug_bases_create_g1(d_.ctx, pB1 + wr_.lo * 64, wr_.hi - wr_.lo, wr_.lo, &d_.B1));
+        if (fusedGroups()) {                            // A and B1 share the witness scalars: one interleaved group
+            const void* hosts[2] = {pA + wr_.lo * 64, pB1 + wr_.lo * 64};
+            const uint64_t counts[2] = {wr_.hi - wr_.lo, wr_.hi - wr_.lo}, firsts[2] = {wr_.lo, wr_.lo};
+            ugCheck(ug_bases_create_group_g1(d_.ctx, 2, hosts, counts, firsts, wr_.lo, wr_.hi - wr_.lo, 0, &d_.G));
+        } else {
+            ugCheck(ug_bases_create_g1(d_.ctx, pA + wr_.lo * 64, wr_.hi - wr_.lo, wr_.lo, &d_.A));
+            ugCheck(ug_bases_create_g1(d_.ctx, pB1 + wr_.lo * 64, wr_.hi - wr_.lo, wr_.lo, &d_.B1));
+        }
         ugCheck(ug_bases_create_g2(d_.ctx, pB2 + wr_.lo * 128, wr_.hi - wr_.lo, wr_.lo, &d_.B2));
         // the round / final sets are multiplied with GATHERED scalars (position k of the slice's index list), so their
         // slices count from 0
@@ -1003,7 +1047,8 @@ public:
     std::vector<TableGroup> tableGroups() override {
         std::vector<TableGroup> groups(4);
         const uint64_t nw = wr_.hi - wr_.lo;
-        groups[0].g1 = {d_.A, d_.B1}; groups[0].n1 = {nw, nw}; groups[0].g2 = {d_.B2}; groups[0].n2 = {nw};
+        if (d_.G) { groups[0].g1 = {d_.G}; groups[0].n1 = {2 * nw}; } else { groups[0].g1 = {d_.A, d_.B1}; groups[0].n1 = {nw, nw}; }
+        groups[0].g2 = {d_.B2}; groups[0].n2 = {nw};
         groups[0].scalars = nw; groups[0].c = &tableW_;
         groups[1].g1 = {d_.roundC}; groups[1].n1 = {roundIdx_.size()}; groups[1].scalars = roundIdx_.size(); groups[1].c = &tableC1_;
         groups[2].g1 = {d_.C}; groups[2].n1 = {finalIdx_.size()}; groups[2].scalars = finalIdx_.size(); groups[2].c = &tableC2_;
@@ -1110,11 +1155,8 @@ public:
         if (!committed_) throw std::invalid_argument("the round commitment has not been applied");
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
         buildSchedule(d_.sw, wCur_, wr_.lo, wr_.hi - wr_.lo, tableW_);
-        {                                                                                   // MSM1-3 :201,214,227
-            const ug_bases* sets[3] = {d_.A, d_.B1, d_.B2};
-            void* outs[3] = {partials, partials + 64, partials + 128};
-            ugCheck(ug_msm_batch(d_.ctx, 3, sets, d_.sw, nullptr, outs));
-        }
+        enqueueWitnessProducts(d_, d_.ctx, d_.sw, partials, partials + 64, partials + 128, nullptr, 0, false);      // MSM1-3 :201,214,227
+        ugCheck(ug_ctx_collect(d_.ctx));
         mark("A, B1, B2 MSMs");
         ugCheck(ug_dvec_gather_index(d_.aux, wCur_, d_.finalIdx));                           // :439-445
         mark("final gather");
@@ -1222,9 +1264,7 @@ public:
             // witnesses (:439-445) and MSM4 (:234), the FFT block (:243-320), MSM5 (:322)
             memset(sums, 0, sizeof sums);
             buildSchedule(d_.sw, wCur_, wr_.lo, wr_.hi - wr_.lo, tableW_);
-            const ug_bases* sets[3] = {d_.A, d_.B1, d_.B2};
-            void* outs[3] = {sums, sums + 64, sums + 128};
-            ugCheck(ug_msm_batch_enqueue(d_.ctx, 3, sets, d_.sw, nullptr, outs));
+            enqueueWitnessProducts(d_, d_.ctx, d_.sw, sums, sums + 64, sums + 128, nullptr, 0, false);
             ugCheck(ug_dvec_gather_index(d_.aux, wCur_, d_.finalIdx));
             buildSchedule(d_.saux, d_.aux, 0, finalIdx_.size(), tableC2_);
             const ug_bases* setC[1] = {d_.C};

@@ -112,7 +112,7 @@ struct ug_ctx {
     StagedUploader uploader;
     hipStream_t stream = nullptr;
     MsmWorkspace ws_g1, ws_g2;
-    MsmStats stats[3];                     // [0] G1, [1] G2 bucket-accumulation launches, [2] NTT pass launches
+    MsmStats stats[4];                     // [0] G1, [1] G2 bucket-accumulation launches, [2] NTT pass launches, [3] G1 group accumulation
     double msm_ms = 0, fft_ms = 0;
     // stream-time accounting without host waits: every timed span is an event pair that is resolved (elapsed time added
     // to its accumulator) the next time the stream is known to be idle -- ug_ctx_collect, ug_ctx_timings, ug_ctx_sync
@@ -141,6 +141,8 @@ struct ug_ctx {
 struct ug_bases {
     ug_ctx* ctx; bool g2; u64 n; u64 global_first; u32* pts;
     int table_c = 0;          // window width of the precomputed tables (0: none, pts holds the n points only)
+    int members = 1;          // > 1: a group -- n = slots * members records, record slot * members + m is member m's point of
+    u64 slots = 0;            //      scalar global_first + slot (ug_bases_create_group_g1)
 };
 struct ug_dvec {
     ug_ctx* ctx; u64 n; u32* data; bool owns;
@@ -225,7 +227,7 @@ void resolve_spans(ug_ctx* c) {
         c->spans_free.push_back(sp);
     }
     c->spans_pending.clear();
-    for (int k = 0; k < 3; k++) c->stats[k].collect();
+    for (int k = 0; k < 4; k++) c->stats[k].collect();
 }
 void sync_and_resolve(ug_ctx* c) {
     UG_HIP(hipStreamSynchronize(c->stream));
@@ -256,7 +258,7 @@ int ug_ctx_create(ug_ctx** out, int device) {
     c->use();
     UG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     UG_HIP(hipEventCreateWithFlags(&c->order_event, hipEventDisableTiming));
-    for (int k = 0; k < 3; k++) c->stats[k].create();
+    for (int k = 0; k < 4; k++) c->stats[k].create();
     UG_HIP(hipHostMalloc((void**)&c->pinned_results, (size_t)MsmStats::MAX_BATCH * MSM_PENDING_WORDS * 4, hipHostMallocDefault));
     *out = c;
     UG_CATCH
@@ -271,7 +273,7 @@ void ug_ctx_destroy(ug_ctx* c) {
     for (auto& sp : c->spans_free) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
     for (auto& sp : c->spans_pending) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
     if (c->order_event) hipEventDestroy(c->order_event);
-    for (int k = 0; k < 3; k++) c->stats[k].destroy();
+    for (int k = 0; k < 4; k++) c->stats[k].destroy();
     if (c->pinned_results) hipHostFree(c->pinned_results);
     hipStreamDestroy(c->stream);
     delete c;
@@ -334,6 +336,60 @@ int ug_bases_create_g1(ug_ctx* c, const void* host, uint64_t n, uint64_t gf, ug_
 int ug_bases_create_g2(ug_ctx* c, const void* host, uint64_t n, uint64_t gf, ug_bases** out) { return bases_create(c, host, n, gf, true, 0, out); }
 int ug_bases_create_tables_g1(ug_ctx* c, const void* host, uint64_t n, uint64_t gf, int table_c, ug_bases** out) { return bases_create(c, host, n, gf, false, table_c, out); }
 int ug_bases_create_tables_g2(ug_ctx* c, const void* host, uint64_t n, uint64_t gf, int table_c, ug_bases** out) { return bases_create(c, host, n, gf, true, table_c, out); }
+
+// A group of `members` (2 or 3) G1 sets that are always multiplied by the same scalars, as ONE array of members-point
+// records (msm.hip: segment_accumulate_group_kernel). Member m brings n[m] points; its first point belongs to the scalar
+// with global index first[m]. The group covers the scalars [group_first, group_first + slots); slots a member has no point
+// for hold infinity. With table_c the window tables are built over the interleaved array (a plain G1 array of slots * members
+// points as far as the table kernel is concerned), queued on the context's stream as for ug_bases_create_tables_g1.
+int ug_bases_create_group_g1(ug_ctx* c, int members, const void* const* host, const uint64_t* n, const uint64_t* first,
+                             uint64_t group_first, uint64_t slots, int table_c, ug_bases** out) {
+    UG_TRY
+    if (!c || !out || !host || !n || !first) throw std::invalid_argument("null argument");
+    if (members < 2 || members > 3) throw std::invalid_argument("a base group has 2 or 3 members");
+    for (int m = 0; m < members; m++) {
+        if (!host[m] && n[m]) throw std::invalid_argument("null argument");
+        if (n[m] && (first[m] < group_first || first[m] + n[m] > group_first + slots)) throw std::invalid_argument("group member outside the group's scalar range");
+    }
+    c->use();
+    int windows = 1;
+    if (table_c) windows = MsmGeometry::choose_tables(slots, table_c).windows;      // validates the width
+    if (slots > ((u64)1 << TABLE_INDEX_BITS)) throw std::invalid_argument("a base group holds at most 2^27 scalars");
+    ug_bases* b = new ug_bases{c, false, slots * (u64)members, group_first, nullptr, 0};
+    b->members = members; b->slots = slots;
+    const size_t bytes = (size_t)b->n * 64;
+    u64 most = 0;
+    for (int m = 0; m < members; m++) most = n[m] > most ? n[m] : most;
+    u32* stage = nullptr;
+    if (hipMalloc(&b->pts, bytes ? bytes * (size_t)windows : 4) != hipSuccess || hipMalloc(&stage, most ? (size_t)most * 64 : 4) != hipSuccess) {
+        (void)hipGetLastError();
+        if (b->pts) hipFree(b->pts);
+        delete b;
+        throw std::runtime_error(table_c ? "not enough device memory for the window tables" : "not enough device memory for the base points");
+    }
+    try {
+        if (bytes) {
+            UG_HIP(hipMemsetAsync(b->pts, 0, bytes, c->stream));            // slots without a point: infinity
+            UG_HIP(hipStreamSynchronize(c->stream));
+        }
+        u32* pts = b->pts;
+        for (int m = 0; m < members; m++) {
+            // chunks of whole records: converted to the device form and moved to their slots behind their own DMA
+            if (!n[m]) continue;
+            const u64 slot0 = first[m] - group_first;
+            host_to_device(c, stage, host[m], (size_t)n[m] * 64, [=](size_t off, size_t len, hipStream_t st) {
+                convert_points_g1(stage + off / 4, len / 64, st);
+                interleave_points_g1(pts, stage + off / 4, len / 64, members, m, slot0 + off / 64, st);
+            }, /*fresh*/ true);
+        }
+        if (table_c && b->n) build_window_tables(false, pts, b->n, table_c, windows, c->stream);
+    } catch (...) { hipFree(stage); hipFree(b->pts); delete b; throw; }
+    hipFree(stage);
+    b->table_c = table_c;
+    *out = b;
+    UG_CATCH
+}
+int ug_bases_members(const ug_bases* b) { return b ? b->members : 0; }
 int ug_msm_table_window(uint64_t n) { return MsmGeometry::table_window(n); }
 uint64_t ug_bases_tables_bytes(uint64_t n, int g2, int c) {
     if (c < TABLE_MIN_C || c > TABLE_MAX_C) return 0;
@@ -344,7 +400,7 @@ int ug_bases_precompute(ug_bases* b, int c) {
     if (!b) throw std::invalid_argument("null argument");
     if (b->table_c) throw std::invalid_argument("bases already hold window tables");
     MsmGeometry g = MsmGeometry::choose_tables(b->n, c);             // validates c
-    if (b->n > ((u64)1 << TABLE_INDEX_BITS)) throw std::invalid_argument("window tables need at most 2^27 points per set");
+    if ((b->members > 1 ? b->slots : b->n) > ((u64)1 << TABLE_INDEX_BITS)) throw std::invalid_argument("window tables need at most 2^27 points per set");
     ug_ctx* ctx = b->ctx;
     ctx->use();
     if (b->n) {
@@ -648,6 +704,7 @@ int ug_msm_g1(ug_ctx* c, const ug_bases* b, const ug_schedule* s, int64_t index_
     UG_TRY
     if (!c || !b || !s || !out) throw std::invalid_argument("null argument");
     if (b->g2) throw std::invalid_argument("ug_msm_g1 called with G2 bases");
+    if (b->members > 1) throw std::invalid_argument("a base group is multiplied with ug_msm_group_enqueue");
     check_tables(b, s);
     c->use();
     ScopedTimer tm(c, &c->msm_ms);
@@ -686,6 +743,7 @@ int ug_msm_batch_enqueue(ug_ctx* c, int count, const ug_bases* const* bases, con
         throw std::invalid_argument("at most 8 products may be queued before ug_ctx_collect");
     for (int k = 0; k < count; k++) {
         if (!bases[k] || !outs[k]) throw std::invalid_argument("null argument");
+        if (bases[k]->members > 1) throw std::invalid_argument("a base group is multiplied with ug_msm_group_enqueue");
         check_tables(bases[k], s);
     }
     c->use();
@@ -723,6 +781,34 @@ int ug_msm_batch_enqueue(ug_ctx* c, int count, const ug_bases* const* bases, con
         flush();
     }
     } catch (...) { c->pending_msm.resize(first_slot); throw; }      // nothing of a failed call stays queued
+    tm.stop();
+    UG_CATCH
+}
+// The K products of a base group over one schedule, queued like ug_msm_batch_enqueue (results after ug_ctx_collect): ONE
+// accumulation launch gathers each K-point record once and keeps K accumulators; outs[m] receives member m's sum (64 bytes).
+int ug_msm_group_enqueue(ug_ctx* c, const ug_bases* group, const ug_schedule* s, void* const* outs) {
+    UG_TRY
+    if (!c || !group || !s || !outs) throw std::invalid_argument("null argument");
+    if (group->members < 2) throw std::invalid_argument("not a base group");
+    const int K = group->members;
+    if (c->pending_msm.size() + (size_t)K > (size_t)MsmStats::MAX_BATCH) throw std::invalid_argument("at most 8 products may be queued before ug_ctx_collect");
+    for (int m = 0; m < K; m++) if (!outs[m]) throw std::invalid_argument("null argument");
+    check_tables(group, s);
+    c->use();
+    ScopedTimer tm(c, &c->msm_ms);
+    const size_t first_slot = c->pending_msm.size();
+    for (int m = 0; m < K; m++) {
+        ug_ctx::QueuedMsm q;
+        q.g2 = false; q.out = outs[m];
+        c->pending_msm.push_back(q);
+    }
+    try {
+        u32* host[MSM_BATCH_MAX]; MsmPending pend[MSM_BATCH_MAX];
+        for (int m = 0; m < K; m++) host[m] = c->pinned_results + (first_slot + m) * MSM_PENDING_WORDS;
+        const int64_t delta = (int64_t)s->first - (int64_t)group->global_first;
+        msm_enqueue_group_g1(s->sched, c->ws_g1, K, group->pts, group->slots, delta, c->stream, &c->stats[3], host, pend);
+        for (int m = 0; m < K; m++) c->pending_msm[first_slot + m].pend = pend[m];
+    } catch (...) { c->pending_msm.resize(first_slot); throw; }
     tm.stop();
     UG_CATCH
 }
@@ -973,7 +1059,7 @@ int ug_ctx_timings(ug_ctx* c, double* msm_ms, double* fft_ms, int reset) {
 int ug_ctx_kernel_stats(ug_ctx* c, int which, double* avg_ms, uint64_t* launches, uint64_t* entries, int reset) {
     UG_TRY
     if (!c) throw std::invalid_argument("null argument");
-    if (which < 0 || which > 2) throw std::invalid_argument("kernel stats: 0 = G1 accumulation, 1 = G2 accumulation, 2 = NTT pass");
+    if (which < 0 || which > 3) throw std::invalid_argument("kernel stats: 0 = G1 accumulation, 1 = G2 accumulation, 2 = NTT pass, 3 = G1 group accumulation");
     c->use();
     sync_and_resolve(c);
     MsmStats& st = c->stats[which];
