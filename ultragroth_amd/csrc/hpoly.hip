@@ -57,11 +57,25 @@ __global__ __launch_bounds__(256) void matvec_kernel(u32* a_br, u32* b_br, const
     u32 s = row_ptr[r], e = row_ptr[r + 1];
     Fr acc = fp_zero<FrParams>();
     u32 since = 0;
-    for (u32 p = s; p < e; p++) {
-        Fr w = ld_packed<FrParams>(wtns + (size_t)sig[p] * 8);       // plain integer, any value < 2^256
-        Fr v = ld_packed<FrParams>(val + (size_t)p * 8);
-        acc = add(acc, mul(w, v));                                    // + < 2q
-        if (++since == 24) { acc = contract(acc); since = 0; }        // keep below 64 q
+    // four entries at a time: their signal ids first, then the four 32-byte witness gathers and the four coefficients all in
+    // flight together, then the products (one entry per turn left every gather's latency -- a DRAM row miss -- exposed: 69 %
+    // of the kernel's wave cycles were waits)
+    for (u32 p = s; p < e; p += 4) {
+        const u32 cnt = e - p < 4 ? e - p : 4;
+        u32 sg[4], wr[4][8], vr[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) sg[k] = (u32)k < cnt ? sig[p + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((u32)k < cnt) { load8(wr[k], wtns + (size_t)sg[k] * 8); load8(vr[k], val + (size_t)(p + k) * 8); }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((u32)k < cnt) {
+                acc = add(acc, mul(unpack256<FrParams>(wr[k]), unpack256<FrParams>(vr[k])));      // + < 2q  (w: plain integer, any value < 2^256)
+                if (++since == 24) { acc = contract(acc); since = 0; }                              // keep below 64 q
+            }
+        }
     }
     acc = contract(acc);
     u32 c = r >= domain ? r - domain : r;

@@ -19,6 +19,13 @@ void bitrev_copy(u32* out, const u32* in, int logn, hipStream_t stream);
 //   fin_a, fin_b   last pass: out[i] = plain integer of fin_a[i] * fin_b[i] - x[i] (32-byte plain, not device form)
 struct NttFusion { const u32* in2 = nullptr; u32* work = nullptr; const u32* fin_a = nullptr; const u32* fin_b = nullptr; };
 
+// one pass of a transform as the host plans it (ntt.hip turns it into kernel arguments)
+struct NttPass {
+    const u32* in; u32* out; const u32* tw; const u32* post; const u32* post_const; const u32* in2; const u32* fin_a; const u32* fin_b;
+    int logn, s0, k, j, gather_bitrev, scatter_bitrev;
+};
+constexpr int NTT_MAX_PASSES = 8;
+
 struct NttPlan {
     int logn = -1;
     u32* tw_fwd = nullptr;    // omega_n^i,   i < n/2
@@ -34,6 +41,12 @@ struct NttPlan {
     void transform(u32* out, const u32* in, bool inverse, bool gather_bitrev, bool scatter_bitrev,
                    const u32* post, const u32* post_const, hipStream_t stream, struct MsmStats* stats = nullptr,
                    const struct NttFusion* fuse = nullptr) const;
+    // the same in two steps, for callers that run several transforms of this size side by side: passes() fills `list`
+    // (NTT_MAX_PASSES entries) and returns the pass count -- the same for every transform of the plan --, launch() runs pass
+    // p of up to three such lists in one kernel launch (logn >= 1)
+    int passes(NttPass* list, u32* out, const u32* in, bool inverse, bool gather_bitrev, bool scatter_bitrev,
+               const u32* post, const u32* post_const, const struct NttFusion* fuse = nullptr) const;
+    void launch(const NttPass* const* lists, int count, int p, hipStream_t stream, struct MsmStats* stats = nullptr) const;
     ~NttPlan() { release(); }
 };
 

@@ -29,10 +29,22 @@ namespace {
 constexpr int NTT_MAX_LOG_TILE = 10;
 constexpr int NTT_THREADS = 256;          // one radix-4 butterfly per lane per step at the full tile
 
+// Twiddles live in HBM UNPACKED: 9 limbs of 29 bits in 12 words (48 bytes: three aligned 16-byte loads, no shifts or masks at
+// the point of use -- a packed 32-byte entry cost ~26 vector instructions to unpack, three times per radix-4 step).
+constexpr int TW_WORDS = 12;
+__device__ __forceinline__ Fr ld_twiddle(const u32* tw, size_t entry) {
+    const uint4* q = reinterpret_cast<const uint4*>(tw + entry * TW_WORDS);
+    const uint4 a = q[0], b = q[1];
+    Fr r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = tw[entry * TW_WORDS + 8];
+    return r;
+}
+
 struct PassArgs {
     const u32* in;
     u32* out;
-    const u32* tw;        // packed twiddles, stage-major: entry (2^s - 1 + j) = omega_{2^(s+1)}^j, j < 2^s
+    const u32* tw;        // unpacked twiddles (TW_WORDS each), stage-major: entry (2^s - 1 + j) = omega_{2^(s+1)}^j, j < 2^s
     const u32* post;      // optional: out[i] *= post[i]   (natural index), nullptr if none
     const u32* post_const;// optional: out[i] *= *post_const
     const u32* in2;       // optional, first pass: the input element is in[i] * in2[i]
@@ -67,8 +79,12 @@ __device__ __forceinline__ Fr as_fr(const u32* x) { return fp_from<FrParams>(x);
 // twiddle still hold: 9 * 2^60 + 9 * 2^58 < 2^64). An odd k starts with one radix-2 step. Bounds in units of q: every
 // stage adds a product (< 2q) or its negation (+ 2q), so a pass of 12 stages takes a packed input (< 2^256 < 5.3 q) to
 // below 30 q; the last loop contracts to < 2.01 q for packing.
-__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
+// up to three transforms of the same size in one launch (blockIdx.y picks one): the three chains of the H-polynomial block
+struct PassBatch { PassArgs a[3]; };
+
+__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassBatch batch) {
     extern __shared__ u32 lds[];
+    const PassArgs& a = batch.a[blockIdx.y];
     const int E = 1 << (a.k + a.j);               // elements per workgroup
     const int tid = threadIdx.x, nth = blockDim.x;
     const u32 bid = blockIdx.x;
@@ -118,7 +134,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
             const u32 pos0 = lpos(e0, t), pos1 = lpos(e0 + 1, t);
             u32 x0[NL], x1[NL], y[NL];
             ld(x0, pos0); ld(x1, pos1);
-            Fr w = ld_packed<FrParams>(a.tw + (size_t)twidx(0, 0, t) * 8);
+            Fr w = ld_twiddle(a.tw, twidx(0, 0, t));
             Fr tt = mul(as_fr(x1), w);
             raw_add(y, x0, tt); st(pos0, norm_weak<FrParams>(y));
             raw_sub2q(y, x0, tt); st(pos1, norm_weak<FrParams>(y));
@@ -135,9 +151,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
             const u32 e0 = ((p >> d) << (d + 2)) | elow;
             const u32 p0 = lpos(e0, t), p1 = lpos(e0 + D, t), p2 = lpos(e0 + 2 * D, t), p3 = lpos(e0 + 3 * D, t);
             // twiddles first: their latency (L2 / HBM) hides behind the LDS reads
-            Fr wa = ld_packed<FrParams>(a.tw + (size_t)twidx(d, elow, t) * 8);
-            Fr wb0 = ld_packed<FrParams>(a.tw + (size_t)twidx(d + 1, elow, t) * 8);
-            Fr wb1 = ld_packed<FrParams>(a.tw + (size_t)twidx(d + 1, elow + D, t) * 8);
+            Fr wa = ld_twiddle(a.tw, twidx(d, elow, t));
+            Fr wb0 = ld_twiddle(a.tw, twidx(d + 1, elow, t));
+            Fr wb1 = ld_twiddle(a.tw, twidx(d + 1, elow + D, t));
             u32 x0[NL], x1[NL], x2[NL], x3[NL];
             ld(x0, p0); ld(x1, p1); ld(x2, p2); ld(x3, p3);
             // stage d: (x0, x1) and (x2, x3), both with wa; sums left raw
@@ -188,7 +204,8 @@ __global__ void bitrev_copy_kernel(u32* out, const u32* in, int logn) {
 
 // table[i] = scale * base^i for i < count, packed canonical; thread t fills a run of RUN entries
 constexpr int POW_RUN = 64;
-__global__ void power_table_kernel(u32* table, const u32* base_packed, const u32* scale_packed, u64 count) {
+// unpacked: entries of TW_WORDS words holding the 9 limbs (twiddle tables); else packed 32-byte entries
+__global__ void power_table_kernel(u32* table, const u32* base_packed, const u32* scale_packed, u64 count, int unpacked) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 start = t * POW_RUN;
     if (start >= count) return;
@@ -201,7 +218,13 @@ __global__ void power_table_kernel(u32* table, const u32* base_packed, const u32
         sq = sqr(sq);
     }
     for (int i = 0; i < POW_RUN && start + i < count; i++) {
-        st_packed(table + (start + i) * 8, cond_sub_q(acc));
+        const Fr c = cond_sub_q(acc);
+        if (unpacked) {
+            u32* o = table + (start + i) * TW_WORDS;
+#pragma unroll
+            for (int l = 0; l < NL; l++) o[l] = c.l[l];
+            o[9] = 0; o[10] = 0; o[11] = 0;
+        } else st_packed(table + (start + i) * 8, c);
         acc = mul(acc, b);
     }
 }
@@ -237,8 +260,8 @@ void NttPlan::init(int logn_, hipStream_t stream) {
     // lanes of a wave touch consecutive 32-byte entries at every stage (a single table of omega_n^i indexed with a
     // stage-dependent stride makes the late stages hit one L2 channel with 64 KiB strides).
     u64 entries = n > 1 ? n - 1 : 1;
-    UG_HIP(hipMalloc(&tw_fwd, entries * 32));
-    UG_HIP(hipMalloc(&tw_inv, entries * 32));
+    UG_HIP(hipMalloc(&tw_fwd, entries * TW_WORDS * 4));
+    UG_HIP(hipMalloc(&tw_inv, entries * TW_WORDS * 4));
     UG_HIP(hipMalloc(&twist, n * 32));
     UG_HIP(hipMalloc(&ninv, 32));
     Fr w2n = fr_root_of_unity(logn + 1);
@@ -254,18 +277,18 @@ void NttPlan::init(int logn_, hipStream_t stream) {
     u32* d_consts;
     UG_HIP(hipMalloc(&d_consts, consts.size() * 4));
     UG_HIP(hipMemcpyAsync(d_consts, consts.data(), consts.size() * 4, hipMemcpyHostToDevice, stream));
-    auto launch = [&](u32* table, int base_i, int scale_i, u64 count) {
+    auto launch = [&](u32* table, int base_i, int scale_i, u64 count, int unpacked) {
         u64 threads = (count + POW_RUN - 1) / POW_RUN;
         unsigned blocks = (unsigned)((threads + 255) / 256);
-        hipLaunchKernelGGL(power_table_kernel, dim3(blocks), dim3(256), 0, stream, table, d_consts + 8 * base_i, d_consts + 8 * scale_i, count);
+        hipLaunchKernelGGL(power_table_kernel, dim3(blocks), dim3(256), 0, stream, table, d_consts + 8 * base_i, d_consts + 8 * scale_i, count, unpacked);
         UG_KERNEL_CHECK();
     };
     for (int st = 0; st < logn; st++) {
         u64 off = ((u64)1 << st) - 1;
-        launch(tw_fwd + off * 8, 3 + 2 * st, 2, (u64)1 << st);
-        launch(tw_inv + off * 8, 4 + 2 * st, 2, (u64)1 << st);
+        launch(tw_fwd + off * TW_WORDS, 3 + 2 * st, 2, (u64)1 << st, 1);
+        launch(tw_inv + off * TW_WORDS, 4 + 2 * st, 2, (u64)1 << st, 1);
     }
-    launch(twist, 0, 1, n);                    // n^-1 * omega_{2n}^i
+    launch(twist, 0, 1, n, 0);                 // n^-1 * omega_{2n}^i (packed: one product per element, in the last pass)
     UG_HIP(hipMemcpyAsync(ninv, d_consts + 8, 32, hipMemcpyDeviceToDevice, stream));
     UG_HIP(hipStreamSynchronize(stream));
     UG_HIP(hipFree(d_consts));
@@ -279,22 +302,21 @@ void NttPlan::release() {
     tw_fwd = tw_inv = twist = ninv = nullptr;
 }
 
-// One DIT transform. `in` holds the input in bit-reversed order unless gather_bitrev is set (then
+// The passes of one DIT transform. `in` holds the input in bit-reversed order unless gather_bitrev is set (then
 // natural order, gathered on the fly); output natural order, or bit-reversed if scatter_bitrev.
 // post (optional) multiplies output element i (natural index) by post[i] in the last pass.
-void NttPlan::transform(u32* out, const u32* in, bool inverse, bool gather_bitrev, bool scatter_bitrev,
-                        const u32* post, const u32* post_const, hipStream_t stream, MsmStats* stats, const NttFusion* fuse) const {
+// Buffers: the first pass reads `in` (and fuse->in2); intermediate passes run in place on `mid` = fuse->work when given
+// (then `in` is only read), else `in` itself for a scattering transform (which is clobbered) and `out` otherwise; the last
+// pass writes `out`.
+int NttPlan::passes(NttPass* list, u32* out, const u32* in, bool inverse, bool gather_bitrev, bool scatter_bitrev,
+                    const u32* post, const u32* post_const, const NttFusion* fuse) const {
     const u32* in2 = fuse ? fuse->in2 : nullptr;
     u32* work = fuse ? fuse->work : nullptr;
-    if (logn == 0) {
-        if (in2 || (fuse && fuse->fin_a)) throw std::invalid_argument("ntt: fused forms need at least two points");
-        if (out != in) UG_HIP(hipMemcpyAsync(out, in, 32, hipMemcpyDeviceToDevice, stream));
-        return;   // size-1 transform is the identity (n^-1 = 1, omega_2^0 = 1)
-    }
+    if (logn <= 0) throw std::invalid_argument("ntt: a pass list needs at least two points");
     if (gather_bitrev && scatter_bitrev) throw std::invalid_argument("ntt: gather and scatter together not supported");
-    if ((gather_bitrev || scatter_bitrev) && out == in) throw std::invalid_argument("ntt: permuting transform must be out of place");
+    if ((gather_bitrev || scatter_bitrev) && out == in && !work) throw std::invalid_argument("ntt: permuting transform must be out of place");
     // split the stages: first pass contiguous (up to NTT_MAX_LOG_TILE stages), then strided passes with 2^j adjacent elements per row
-    int stages[8], nj[8], np = 0, rem = logn;
+    int stages[NTT_MAX_PASSES], nj[NTT_MAX_PASSES], np = 0, rem = logn;
     int first = rem < NTT_MAX_LOG_TILE ? rem : NTT_MAX_LOG_TILE;
     stages[np] = first; nj[np] = 0; np++; rem -= first;
     while (rem > 0) {
@@ -303,12 +325,12 @@ void NttPlan::transform(u32* out, const u32* in, bool inverse, bool gather_bitre
         int k = (rem + npass_left - 1) / npass_left;
         stages[np] = k; nj[np] = NTT_MAX_LOG_TILE - k; np++; rem -= k;
     }
-    // Buffer plan. Intermediate passes run in place on a work buffer: `work` when given (then `in`, and `in2`, are only
-    // read), else `in` itself for a scattering transform (which is clobbered) and `out` otherwise. The last pass writes `out`.
+    if (np == 1 && (gather_bitrev || scatter_bitrev) && out == in) throw std::invalid_argument("ntt: a single permuting pass must be out of place");
     u32* mid = work ? work : (scatter_bitrev ? const_cast<u32*>(in) : out);
+    if ((gather_bitrev || scatter_bitrev) && np > 1 && out == mid && scatter_bitrev) throw std::invalid_argument("ntt: the scattering pass must leave its work buffer");
     int s0 = 0;
     for (int p = 0; p < np; p++) {
-        PassArgs a;
+        NttPass& a = list[p];
         bool last = (p == np - 1);
         a.in = (p == 0) ? in : mid;
         a.out = last ? out : mid;
@@ -322,16 +344,45 @@ void NttPlan::transform(u32* out, const u32* in, bool inverse, bool gather_bitre
         a.scatter_bitrev = (last && scatter_bitrev) ? 1 : 0;
         a.post = last ? post : nullptr;
         a.post_const = last ? post_const : nullptr;
-        int E = 1 << (a.k + a.j);
-        unsigned blocks = (unsigned)(((u64)1 << logn) >> (a.k + a.j));
-        int threads = E / 4 > NTT_THREADS ? NTT_THREADS : (E / 4 < 64 ? 64 : E / 4);
-        size_t lds = (size_t)E * NL * 4;
-        int slot = stats ? stats->begin(stream, (u64)1 << logn) : -1;
-        hipLaunchKernelGGL(ntt_pass_kernel, dim3(blocks), dim3(threads), lds, stream, a);
-        UG_KERNEL_CHECK();
-        if (stats) stats->end(slot, stream);
         s0 += stages[p];
     }
+    return np;
+}
+
+// pass `p` of up to three transforms of this plan's size in ONE launch (their pass lists share the geometry)
+void NttPlan::launch(const NttPass* const* lists, int count, int p, hipStream_t stream, MsmStats* stats) const {
+    if (count < 1 || count > 3) throw std::logic_error("ntt: batch size");
+    PassBatch b;
+    for (int c = 0; c < count; c++) {
+        const NttPass& n = lists[c][p];
+        PassArgs& a = b.a[c];
+        a.in = n.in; a.out = n.out; a.tw = n.tw; a.post = n.post; a.post_const = n.post_const; a.in2 = n.in2; a.fin_a = n.fin_a; a.fin_b = n.fin_b;
+        a.logn = n.logn; a.s0 = n.s0; a.k = n.k; a.j = n.j; a.gather_bitrev = n.gather_bitrev; a.scatter_bitrev = n.scatter_bitrev;
+    }
+    for (int c = count; c < 3; c++) b.a[c] = b.a[0];
+    const PassArgs& a = b.a[0];
+    int E = 1 << (a.k + a.j);
+    unsigned blocks = (unsigned)(((u64)1 << logn) >> (a.k + a.j));
+    int threads = E / 4 > NTT_THREADS ? NTT_THREADS : (E / 4 < 64 ? 64 : E / 4);
+    size_t lds = (size_t)E * NL * 4;
+    int slot = stats ? stats->begin(stream, ((u64)1 << logn) * (u64)count) : -1;
+    hipLaunchKernelGGL(ntt_pass_kernel, dim3(blocks, (unsigned)count), dim3(threads), lds, stream, b);
+    UG_KERNEL_CHECK();
+    if (stats) stats->end(slot, stream);
+}
+
+void NttPlan::transform(u32* out, const u32* in, bool inverse, bool gather_bitrev, bool scatter_bitrev,
+                        const u32* post, const u32* post_const, hipStream_t stream, MsmStats* stats, const NttFusion* fuse) const {
+    if (logn == 0) {
+        if (fuse && (fuse->in2 || fuse->fin_a)) throw std::invalid_argument("ntt: fused forms need at least two points");
+        if (out != in) UG_HIP(hipMemcpyAsync(out, in, 32, hipMemcpyDeviceToDevice, stream));
+        return;   // size-1 transform is the identity (n^-1 = 1, omega_2^0 = 1)
+    }
+    if ((gather_bitrev || scatter_bitrev) && out == in) throw std::invalid_argument("ntt: permuting transform must be out of place");
+    NttPass list[NTT_MAX_PASSES];
+    const int np = passes(list, out, in, inverse, gather_bitrev, scatter_bitrev, post, post_const, fuse);
+    const NttPass* one[1] = {list};
+    for (int p = 0; p < np; p++) launch(one, 1, p, stream, stats);
 }
 
 void bitrev_copy(u32* out, const u32* in, int logn, hipStream_t stream) {

@@ -136,6 +136,9 @@ struct ug_ctx {
         return lookup_stage;
     }
     u32* pinned_results = nullptr;         // MsmStats::SLOTS result blocks of queued MSMs (ug_msm_batch)
+    std::vector<void*> deferred_free;      // staging memory of queued set-up work: hipFree waits for the whole device, so it is
+                                           // freed the next time the stream is idle anyway (ug_ctx_sync, destroy)
+    void free_deferred() { for (void* p : deferred_free) hipFree(p); deferred_free.clear(); }
     void use() const { UG_HIP(hipSetDevice(device)); }
 };
 struct ug_bases {
@@ -232,6 +235,7 @@ void resolve_spans(ug_ctx* c) {
 void sync_and_resolve(ug_ctx* c) {
     UG_HIP(hipStreamSynchronize(c->stream));
     resolve_spans(c);
+    c->free_deferred();
 }
 template <class F> void store_mont256(uint8_t* out, const F& v);
 template <> void store_mont256<Fq>(uint8_t* out, const Fq& v) { u32 w[8]; to_mont256(w, v); memcpy(out, w, 32); }
@@ -267,6 +271,7 @@ void ug_ctx_destroy(ug_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    c->free_deferred();
     c->ws_g1.release(); c->ws_g2.release(); c->raw_ntt.release(); c->uploader.release();
     if (c->lookup_last) hipFree(c->lookup_last);
     if (c->lookup_stage) hipFree(c->lookup_stage);
@@ -384,7 +389,8 @@ int ug_bases_create_group_g1(ug_ctx* c, int members, const void* const* host, co
         }
         if (table_c && b->n) build_window_tables(false, pts, b->n, table_c, windows, c->stream);
     } catch (...) { hipFree(stage); hipFree(b->pts); delete b; throw; }
-    hipFree(stage);
+    c->deferred_free.push_back(stage);      // (not hipFree here: it would wait for the table build just queued, and the caller's next
+                                            // section could no longer be uploaded beside it)
     b->table_c = table_c;
     *out = b;
     UG_CATCH
@@ -896,19 +902,46 @@ int ug_hpoly_run(ug_hpoly* hp, const ug_dvec* w, ug_dvec* h_out) {
         tm.stop();
         return UG_OK;
     }
-    // S7 + the inverse half of the third chain: c = a o b is formed inside the first pass of its ifft (:100-108), whose
-    // passes run on hp->c so that a and b stay intact; the twisted coefficients wait in hp->t2
+    static const bool batched = !(getenv("UG_NTT_BATCH") && atoi(getenv("UG_NTT_BATCH")) == 0);      // tuning knob (A/B)
+    NttPass pa[NTT_MAX_PASSES], pb[NTT_MAX_PASSES], pc[NTT_MAX_PASSES];
     NttFusion cinv; cinv.in2 = hp->b; cinv.work = hp->c;
-    hp->ntt.transform(hp->t2, hp->a, /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, &c->stats[2], &cinv);
-    // S8: ifft, twist by omega_2n^i (with 1/n folded in), fft          :110-140
-    u32* polys[2] = {hp->a, hp->b};
-    for (int p = 0; p < 2; p++) {
-        hp->ntt.transform(hp->t, polys[p], /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, &c->stats[2]);
-        hp->ntt.transform(polys[p], hp->t, /*inverse*/ false, false, false, nullptr, nullptr, st, &c->stats[2]);
-    }
-    // the forward half of the third chain, with S9 (h = a o b - c, to plain integers, :142-148) inside its last pass
     NttFusion cfwd; cfwd.work = hp->c; cfwd.fin_a = hp->a; cfwd.fin_b = hp->b;
-    hp->ntt.transform(h_out->data, hp->t2, /*inverse*/ false, false, false, nullptr, nullptr, st, &c->stats[2], &cfwd);
+    const int np = hp->ntt.passes(pc, hp->t2, hp->a, /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, &cinv);
+    if (batched && np > 1) {
+        // The three chains side by side, pass by pass: ONE launch per pass index holds the same pass of all three transforms
+        // (blockIdx.y), 7 launches instead of 18 for a three-pass size, and the ends of the launches fill with the other
+        // chains' workgroups. Buffers: every first pass only READS a and b (chain c's forms a o b from them, S7 :100-108), so
+        // chains a and b take their intermediate passes to work buffers (hp->t and the h vector, which is written last of
+        // all) and scatter their twisted coefficients back into a and b; chain c works on hp->c and leaves them in hp->t2.
+        NttFusion wa; wa.work = hp->t;
+        NttFusion wb; wb.work = h_out->data;
+        hp->ntt.passes(pa, hp->a, hp->a, true, false, true, hp->ntt.twist, nullptr, &wa);      // S8 ifft + twist :110-128
+        hp->ntt.passes(pb, hp->b, hp->b, true, false, true, hp->ntt.twist, nullptr, &wb);
+        const NttPass* inv3[3] = {pa, pb, pc};
+        for (int p = 0; p < np; p++) hp->ntt.launch(inv3, 3, p, st, &c->stats[2]);
+        // S8 fft :130-140, in place on a and b; chain c's last pass also forms h = a o b - c (S9 :142-148) from the FINISHED
+        // a and b, so it goes after theirs
+        hp->ntt.passes(pa, hp->a, hp->a, false, false, false, nullptr, nullptr, nullptr);
+        hp->ntt.passes(pb, hp->b, hp->b, false, false, false, nullptr, nullptr, nullptr);
+        hp->ntt.passes(pc, h_out->data, hp->t2, false, false, false, nullptr, nullptr, &cfwd);
+        const NttPass* fwd3[3] = {pa, pb, pc};
+        for (int p = 0; p + 1 < np; p++) hp->ntt.launch(fwd3, 3, p, st, &c->stats[2]);
+        hp->ntt.launch(fwd3, 2, np - 1, st, &c->stats[2]);
+        const NttPass* last[1] = {pc};
+        hp->ntt.launch(last, 1, np - 1, st, &c->stats[2]);
+    } else {
+        // S7 + the inverse half of the third chain: c = a o b is formed inside the first pass of its ifft (:100-108), whose
+        // passes run on hp->c so that a and b stay intact; the twisted coefficients wait in hp->t2
+        hp->ntt.transform(hp->t2, hp->a, /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, &c->stats[2], &cinv);
+        // S8: ifft, twist by omega_2n^i (with 1/n folded in), fft          :110-140
+        u32* polys[2] = {hp->a, hp->b};
+        for (int p = 0; p < 2; p++) {
+            hp->ntt.transform(hp->t, polys[p], /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, &c->stats[2]);
+            hp->ntt.transform(polys[p], hp->t, /*inverse*/ false, false, false, nullptr, nullptr, st, &c->stats[2]);
+        }
+        // the forward half of the third chain, with S9 (h = a o b - c, to plain integers, :142-148) inside its last pass
+        hp->ntt.transform(h_out->data, hp->t2, /*inverse*/ false, false, false, nullptr, nullptr, st, &c->stats[2], &cfwd);
+    }
     tm.stop();
     UG_CATCH
 }
