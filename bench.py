@@ -4,31 +4,33 @@
     python bench.py --gpus N --steps K --warmup W [--log-domain 24] [--mix U|C]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step is one proof of a seeded synthetic circuit (ultragroth_amd/synth.py, shapes of SURVEY.md section 8d) as SURVEY.md
-section 8(d) defines the metric: the wall time of `groth16_prover_prove` on a CREATED prover with the .wtns in HOST
-memory -- parse, host-to-device copy of the witness, the five MSMs and the H-polynomial block on the device, blinding and
-JSON on the host. `value` is therefore PCIe-inclusive for the witness (512 MiB at 2^24). At N = 1 the K timed steps are
-issued from two host threads on the ONE prover object (--host-threads): the reference's prover keeps no per-proof state,
-so callers may do that, and here the witness of the next call is copied into a second device buffer while the kernels of
-the current call run -- `value` = K / the wall time of those K whole proofs. `sequential_ms_per_step` (the same K steps
-strictly one after the other: the latency of one proof), `witness_upload_ms_per_proof` and `resident_ms_per_step` (a
-sequential step minus its upload) are extra keys. `create` (zkey upload, conversion, window
-tables) is reported separately as `create_s`. Default workload: configs[2] of BASELINE.json, the 2^24-constraint circuit
-with full G1+G2 MSMs that the 10x target is quoted on.
+A step is one proof of a seeded synthetic circuit (ultragroth_amd/synth.py, shapes of SURVEY.md section 8d): the whole hot
+path S1-S13 of src/groth16.cpp:48-203 -- the five MSMs and the H-polynomial block on the device, blinding and JSON on the
+host -- on a CREATED prover with the witness ALREADY RESIDENT IN HBM when the timed region starts, K steps strictly one
+after the other from one host thread: `value` = K / their wall time, `ms_per_step` its inverse, and `msm_ms_per_proof` /
+`fft_ms_per_proof` are the device times of the MSM and FFT parts of exactly those K steps. Default workload: configs[2] of
+BASELINE.json, the 2^24-constraint circuit with full G1+G2 MSMs that the 10x target is quoted on.
+Beside it, outside that region (N = 1): `prove_call_ms_per_step` = the same K proofs through `groth16_prover_prove` with the
+.wtns in HOST memory, one call after the other (SURVEY.md section 8(d)'s "ms/proof": parse + PCIe copy of the witness, 512 MiB
+at 2^24, + device + host; `witness_upload_ms_per_proof` is the copy's share), and `pipelined_proofs_per_s` = the K calls issued
+from `--host-threads` threads on the one prover object (the reference's prover keeps no per-proof state, so its callers may;
+here the witness of the waiting call is copied while the kernels of the running one execute). `create_s` = zkey upload,
+conversion and window tables.
 
-With N > 1 ranks the base points of every section are sharded by contiguous range (one process per GPU), every rank
-uploads the witness, computes partial sums of the five MSMs over its slice, the 384-byte partial records are
-all-gathered over RCCL and added on every rank (an EC addition is not an RCCL reduction operator), and rank 0
-finishes the proof. The three NTT chains of the H polynomial are taken by ranks 0..2 and their evaluation vectors
-scattered slice-wise over RCCL, so each rank forms only its own slice of h. The same proof is produced at every N
-("strong" scaling of one proof).
+With N > 1 ranks the base points of every section are sharded by contiguous range (one process per GPU); the witness is
+resident as at N = 1 (each rank its slice; the ranks that run an H-polynomial chain all of it). A step: partial sums of the
+five MSMs over the rank's slices, the three NTT chains on ranks 0..2 with their evaluation vectors scattered slice-wise over
+RCCL, every rank's slice of h and its H-MSM shard, the 384-byte partial records all-gathered over RCCL and added on every
+rank (an EC addition is not an RCCL reduction operator), rank 0 finishes. The same proof is produced at every N ("strong"
+scaling of one proof). `comm` records what the live process group is (backend, world size, RCCL version).
 
-Rank 0 prints ONE JSON line. `roofline` is for the G1 bucket-accumulation kernel (the dominant one), with the G2
-accumulation and the NTT pass kernel beside it under `roofline.kernels`; all three are measured in this run with HIP
-events on the launch stream inside the library. `cpu_baseline` times the CPU oracle (oracle/, OpenMP) on bounded
-samples. The oracle is the checker/baseline only; the timed path never touches it. `--check` proves once more with
-fixed blinding and compares proof.json byte for byte with the expected proof (oracle/closed_form.py: oracle H polynomial
-+ MSMs in the exponent, any size); a mismatch makes the exit code 3.
+Rank 0 prints ONE JSON line. `roofline` is for the bucket-accumulation kernel that takes most of a step, the other large
+kernels beside it under `roofline.kernels`; all are measured in this run with HIP events on the launch stream inside the
+library. `cpu_baseline` times the CPU oracle (oracle/, OpenMP, mulx/adcx/adox Montgomery) on the benchmarked circuit itself
+when that takes about two minutes or less (2^24: yes), else on bounded samples with a fitted extrapolation, marked so. The
+oracle is the checker/baseline only; the timed path never touches it. `--check` proves once more with fixed blinding and
+compares proof.json byte for byte with the expected proof (oracle/closed_form.py: oracle H polynomial + MSMs in the
+exponent, any size); a mismatch makes the exit code 3.
 """
 import argparse
 import json
@@ -90,60 +92,65 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(dev, args, log_domain):
-    """Oracle (plain C + OpenMP) on bounded samples of the same generator. The proof is timed at two sizes (2^20 and 2^22
-    by default, the larger one twice, about 30 s of CPU work together), MSM and FFT parts separately; each part is extrapolated to the
-    benchmarked size with ITS OWN fitted exponent (t ~ N^e: Pippenger is sub-linear, the FFT block N log N), not
-    linearly. A benchmarked size at or below the larger sample is measured directly. The box may show more cores than
-    its share (16 per GPU): the small sample is timed with the detected share and with 16 and 32 threads when those are
-    fewer, and the fastest setting is kept (the baseline gets every benefit)."""
+def cpu_baseline(dev, args, log_domain, circuit=None):
+    """Oracle (plain C + OpenMP; Montgomery product in mulx / adcx / adox form, oracle/field.h) on the SAME generator.
+    A 2^20 sample (2^lo in general) is timed first, with the detected CPU share and with 16 and 32 threads when those are
+    fewer (the box may show more cores than its share; the fastest setting is kept: the baseline gets every benefit). If the
+    benchmarked size is then expected to take at most ~150 s it is proved DIRECTLY (`extrapolated`: false; `circuit` = the
+    (zkey, wtns) the GPU just proved, when the caller still holds it). Otherwise 2^hi is timed too and MSM and FFT parts are
+    extrapolated with their own fitted exponents (t ~ N^e: Pippenger is sub-linear, the FFT block N log N), marked so."""
     import math
     import oracle as O
     from ultragroth_amd import synth
-    hi = args.cpu_sample_log if args.cpu_sample_log is not None else min(log_domain, 22)
-    lo = max(min(hi - 2, 20), 10) if hi > 12 else hi
     share = cpu_share()
 
-    def timed(log, threads):
-        zk, wt, _ = synth.build_circuit(dev, log, mix=args.mix, g1_only=args.g1_only)
+    def timed(log, threads, given=None):
+        zk, wt = given if given is not None else synth.build_circuit(dev, log, mix=args.mix, g1_only=args.g1_only)[:2]
         O.lib.ugo_set_num_threads(threads)
         t0 = time.perf_counter()
         _, _, (msm_s, fft_s) = O.groth16_prove(zk, wt, 12345, 67890, want_timings=True)
         return time.perf_counter() - t0, msm_s, fft_s, O.lib.ugo_num_threads()
 
+    cap = args.cpu_sample_log if args.cpu_sample_log is not None else log_domain
+    lo = min(cap, 20, log_domain)
     best = None
     for threads in sorted({share, min(share, 16), min(share, 32)}):
         t = timed(lo, threads)
         if best is None or t[0] < best[0]:
             best = t
     dt_lo, msm_lo, fft_lo, cores = best
-    if hi > lo:
-        # the host is shared with other tenants' jobs: the faster of two runs (12 vs 14 s were seen for the same sample, and
-        # the fitted exponents double such noise in the extrapolation)
-        dt_hi, msm_hi, fft_hi, _ = min(timed(hi, cores), timed(hi, cores))
-    else:
-        dt_hi, msm_hi, fft_hi = dt_lo, msm_lo, fft_lo
-    rest_hi = max(dt_hi - msm_hi - fft_hi, 0.0)                # parsing, blinding, JSON: grows at most linearly
-    # for reference, one thread against all of them on a small circuit (SURVEY.md section 8d)
-    one_log = min(lo, 16)
+    one_log = min(lo, 16)                                       # for reference: one thread against all of them (SURVEY.md section 8d)
     one = timed(one_log, 1)
     many = timed(one_log, cores)
-    if log_domain > hi:
-        e_msm = math.log2(msm_hi / msm_lo) / (hi - lo)
-        e_fft = math.log2(fft_hi / fft_lo) / (hi - lo)
-        k = log_domain - hi
-        est = msm_hi * 2.0 ** (e_msm * k) + fft_hi * 2.0 ** (e_fft * k) + rest_hi * 2.0 ** k
-        how = ("extrapolated to 2^%d with the fitted exponents t ~ N^e: MSM e = %.3f, FFT e = %.3f -> %.1f s per proof"
-               % (log_domain, e_msm, e_fft, est))
+    direct_guess = dt_lo * 2.0 ** (log_domain - lo)             # (linear: an upper bound, Pippenger is sub-linear)
+    samples = "2^%d in %.2f s (MSM %.2f | FFT %.2f)" % (lo, dt_lo, msm_lo, fft_lo)
+    if log_domain == lo:
+        est, msm_s, fft_s, extrapolated, how = dt_lo, msm_lo, fft_lo, False, "measured at the benchmarked size"
+    elif cap >= log_domain and direct_guess <= 150.0:
+        est, msm_s, fft_s, _ = timed(log_domain, cores, circuit)
+        extrapolated, how = False, "the benchmarked 2^%d circuit itself proved in %.1f s (MSM %.1f | FFT %.1f)" % (log_domain, est, msm_s, fft_s)
     else:
-        est = dt_hi
-        how = "measured at the benchmarked size"
+        hi = max(min(cap, log_domain - 1, 22), lo + 1) if lo + 1 <= min(cap, log_domain) else lo
+        if hi > lo:
+            dt_hi, msm_hi, fft_hi, _ = min(timed(hi, cores), timed(hi, cores))      # the host is shared: the faster of two runs
+            samples += ", 2^%d in %.2f s (MSM %.2f | FFT %.2f)" % (hi, dt_hi, msm_hi, fft_hi)
+            e_msm = math.log2(msm_hi / msm_lo) / (hi - lo)
+            e_fft = math.log2(fft_hi / fft_lo) / (hi - lo)
+        else:
+            dt_hi, msm_hi, fft_hi, e_msm, e_fft = dt_lo, msm_lo, fft_lo, 0.9, 1.0
+        rest_hi = max(dt_hi - msm_hi - fft_hi, 0.0)            # parsing, blinding, JSON: grows at most linearly
+        k = log_domain - hi
+        msm_s, fft_s = msm_hi * 2.0 ** (e_msm * k), fft_hi * 2.0 ** (e_fft * k)
+        est = msm_s + fft_s + rest_hi * 2.0 ** k
+        extrapolated = True
+        how = ("EXTRAPOLATED to 2^%d with the fitted exponents t ~ N^e: MSM e = %.3f, FFT e = %.3f -> %.1f s per proof"
+               % (log_domain, e_msm, e_fft, est))
     return {
-        "value": 1.0 / est, "unit": "proofs/s", "cores": cores, "kind": "port",
+        "value": 1.0 / est, "unit": "proofs/s", "cores": cores, "kind": "port", "extrapolated": extrapolated,
+        "seconds_per_proof": est, "msm_s": msm_s, "fft_s": fft_s,
         "cpu": "%s, nproc %d, share %d" % (cpu_model(), os.cpu_count() or 0, share),
-        "sample": "oracle (restated rapidsnark-equivalent CPU path, plain C + OpenMP, %d threads) proving the 2^%d circuit of the "
-                  "same generator in %.2f s (MSM %.2f | FFT %.2f) and the 2^%d circuit in %.2f s (MSM %.2f | FFT %.2f); %s"
-                  % (cores, lo, dt_lo, msm_lo, fft_lo, hi, dt_hi, msm_hi, fft_hi, how),
+        "sample": "oracle (restated rapidsnark-equivalent CPU path: plain C + OpenMP, mulx/adcx/adox Montgomery product, %d threads, one proof at "
+                  "a time, inputs in memory) on circuits of the same generator: %s; %s" % (cores, samples, how),
         "single_thread": {"log_domain": one_log, "seconds_1_thread": one[0], "seconds_all_threads": many[0], "threads": cores},
     }
 
@@ -389,8 +396,9 @@ def main():
         t0 = time.perf_counter()
         prover = ug.Groth16Prover(zkey)          # groth16_prover_create: the reference's own entry point
         create_s = time.perf_counter() - t0
-        if not args.check:
+        if not args.check and args.no_cpu_baseline:
             del zkey
+            zkey = None
     else:
         # every rank makes ONLY its slices of the point sections (same generator walk, entered at the slice); the
         # coefficient records only on the ranks that run an H-polynomial chain: no rank holds the whole zkey
@@ -437,20 +445,26 @@ def main():
 
     my_chains = [k for k in range(3) if k % world == rank] if split_h else []
 
+    def load():
+        """the witness into HBM (outside the timed region: BASELINE contract -- inputs resident when the timed region starts)"""
+        if world == 1 or not split_h:
+            prover.load_witness(wtns)
+            return
+        prover.load_witness_part(wtns, 0)        # this rank's slice of the scalars: all its witness MSMs read
+        if my_chains:
+            prover.load_witness_part(wtns, 1)    # the rest: only the mat-vec of a chain rank reads it
+
     def run_chains():
-        # the H-polynomial branch has its own stream inside the library: the rest of the witness (all the mat-vec reads)
-        # is uploaded there, then the chains run, beside this rank's witness MSMs
-        prover.load_witness_part(wtns, 1)
         for k in my_chains:
             prover.hpoly_chain(k, fulls[k].data_ptr())
 
     def step():
+        """one proof from the witness resident in HBM: S1-S13 of src/groth16.cpp:48-203"""
         if world == 1:
-            return prover.prove(wtns)            # groth16_prover_prove on the .wtns in host memory: THE metric
+            return prover.finish(prover.run())
         if split_h:
-            prover.load_witness_part(wtns, 0)    # this rank's slice of the scalars: all its witness MSMs read
             th = None
-            if my_chains:
+            if my_chains:                        # the H branch has its own stream inside the library: chains beside the MSMs
                 th = threading.Thread(target=run_chains)
                 th.start()
             part = prover.run_witness_msm()
@@ -464,7 +478,6 @@ def main():
             prover.hpoly_combine(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr())
             part = part[:320] + prover.run_h_msm()[320:384]
         else:                                    # the domain does not split evenly: every rank forms h itself
-            prover.load_witness(wtns)
             part = prover.run()
         mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)
         if backend == "nccl":
@@ -477,60 +490,20 @@ def main():
         return prover.finish(total) if rank == 0 else None
 
     out = None
+    load()
     for _ in range(args.warmup):
         out = step()
     for which in range(4):
         prover.kernel_stats(which=which, reset=True)
-    msm_ms = fft_ms = upload_ms = 0.0
-    host_threads = max(1, args.host_threads) if world == 1 else 1
-    sequential_ms = None
-    if host_threads > 1:
-        # the same K steps strictly one after the other first (an extra figure: the latency of one proof)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-            m, f, _ = prover.last_timings()
-            msm_ms += m
-            fft_ms += f
-            upload_ms += prover.last_upload_ms()
-        barrier()
-        sequential_ms = 1e3 * (time.perf_counter() - t0) / args.steps
-    tally = threading.Lock()
-    todo = iter(range(args.steps))
-
-    failures = []
-
-    def issue_steps():
-        nonlocal out, msm_ms, fft_ms, upload_ms
-        while True:
-            with tally:
-                if failures or next(todo, None) is None:
-                    return
-            try:
-                o = step()
-            except BaseException as e:          # a helper thread must not lose a step silently: the run fails below
-                with tally:
-                    failures.append(e)
-                return
-            m, f, _ = prover.last_timings()
-            with tally:
-                out = o
-                if sequential_ms is None:       # (with several host threads these figures come from the sequential steps:
-                    msm_ms += m                 #  a copy that runs beside another proof's kernels takes longer and is hidden)
-                    fft_ms += f
-                    upload_ms += prover.last_upload_ms()
-
+    # ---- THE timed region: K proofs, one after the other, witness resident in HBM ----
+    msm_ms = fft_ms = 0.0
     barrier()
     t0 = time.perf_counter()
-    helpers = [threading.Thread(target=issue_steps) for _ in range(host_threads - 1)]
-    for th in helpers:
-        th.start()
-    issue_steps()
-    for th in helpers:
-        th.join()
-    if failures:
-        raise failures[0]
+    for _ in range(args.steps):
+        out = step()
+        m, f, _ = prover.last_timings()
+        msm_ms += m
+        fft_ms += f
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -538,18 +511,63 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    kstats = [prover.kernel_stats(which=w) for w in range(4)]      # of the K timed steps only (reset after the warm-up)
+
+    # ---- extra figures (N = 1), outside the contract's region: the same K proofs through groth16_prover_prove with the .wtns
+    # in HOST memory -- SURVEY.md section 8(d)'s "ms/proof": parse + PCIe copy + device + host -- one call after the other, and
+    # from `--host-threads` threads on the one prover object (the witness copy of a call runs beside the kernels of the other)
+    host_threads = max(1, args.host_threads) if world == 1 else 1
+    prove_call_ms = upload_ms = pipelined_s = None
+    if world == 1:
+        prover.prove(wtns)
+        t1 = time.perf_counter()
+        upload_ms = 0.0
+        for _ in range(args.steps):
+            out = prover.prove(wtns)
+            upload_ms += prover.last_upload_ms()
+        prove_call_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+        upload_ms /= args.steps
+        if host_threads > 1:
+            tally = threading.Lock()
+            todo = iter(range(args.steps))
+            failures = []
+
+            def issue_steps():
+                while True:
+                    with tally:
+                        if failures or next(todo, None) is None:
+                            return
+                    try:
+                        prover.prove(wtns)
+                    except BaseException as e:      # a helper thread must not lose a step silently: the run fails below
+                        with tally:
+                            failures.append(e)
+                        return
+            t1 = time.perf_counter()
+            helpers = [threading.Thread(target=issue_steps) for _ in range(host_threads - 1)]
+            for th in helpers:
+                th.start()
+            issue_steps()
+            for th in helpers:
+                th.join()
+            if failures:
+                raise failures[0]
+            pipelined_s = time.perf_counter() - t1
+
     chk = None
     if args.check:                              # one more step on EVERY rank (it contains collectives), fixed blinding
         ug.set_test_blinding(bytes(range(1, 32)) + bytes(range(31, 62)))
         chk = step()
+        if world == 1:                          # ... and once more through the reference's entry point, witness in host memory
+            ug.set_test_blinding(bytes(range(1, 32)) + bytes(range(31, 62)))
+            if prover.prove(wtns) != chk:
+                chk = ("groth16_prover_prove differs from the phase calls", "")
         ug.set_test_blinding(b"")
 
     rc = 0
     if rank == 0:
-        acc_ms, launches, entries = prover.kernel_stats(which=0)
-        g2_ms, g2_launches, g2_entries = prover.kernel_stats(which=1)
-        ntt_ms, ntt_launches, ntt_points = prover.kernel_stats(which=2)
-        grp_ms, grp_launches, grp_entries = prover.kernel_stats(which=3)       # A | B1 | C in one launch (three products per entry)
+        (acc_ms, launches, entries), (g2_ms, g2_launches, g2_entries), (ntt_ms, ntt_launches, ntt_points) = kstats[:3]
+        grp_ms, grp_launches, grp_entries = kstats[3]                          # A | B1 | C in one launch (three products per entry)
         ws = witness_slice(info, 0, world)
         n_local = (ws[1] - ws[0]) if ws else info["nVars"] // world
         # Algorithmic bytes per launch (restated in DESIGN.md): G1 accumulation 96 B per point of
@@ -563,69 +581,80 @@ def main():
 
         def mads(per_unit, units, n, ms):
             return (per_unit * units / max(n, 1) / (ms * 1e-3) / 1e12) if ms > 0 else 0.0
-        achieved = gbs(g1_bytes, acc_ms)
-        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, corrected as the microarch guide says):
-        # NOT measured in this run -- read from the committed summary of the same workload under profiles/ (null if absent)
-        traffic, traffic_source = None, None
-        for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        # One entry per large kernel, all measured in THIS run with HIP events on the launch stream inside the library.
+        # Algorithmic bytes per launch: each base and each scalar read once.
+        # issue_bound: the roof that actually binds -- v_mad_u64_u32 issue, 29 T mad/s measured (tools/ubench_int.hip); one G1
+        # mixed addition = 1467 mads, G2 4470
+        def entry(name, nbytes, ms, n_launch, units, mad_per_unit=None, **extra):
+            e = {"bound": "hbm", "kernel": name, "achieved": gbs(nbytes, ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": gbs(nbytes, ms) / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                 "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms, "launches": n_launch,
+                 "ms_per_step": ms * n_launch / max(args.steps, 1)}
+            if mad_per_unit:
+                e["issue_bound"] = {"unit": "T mad/s", "peak": 29.0, "achieved": mads(mad_per_unit, units, n_launch, ms),
+                                    "frac": mads(mad_per_unit, units, n_launch, ms) / 29.0}
+            e.update(extra)
+            return e
+        kern = [entry("segment_accumulate_kernel<G1Cfg>", g1_bytes, acc_ms, launches, entries, 1467.0),
+                entry("segment_accumulate_kernel<G2Cfg>", g2_bytes, g2_ms, g2_launches, g2_entries, 4470.0),
+                entry("segment_accumulate_group_kernel<3>", grp_bytes, grp_ms, grp_launches, grp_entries, 1467.0, products_per_launch=3),
+                entry("ntt_pass_kernel", ntt_bytes * (ntt_points / max(ntt_launches, 1) / info["domainSize"] if ntt_launches else 1.0), ntt_ms,
+                      ntt_launches, ntt_points, None, transforms_per_launch=(ntt_points / max(ntt_launches, 1) / info["domainSize"]) if ntt_launches else None)]
+        kern = [e for e in kern if e["launches"]]
+        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, corrected as the microarch guide says): NOT
+        # measured in this run -- read from the committed summary of the same workload under profiles/ (null if absent)
+        for name in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
-                k = pmc.get(str(log_domain), {}).get("segment_accumulate_kernel<G1Cfg>")
-                if k and world == 1 and args.mix == "U" and not args.g1_only:
-                    traffic = k["fetch"] + k["write"]
-                    traffic_source = "profiles/%s (separate rocprofv3 --pmc passes on this workload; not measured in this run)" % name
-                    break
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name))).get(str(log_domain), {})
             except Exception:
-                pass
+                continue
+            for e in kern:
+                k = pmc.get(e["kernel"])
+                if k and e["traffic"] is None and world == 1 and args.mix == "U" and not args.g1_only:
+                    e["traffic"] = k["fetch"] + k["write"]
+                    e["traffic_source"] = "profiles/%s (separate rocprofv3 --pmc passes on this workload; not measured in this run)" % name
+        kern.sort(key=lambda e: -e["ms_per_step"])
+        roofline = dict(kern[0]) if kern else {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None}
+        roofline["kernels"] = {e["kernel"]: e for e in kern[1:]}
+        roofline["note"] = ("the kernel with the largest share of a step; integer-issue-bound kernels: issue_bound gives modmul work against the "
+                            "v_mad_u64_u32 peak (DESIGN.md)")
         ms_per_step = 1e3 * elapsed / args.steps
+        comm = None
+        if dist is not None:
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+            except Exception:
+                ver = None
+            comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": ver,
+                    "devices_visible": torch.cuda.device_count()}
         res = {
             "metric": "proofs/s", "value": args.steps / elapsed, "unit": "proofs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 254-bit modular integers)",
             "data": "synthetic",
             "config": {"workload": "groth16-bn254 2^%d constraints, nVars 2^%d-1, nCoefs 4N, %s + H-poly FFT, scalar mix %s "
-                                   "(BASELINE.json configs[%d] shape); step = groth16_prover_prove on a created prover, .wtns in host memory%s"
+                                   "(BASELINE.json configs[%d] shape); step = one proof (S1-S13) on a created prover, witness resident in HBM, "
+                                   "one proof after the other from one host thread"
                                    % (log_domain, log_domain, "G1 MSMs A and H only" if args.g1_only else "full G1+G2 MSM", args.mix,
-                                      1 if args.g1_only else 2,
-                                      "; the K steps are issued from %d host threads on the one prover object, so the witness copy of a "
-                                      "step runs beside the kernels of the step before" % host_threads if host_threads > 1 else ""),
-                       "log_domain": log_domain, "mix": args.mix, "host_threads": host_threads, "overlap": bool(os.environ.get("ULTRAGROTH_OVERLAP", "0") not in ("", "0")),
+                                      1 if args.g1_only else 2),
+                       "log_domain": log_domain, "mix": args.mix, "overlap": bool(os.environ.get("ULTRAGROTH_OVERLAP", "0") not in ("", "0")),
+                       "fused_g1_group": os.environ.get("ULTRAGROTH_FUSED", "1") != "0",
                        "parallelism": "one GPU" if world == 1 else "base-range shard x%d%s" % (world, ", H-poly chains split over ranks" if split_h else "")},
             "msm_ms_per_proof": msm_ms / args.steps, "fft_ms_per_proof": fft_ms / args.steps,
-            "witness_upload_ms_per_proof": upload_ms / args.steps,
-            "sequential_ms_per_step": sequential_ms if sequential_ms is not None else ms_per_step,
-            "resident_ms_per_step": (sequential_ms if sequential_ms is not None else ms_per_step) - upload_ms / args.steps,
-            "witness_upload_gbs": (32.0 * info["nVars"] / (upload_ms / args.steps * 1e-3) / 1e9) if upload_ms > 0 else None,
+            "split_region": "device time of the MSM (S1-S4, S10) and FFT (S5-S9) parts of the K timed steps themselves",
+            "comm": comm,
+            # outside the timed region (N = 1): the reference's call with the .wtns in host memory
+            "prove_call_ms_per_step": prove_call_ms,
+            "witness_upload_ms_per_proof": upload_ms,
+            "witness_upload_gbs": (32.0 * info["nVars"] / (upload_ms * 1e-3) / 1e9) if upload_ms else None,
+            "pipelined_proofs_per_s": (args.steps / pipelined_s) if pipelined_s else None,
+            "pipelined_host_threads": host_threads if pipelined_s else None,
             "create_s": create_s, "zkey_bytes": zkey_bytes, "zkey_ingest_gbs": zkey_bytes / create_s / 1e9,
             "host_peak_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 2),
-            "roofline": {"bound": "hbm", "kernel": "segment_accumulate_kernel<G1Cfg>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": g1_bytes,
-                         "avg_launch_ms": acc_ms, "launches": launches,
-                         # the bound that actually binds: v_mad_u64_u32 issue (29 T mad/s measured, tools/ubench_int.hip);
-                         # one G1 mixed addition = 1467 mads, G2 4470, one NTT butterfly 162
-                         "issue_bound": {"unit": "T mad/s", "peak": 29.0, "achieved": mads(1467.0, entries, launches, acc_ms),
-                                         "frac": mads(1467.0, entries, launches, acc_ms) / 29.0},
-                         "kernels": {
-                             "segment_accumulate_kernel<G2Cfg>": {
-                                 "bound": "hbm", "achieved": gbs(g2_bytes, g2_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": gbs(g2_bytes, g2_ms) / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": g2_bytes,
-                                 "avg_launch_ms": g2_ms, "launches": g2_launches,
-                                 "issue_bound_frac": mads(4470.0, g2_entries, g2_launches, g2_ms) / 29.0},
-                             "segment_accumulate_group_kernel<3>": {
-                                 "bound": "hbm", "achieved": gbs(grp_bytes, grp_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": gbs(grp_bytes, grp_ms) / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": grp_bytes,
-                                 "avg_launch_ms": grp_ms, "launches": grp_launches, "products_per_launch": 3,
-                                 "issue_bound_frac": mads(1467.0, grp_entries, grp_launches, grp_ms) / 29.0},
-                             "ntt_pass_kernel": {
-                                 "bound": "hbm", "achieved": gbs(ntt_bytes, ntt_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": gbs(ntt_bytes, ntt_ms) / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ntt_bytes,
-                                 "avg_launch_ms": ntt_ms, "launches": ntt_launches,
-                                 "passes_per_transform": (ntt_launches / (6.0 * args.steps)) if world == 1 else None}},
-                         "note": "integer-issue-bound kernels: see DESIGN.md for modmul/s against the v_mad_u64_u32 peak"},
+            "roofline": roofline,
         }
         if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(dev, args, log_domain)
+            res["cpu_baseline"] = cpu_baseline(dev, args, log_domain, (zkey, wtns) if zkey is not None else None)
         if args.check:
             from oracle import closed_form
             if zkey is None:                     # N > 1: only now, and only on rank 0, the whole zkey is made (for its coefficient section)

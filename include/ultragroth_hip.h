@@ -124,6 +124,10 @@ int  ug_fr_lookup_table(ug_ctx* ctx, const void* rand_plain, const uint32_t* fre
 /* non-owning view of n 32-byte elements already in device memory (e.g. a torch / RCCL buffer) */
 int  ug_dvec_wrap(ug_ctx* ctx, void* device_ptr, uint64_t n, ug_dvec** out);
 uint64_t ug_dvec_size(const ug_dvec* v);
+/* raw device address of a vector's first element (for the phase calls of include/prover.h that take device pointers) */
+void* ug_dvec_device_ptr(const ug_dvec* v);
+/* dst[dst_first .. + count) = src[src_first .. + count) between vectors of ANY two devices of the node (blocking) */
+int  ug_dvec_copy(ug_dvec* dst, uint64_t dst_first, const ug_dvec* src, uint64_t src_first, uint64_t count);
 void ug_dvec_destroy(ug_dvec* v);
 
 /* Decompose scalars [first, first + count) of `scalars` (plain 32-byte integers) into signed window

@@ -54,7 +54,7 @@ def _load():
         getattr(L, name).argtypes = [vp, vp, vp]
     L.ugo_g1_on_curve.argtypes = [vp]
     L.ugo_g2_on_curve.argtypes = [vp]
-    for name in ("ugo_f_mul", "ugo_f_add", "ugo_f_sub"):
+    for name in ("ugo_f_mul", "ugo_f_mul_portable", "ugo_f_add", "ugo_f_sub"):
         getattr(L, name).argtypes = [C.c_int, vp, vp, vp]
     for name in ("ugo_f_neg", "ugo_f_to_mont", "ugo_f_from_mont", "ugo_f_inv"):
         getattr(L, name).argtypes = [C.c_int, vp, vp]

@@ -134,6 +134,10 @@ static const fctx *pick(int which) { return which == UGO_FIELD_FQ ? &UGO_FQ : &U
 void ugo_f_mul(int which, uint64_t *r, const uint64_t *a, const uint64_t *b) {
     fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe_mul(&z, &x, &y, pick(which)); memcpy(r, &z, 32);
 }
+/* the portable form of the product (field.h: fe_mul_c), for the cross-check of the two in tests/test_oracle.py */
+void ugo_f_mul_portable(int which, uint64_t *r, const uint64_t *a, const uint64_t *b) {
+    fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe_mul_c(&z, &x, &y, pick(which)); memcpy(r, &z, 32);
+}
 void ugo_f_add(int which, uint64_t *r, const uint64_t *a, const uint64_t *b) {
     fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe_add(&z, &x, &y, pick(which)); memcpy(r, &z, 32);
 }

@@ -14,6 +14,7 @@
 #define UGO_FIELD_FQ 1
 
 void ugo_f_mul(int which, uint64_t *r, const uint64_t *a, const uint64_t *b);
+void ugo_f_mul_portable(int which, uint64_t *r, const uint64_t *a, const uint64_t *b);
 void ugo_f_add(int which, uint64_t *r, const uint64_t *a, const uint64_t *b);
 void ugo_f_sub(int which, uint64_t *r, const uint64_t *a, const uint64_t *b);
 void ugo_f_neg(int which, uint64_t *r, const uint64_t *a);

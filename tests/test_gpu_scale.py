@@ -248,13 +248,14 @@ def test_bench_two_ranks_over_rccl():
 
 def test_bench_line_contract_one_gpu():
     """`python bench.py` as the driver runs it at N = 1 (here at 2^16 so that it takes seconds): exactly one JSON line
-    with the contract's keys, the `roofline` and `cpu_baseline` objects, K timed steps issued from two host threads,
-    `--check` bit-exact (a mismatch would make the exit code 3)"""
+    with the contract's keys, the `roofline` and `cpu_baseline` objects; the K timed steps run one after the other on the
+    resident witness, the PCIe-inclusive call and the two-thread figure come as extra keys; `--check` bit-exact (a mismatch
+    would make the exit code 3); the CPU baseline is measured at the benchmarked size, not extrapolated"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--log-domain", "16",
-                        "--cpu-sample-log", "14", "--check"], capture_output=True, text=True, timeout=600)
+                        "--check"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
@@ -265,15 +266,20 @@ def test_bench_line_contract_one_gpu():
     assert d["metric"] == "proofs/s" and d["unit"] == "proofs/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
     assert abs(d["value"] * d["ms_per_step"] - 1e3) < 1e-6 * 1e3
-    assert d["config"]["host_threads"] == 2 and d["sequential_ms_per_step"] > 0
+    assert "resident in HBM" in d["config"]["workload"] and d["comm"] is None
+    assert d["prove_call_ms_per_step"] > d["ms_per_step"] * 0.5 and d["witness_upload_ms_per_proof"] > 0
+    assert d["pipelined_proofs_per_s"] > 0 and d["pipelined_host_threads"] == 2
+    assert d["msm_ms_per_proof"] > 0 and d["fft_ms_per_proof"] > 0 and d["msm_ms_per_proof"] + d["fft_ms_per_proof"] < d["ms_per_step"] * 1.05
     rf = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernels"):
         assert key in rf, key
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches"] > 0
+    assert all(rf["ms_per_step"] >= k["ms_per_step"] for k in rf["kernels"].values())        # the top entry is the dominant kernel
+    assert rf["launches"] % 3 == 0                                                            # counted over the K timed steps only
     cb = d["cpu_baseline"]
-    for key in ("value", "unit", "cores", "kind", "sample"):
+    for key in ("value", "unit", "cores", "kind", "sample", "extrapolated"):
         assert key in cb, key
-    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["extrapolated"] is False
     assert d.get("check") == "bit-exact"
 
 
@@ -453,6 +459,58 @@ def test_cli_prover_end_to_end(tmp_path, zkey, wtns, vkey):
     r = subprocess.run([exe + "_ultra_groth", os.path.join(golden, "circuit_final.zkey"), os.path.join(golden, "witness.wtns"),
                         proof_path, public_path], capture_output=True, text=True)
     assert r.returncode == 1 and "zkey file is not ultragroth" in r.stderr
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0", "0,0,0,0,0"])
+def test_cli_and_api_on_several_devices(device, tmp_path, devices):
+    """ULTRAGROTH_DEVICES: the reference's own entry points -- `prover <zkey> <wtns> <proof.json> <public.json>`
+    (src/main_prover.cpp:17-85) and groth16_prover_create / _prove (src/prover.cpp:681-723) -- shard one proof over the
+    listed devices inside the library (one host thread and context pair per rank, peer copies of the evaluation-vector
+    slices, partial sums added on the host): no Python, no torch. Rehearsed with one device listed several times; the files
+    and the API's strings equal the single-device proof byte for byte (fixed blinding through the test hook). Five ranks:
+    the domain does not split evenly, the slices differ in length; two: a rank runs two chains."""
+    import subprocess
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "ultragroth_amd", "csrc", "prover")
+    zkey, wtns, info = synth.build_circuit(device, 14, mix="C", seed=0x5EED0A00)
+    r, s = fixed_rs()
+    exp = O.groth16_prove(zkey, wtns, int.from_bytes(r, "little"), int.from_bytes(s, "little"))[:2]
+    zpath, wpath = tmp_path / "c.zkey", tmp_path / "w.wtns"
+    zpath.write_bytes(bytes(zkey)); wpath.write_bytes(wtns)
+    env = dict(os.environ, ULTRAGROTH_TEST_HOOKS="1", ULTRAGROTH_TEST_BLINDING=(r + s).hex())
+    for dev in (None, devices):
+        e = dict(env)
+        if dev:
+            e["ULTRAGROTH_DEVICES"] = dev
+        out = subprocess.run([exe, str(zpath), str(wpath), str(tmp_path / "proof.json"), str(tmp_path / "public.json")],
+                             capture_output=True, text=True, timeout=300, env=e)
+        assert out.returncode == 0, out.stderr
+        assert ((tmp_path / "proof.json").read_text(), (tmp_path / "public.json").read_text()) == exp, dev
+    # the created-prover API in this process: the variable is read at create
+    os.environ["ULTRAGROTH_DEVICES"] = devices
+    try:
+        with ug.Groth16Prover(zkey) as p:
+            for _ in range(2):
+                ug.set_test_blinding(r + s)
+                try:
+                    assert p.prove(wtns) == exp
+                finally:
+                    ug.set_test_blinding(b"")
+            with pytest.raises(ug.ProverError) as err:
+                p.prove(wtns[:-32])
+            assert "Invalid" in err.value.message or "section" in err.value.message.lower()
+            ug.set_test_blinding(r + s)
+            try:
+                assert p.prove(wtns) == exp
+            finally:
+                ug.set_test_blinding(b"")
+        os.environ["ULTRAGROTH_DEVICES"] = "0,x"
+        with pytest.raises(ug.ProverError, match="ULTRAGROTH_DEVICES"):
+            ug.Groth16Prover(zkey)
+    finally:
+        del os.environ["ULTRAGROTH_DEVICES"]
 
 
 @pytest.mark.parametrize("log_domain,n_public", [(2, 1), (3, 0), (5, 3), (7, 1), (10, 0)])

@@ -86,6 +86,24 @@ def test_field_against_python_and_reference(which, mod, name):
             assert O.ref_op(name, "to_mont", a) == O.f_op("to_mont", which, a)
 
 
+@pytest.mark.parametrize("which,mod", [(O.FR, O.R_MOD), (O.FQ, O.Q_MOD)])
+def test_field_product_asm_form_equals_portable_form(which, mod):
+    """field.h holds the Montgomery product twice: the portable CIOS restatement (fe_mul_c) and, on x86_64 with BMI2 + ADX, the
+    mulx / adcx / adox form the CPU baseline runs on; same bits on random, edge and unreduced operands"""
+    import ctypes as C
+    rng = random.Random(17 + which)
+    edge = [0, 1, mod - 1, mod, mod + 1, (1 << 256) - 1, (1 << 255), (1 << 64) - 1, 1 << 64, (1 << 192) - 1]
+    vals = edge + [rng.randrange(1 << 256) for _ in range(300)] + [rng.randrange(mod) for _ in range(300)]
+    for i, a in enumerate(vals):
+        b = vals[(11 * i + 5) % len(vals)] % mod          # (second operand reduced, as every call site has it)
+        x, y = C.create_string_buffer(O.to_le(a), 32), C.create_string_buffer(O.to_le(b), 32)
+        r1, r2 = C.create_string_buffer(32), C.create_string_buffer(32)
+        O.lib.ugo_f_mul(which, r1, x, y)
+        O.lib.ugo_f_mul_portable(which, r2, x, y)
+        assert r1.raw == r2.raw, (hex(a), hex(b))
+        assert O.from_le(r1.raw) == a * b * pow(1 << 256, -1, mod) % mod
+
+
 def test_pippenger_against_double_and_add(zkey):
     rng = random.Random(3)
     for n in (0, 1, 2, 33, 300):

@@ -153,6 +153,33 @@ class _ProverBase:
             raise ProverError(rc, err.value.decode(errors="replace"))
         return proof.raw.split(b"\0", 1)[0].decode(), pub.raw.split(b"\0", 1)[0].decode()
 
+    # the phases of a proof on a witness that stays resident in HBM (include/prover.h: ug_groth16_prover_load_witness / _run /
+    # _finish; bench.py times run + finish): available on every prover object
+    def load_witness(self, wtns):
+        err = C.create_string_buffer(1024)
+        rc = load().ug_groth16_prover_load_witness(self._h, wtns, len(wtns), err, len(err) - 1)
+        if rc != PROVER_OK:
+            raise ProverError(rc, err.value.decode(errors="replace"))
+
+    def run(self):
+        out = C.create_string_buffer(GROTH16_PARTIALS_SIZE)
+        err = C.create_string_buffer(1024)
+        rc = load().ug_groth16_prover_run(self._h, out, err, len(err) - 1)
+        if rc != PROVER_OK:
+            raise ProverError(rc, err.value.decode(errors="replace"))
+        return out.raw
+
+    def finish(self, partials_sum):
+        psz = C.c_ulonglong(self._proof_size())
+        qsz = C.c_ulonglong(self._public_size)
+        proof = C.create_string_buffer(psz.value)
+        pub = C.create_string_buffer(max(qsz.value, 1))
+        err = C.create_string_buffer(1024)
+        rc = load().ug_groth16_prover_finish(self._h, bytes(partials_sum), proof, C.byref(psz), pub, C.byref(qsz), err, len(err) - 1)
+        if rc != PROVER_OK:
+            raise ProverError(rc, err.value.decode(errors="replace"))
+        return proof.raw.split(b"\0", 1)[0].decode(), pub.raw.split(b"\0", 1)[0].decode()
+
     def last_timings(self):
         """(msm_ms, fft_ms, total_ms) of the last prove: device time of the MSM and H-polynomial parts, host wall time."""
         a, b, c = C.c_double(), C.c_double(), C.c_double()

@@ -170,7 +170,26 @@ bool setRandomOverride(const void* bytes, size_t n) {
     g_override_pos = 0;
     return true;
 }
+// For the CLIs, which have no call to make: under ULTRAGROTH_TEST_HOOKS=1 the environment variable ULTRAGROTH_TEST_BLINDING
+// (hex) sets the override once, before the first draw (tests compare the files `prover` writes byte for byte).
+static void overrideFromEnvOnce() {
+    static const bool done = [] {
+        const char* hex = testHooksEnabled() ? getenv("ULTRAGROTH_TEST_BLINDING") : nullptr;
+        if (!hex) return true;
+        std::vector<uint8_t> bytes;
+        auto nib = [](char ch) { return ch >= '0' && ch <= '9' ? ch - '0' : ch >= 'a' && ch <= 'f' ? ch - 'a' + 10 : ch >= 'A' && ch <= 'F' ? ch - 'A' + 10 : -1; };
+        for (size_t i = 0; hex[i] && hex[i + 1]; i += 2) {
+            const int hi = nib(hex[i]), lo = nib(hex[i + 1]);
+            if (hi < 0 || lo < 0) break;
+            bytes.push_back((uint8_t)(hi * 16 + lo));
+        }
+        if (!bytes.empty()) setRandomOverride(bytes.data(), bytes.size());
+        return true;
+    }();
+    (void)done;
+}
 void randomBytes(void* buf, size_t n) {
+    overrideFromEnvOnce();
     {
         std::lock_guard<std::mutex> lock(g_rand_mutex);
         if (!g_override.empty()) {

@@ -10,6 +10,7 @@
 //                                                 src/prover.cpp:89-117
 //   extern "C" entry points and error mapping     src/prover.cpp:311-891
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -961,6 +962,7 @@ public:
         if (total) *total = totalMs_;
     }
     ug_ctx* ctx() override { return d_.ctx; }
+    ug_ctx* ctx2() { return d_.ctx2; }              // the H branch's context (its stream orders hpolyChain / hpolyCombine / runHMsm)
 
 private:
     static constexpr uint64_t MAX_RANGE = (uint64_t)1 << 26;       // 2^26 scalars * <= 16 windows < 2^31 entries
@@ -1341,6 +1343,186 @@ private:
     double msmMs_ = 0, fftMs_ = 0, totalMs_ = 0;
 };
 
+
+// =================================================================================================================
+// One proof on SEVERAL devices of the node behind the reference's own API (ULTRAGROTH_DEVICES=0,1,2,...): the prover the
+// extern "C" create calls return then holds one sharded Groth16Prover per listed device -- rank k owns the k-th contiguous
+// range of every base-point section (what BASELINE.json's north_star asks: "shard by base-point range across the GPUs of one
+// node") -- and groth16_prover_prove drives them from one host thread per device:
+//   part 0 of the witness (the rank's scalars) -> its A | B1 | B2 | C partial sums          src/groth16.cpp:55-64
+//   ranks 0..2 (k mod R) also upload the rest of the witness and run one iFFT / twist / FFT chain each      :66-140
+//   every rank copies its slice of the three evaluation vectors from the chain ranks' devices (peer copies over xGMI,
+//   ug_dvec_copy), forms its slice of h and its H partial sum                                               :142-154
+//   the 384-byte partial blocks are added on the host (an EC addition, not an RCCL reduction: the data is five points per
+//   rank) and rank 0 blinds and serialises                                                                  :158-250
+// No Python, no torch, no launcher: `prover <zkey> <wtns> <proof.json> <public.json>` uses the node as it is. (bench.py's
+// one-process-per-GPU torchrun path stays the one the driver measures; both call the same phase functions.)
+// A device may be listed more than once: "0,0,0,0" rehearses four ranks on one GPU (tests).
+std::vector<int> devicesFromEnv() {
+    std::vector<int> out;
+    const char* e = getenv("ULTRAGROTH_DEVICES");
+    if (!e || !*e) return out;
+    const char* p = e;
+    while (*p) {
+        char* end = nullptr;
+        long v = strtol(p, &end, 10);
+        if (end == p || v < 0) throw std::invalid_argument(std::string("ULTRAGROTH_DEVICES: not a list of device numbers: ") + e);
+        out.push_back((int)v);
+        p = end;
+        if (*p == ',') p++;
+        else if (*p) throw std::invalid_argument(std::string("ULTRAGROTH_DEVICES: not a list of device numbers: ") + e);
+    }
+    if (out.size() > 64) throw std::invalid_argument("ULTRAGROTH_DEVICES: more than 64 ranks");
+    return out;
+}
+
+// One iFFT/twist/FFT chain costs about this fraction of ALL the witness MSMs of a proof (2^24, tools/phase_times.py), so a
+// rank that also runs chains gets fewer points (the same split bench.py makes for its ranks)
+std::vector<Range> balancedWitnessRanges(uint64_t nVars, int count) {
+    static const double CHAIN_SHARE[3] = {0.063, 0.063, 0.080};
+    std::vector<double> extra(count, 0.0), share(count);
+    for (int c = 0; c < 3; c++) extra[c % count] += CHAIN_SHARE[c];
+    double base = 1.0, tot = 0;
+    for (double x : extra) base += x;
+    base /= count;
+    for (int k = 0; k < count; k++) { share[k] = std::max(base - extra[k], 0.0); tot += share[k]; }
+    std::vector<Range> out(count);
+    double run = 0;
+    uint64_t lo = 0;
+    for (int k = 0; k < count; k++) {
+        run += share[k];
+        uint64_t hi = k == count - 1 ? nVars : std::min<uint64_t>(nVars, (uint64_t)((double)nVars * run / tot + 0.5));
+        if (hi < lo) hi = lo;
+        out[k] = Range{lo, hi};
+        lo = hi;
+    }
+    return out;
+}
+
+class MultiGroth16Prover : public ProverBase {
+public:
+    MultiGroth16Prover(const void* zkey, unsigned long long zkeySize, const std::vector<int>& devices) {
+        const int R = (int)devices.size();
+        BinFile f(zkey, zkeySize, "zkey", 1);
+        ZkeyHeader h = loadZkeyHeader(f, false);
+        if (!h.rIsBn254) throw std::invalid_argument("zkey curve not supported");
+        nPublic_ = h.nPublic; domain_ = h.domainSize;
+        const std::vector<Range> wr = balancedWitnessRanges(h.nVars, R);
+        ranks_.resize(R);
+        // every rank uploads and converts its slices on its own device, all at once
+        const bool oneShot = g_oneShotProver;          // (thread-local: handed to the creating threads by value)
+        std::vector<std::future<void>> jobs;
+        for (int k = 0; k < R; k++)
+            jobs.push_back(std::async(std::launch::async, [&, k, oneShot] {
+                g_oneShotProver = oneShot;
+                ranks_[k].reset(new Groth16Prover(zkey, zkeySize, devices[k], k, R, &wr[k]));
+            }));
+        std::exception_ptr failure;
+        for (auto& j : jobs) { try { j.get(); } catch (...) { if (!failure) failure = std::current_exception(); } }
+        if (failure) { ranks_.clear(); std::rethrow_exception(failure); }
+        // the evaluation vectors of the three chains (on the devices of ranks k mod R) and every rank's slices of them
+        for (int c = 0; c < 3; c++) {
+            ugCheck(ug_dvec_create(ranks_[c % R]->ctx2(), domain_, &full_[c]));
+        }
+        slices_.resize(R);
+        for (int k = 0; k < R; k++) {
+            unsigned long long first = 0, cnt = 0;
+            ranks_[k]->hRange(&first, &cnt, nullptr);
+            for (int c = 0; c < 3; c++) ugCheck(ug_dvec_create(ranks_[k]->ctx2(), cnt ? cnt : 1, &slices_[k].v[c]));
+        }
+    }
+    ~MultiGroth16Prover() override {
+        for (auto& s : slices_) for (ug_dvec* v : s.v) ug_dvec_destroy(v);
+        for (ug_dvec* v : full_) ug_dvec_destroy(v);
+    }
+    void prove(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub) override {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int R = (int)ranks_.size();
+        // checked once here (every rank checks again): the reference's error for a wrong witness comes before any device work
+        { BinFile f(wtns, wtnsSize, "wtns", 2); (void)ranks_[0]->witnessData(f); }
+        std::vector<std::array<uint8_t, UG_GROTH16_PARTIALS_SIZE>> parts(R);
+        std::vector<std::exception_ptr> errs(R);
+        // phase 1: witness products everywhere, the chains beside them on their ranks
+        {
+            std::vector<std::thread> th;
+            for (int k = 0; k < R; k++)
+                th.emplace_back([&, k] {
+                    try {
+                        Groth16Prover& p = *ranks_[k];
+                        p.loadWitnessPart(wtns, wtnsSize, 0);
+                        std::exception_ptr chainErr;
+                        std::thread chains;
+                        const bool mine = k < 3;                        // chains k, k + R, ... of the three
+                        if (mine) chains = std::thread([&] {
+                            try {
+                                p.loadWitnessPart(wtns, wtnsSize, 1);
+                                for (int c = k; c < 3; c += R) p.hpolyChain(c, ug_dvec_device_ptr(full_[c]));
+                            } catch (...) { chainErr = std::current_exception(); }
+                        });
+                        try { p.runWitnessMsm(parts[k].data()); } catch (...) { errs[k] = std::current_exception(); }
+                        if (mine) chains.join();
+                        if (!errs[k] && chainErr) errs[k] = chainErr;
+                    } catch (...) { errs[k] = std::current_exception(); }
+                });
+            for (auto& t : th) t.join();
+        }
+        for (auto& e : errs) if (e) std::rethrow_exception(e);
+        // phase 2: every rank fetches its slices, forms its h slice and multiplies it
+        {
+            std::vector<std::thread> th;
+            for (int k = 0; k < R; k++)
+                th.emplace_back([&, k] {
+                    try {
+                        Groth16Prover& p = *ranks_[k];
+                        unsigned long long first = 0, cnt = 0;
+                        p.hRange(&first, &cnt, nullptr);
+                        for (int c = 0; c < 3; c++) ugCheck(ug_dvec_copy(slices_[k].v[c], 0, full_[c], first, cnt));
+                        p.hpolyCombine(ug_dvec_device_ptr(slices_[k].v[0]), ug_dvec_device_ptr(slices_[k].v[1]), ug_dvec_device_ptr(slices_[k].v[2]));
+                        uint8_t hpart[UG_GROTH16_PARTIALS_SIZE];
+                        p.runHMsm(hpart);
+                        memcpy(parts[k].data() + 320, hpart + 320, 64);
+                    } catch (...) { errs[k] = std::current_exception(); }
+                });
+            for (auto& t : th) t.join();
+        }
+        for (auto& e : errs) if (e) std::rethrow_exception(e);
+        for (int k = 1; k < R; k++)
+            if (ug_groth16_partials_add(parts[0].data(), parts[k].data()) != PROVER_OK) throw std::runtime_error("partial sum failed");
+        ranks_[0]->finish(parts[0].data(), proof, pub);
+        msm_ = fft_ = 0;
+        for (auto& r : ranks_) { double m = 0, f = 0; r->timings(&m, &f, nullptr); msm_ = std::max(msm_, m); fft_ = std::max(fft_, f); }
+        total_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    unsigned long long proofBufferMinSize() const override { return PROOF_MIN_GROTH16; }
+    unsigned long long publicBufferMinSize() const override { return publicMin(nPublic_); }
+    void timings(double* msm, double* fft, double* total) const override {      // the slowest rank's device time per part
+        if (msm) *msm = msm_;
+        if (fft) *fft = fft_;
+        if (total) *total = total_;
+    }
+    ug_ctx* ctx() override { return ranks_[0]->ctx(); }
+    std::vector<TableGroup> tableGroups() override { return {}; }
+    void trimWorkspaces() override { for (auto& r : ranks_) r->trimWorkspaces(); }
+    int kernelStats(int which, double* avgMs, unsigned long long* launches, unsigned long long* entries, int reset) override {
+        return ranks_[0]->kernelStats(which, avgMs, launches, entries, reset);
+    }
+    int rankCount() const { return (int)ranks_.size(); }
+
+private:
+    struct Slices { ug_dvec* v[3] = {nullptr, nullptr, nullptr}; };
+    std::vector<std::unique_ptr<Groth16Prover>> ranks_;
+    ug_dvec* full_[3] = {nullptr, nullptr, nullptr};
+    std::vector<Slices> slices_;
+    uint32_t nPublic_ = 0, domain_ = 0;
+    double msm_ = 0, fft_ = 0, total_ = 0;
+};
+
+ProverBase* newGroth16Prover(const void* zkey, unsigned long long size) {
+    const std::vector<int> devices = devicesFromEnv();
+    if (devices.size() > 1) return new MultiGroth16Prover(zkey, size, devices);
+    return new Groth16Prover(zkey, size, devices.size() == 1 ? devices[0] : deviceFromEnv(), 0, 1);
+}
+
 // =================================================================================================================
 // Resident multi-circuit prover: the GPU form of FullProver's map<circuit, Prover> (src/fullprover.cpp:21-63), without
 // its HTTP shell and witness calculator. Several created provers share one device under an HBM budget. What is given
@@ -1632,7 +1814,7 @@ int groth16_prover_create(void** prover_object, const void* zkey_buffer, unsigne
     API_TRY
     if (prover_object == NULL) throw std::invalid_argument("Null prover object");
     if (zkey_buffer == NULL) throw std::invalid_argument("Null zkey buffer");
-    *prover_object = static_cast<ProverBase*>(new Groth16Prover(zkey_buffer, zkey_size, deviceFromEnv(), 0, 1));
+    *prover_object = newGroth16Prover(zkey_buffer, zkey_size);
     API_CATCH
 }
 int ultra_groth_prover_create(void** prover_object, const void* zkey_buffer, unsigned long long zkey_size, char* error_msg,
@@ -1648,7 +1830,7 @@ int groth16_prover_create_zkey_file(void** prover_object, const char* zkey_file_
     API_TRY
     if (prover_object == NULL) throw std::invalid_argument("Null prover object");
     FileMap m(zkey_file_path);
-    *prover_object = static_cast<ProverBase*>(new Groth16Prover(m.data(), m.size(), deviceFromEnv(), 0, 1));
+    *prover_object = newGroth16Prover(m.data(), m.size());
     API_CATCH
 }
 int ultra_groth_prover_create_zkey_file(void** prover_object, const char* zkey_file_path, char* error_msg,

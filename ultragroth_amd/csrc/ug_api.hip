@@ -628,6 +628,25 @@ int ug_fr_lookup_table(ug_ctx* c, const void* rand_plain, const uint32_t* freque
     UG_CATCH
 }
 uint64_t ug_dvec_size(const ug_dvec* v) { return v ? v->n : 0; }
+void* ug_dvec_device_ptr(const ug_dvec* v) { return v ? v->data : nullptr; }
+// dst[dst_first .. + count) = src[src_first .. + count); the vectors may live on different devices of the node (peer copy over
+// xGMI, or through the host when peer access is not there: hipMemcpyPeer decides). Blocking; both vectors' earlier work must be
+// complete (the phase calls that produce them are).
+int ug_dvec_copy(ug_dvec* dst, uint64_t dst_first, const ug_dvec* src, uint64_t src_first, uint64_t count) {
+    UG_TRY
+    if (!dst || !src) throw std::invalid_argument("null argument");
+    if (dst_first + count > dst->n || src_first + count > src->n) throw std::invalid_argument("copy outside the vectors");
+    if (!count) return UG_OK;
+    ug_ctx* c = dst->ctx;
+    c->use();
+    const size_t bytes = (size_t)count * 32;
+    if (src->ctx->device == c->device)
+        UG_HIP(hipMemcpyAsync(dst->data + dst_first * 8, src->data + src_first * 8, bytes, hipMemcpyDeviceToDevice, c->stream));
+    else
+        UG_HIP(hipMemcpyPeerAsync(dst->data + dst_first * 8, c->device, src->data + src_first * 8, src->ctx->device, bytes, c->stream));
+    UG_HIP(hipStreamSynchronize(c->stream));
+    UG_CATCH
+}
 int ug_dvec_wrap(ug_ctx* c, void* device_ptr, uint64_t n, ug_dvec** out) {
     UG_TRY
     if (!c || !out || (!device_ptr && n)) throw std::invalid_argument("null argument");
