@@ -496,16 +496,17 @@ def main():
     for which in range(4):
         prover.kernel_stats(which=which, reset=True)
     # ---- THE timed region: K proofs, one after the other, witness resident in HBM ----
-    msm_ms = fft_ms = 0.0
+    # (the library's device-time accumulators restart when a witness is loaded: with the witness resident they run on, so the
+    # K steps' share is the difference across the region)
+    m0, f0, _ = prover.last_timings()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-        m, f, _ = prover.last_timings()
-        msm_ms += m
-        fft_ms += f
     barrier()
     elapsed = time.perf_counter() - t0
+    m1, f1, _ = prover.last_timings()
+    msm_ms, fft_ms = m1 - m0, f1 - f0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -387,7 +387,7 @@ template <int K, bool ROTATE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void segment_accumulate_group_kernel(
         const u32* __restrict__ bases, u64 n_slots, int64_t delta, const u32* __restrict__ keys, const u32* __restrict__ tkeys,
         const u32* __restrict__ tvals, const u32* __restrict__ meta, int log_a, int log_b, u32* __restrict__ bucket_pts,
-        u32* __restrict__ slot_pts, size_t bucket_stride, size_t slot_stride) {
+        u32* __restrict__ slot_pts, size_t bucket_stride, size_t slot_stride, u32 fold_mask) {
     typedef G1Cfg Cfg;
     typedef Fq F;
     const u32 n_valid = meta[1];
@@ -405,7 +405,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     XYZZ<F> acc[K];
     StaticFor<0, K>::up([&](auto m) { acc[m] = xyzz_inf<F>(); });
     const u32 IDX_MASK = (1u << TABLE_INDEX_BITS) - 1;
+    // (fold_mask: measurement only -- UG_GROUP_FOLD_LOG folds every gather into the first 2^log records of table 0, i.e. into
+    // cache: what the launch would take without DRAM misses; sums are then wrong, ~0u leaves the addresses alone)
     auto record = [&](u32 val, int64_t idx, int m) -> const u32* {
+        if (fold_mask != ~0u) return bases + (((u64)idx & fold_mask) * K + (u64)m) * Cfg::AFF_WORDS;
         return bases + (((u64)((val >> TABLE_INDEX_BITS) & 15u) * n_slots + (u64)idx) * K + (u64)m) * Cfg::AFF_WORDS;
     };
     auto flush = [&](bool to_slot, size_t slot, u32 bucket) {
@@ -978,12 +981,14 @@ void msm_enqueue_multi(const MsmSchedule& s, MsmWorkspace& ws, int count, const 
         if (group) {                                 // (all K products are live, or none: they share the slot count)
             const char* rot = getenv("UG_GROUP_ROTATE");                      // tuning knob, read per launch (the tests take both shapes)
             const bool rotate = rot && atoi(rot) != 0;
+            const char* fold = getenv("UG_GROUP_FOLD_LOG");                   // measurement knob (wrong sums): see the kernel
+            const u32 fold_mask = fold ? ((1u << atoi(fold)) - 1) : ~0u;
             int slot = stats ? stats->begin(stream, g.n * g.windows * (u64)group) : -1;
             if (nseg) {
                 const dim3 grid((unsigned)((nseg + 255) / 256)), block(256);
 #define UG_GROUP_LAUNCH(K_, R_) hipLaunchKernelGGL((segment_accumulate_group_kernel<K_, R_>), grid, block, 0, stream, bases[0], n_bases[0], \
                                                    delta[0], s.keys, s.tkeys, s.tvals, s.meta, s.log_seg, s.log_seg_tail, ws.bucket_pts, ws.slot_pts,   \
-                                                   bucket_stride, slot_stride)
+                                                   bucket_stride, slot_stride, fold_mask)
                 if (group == 3) { if (rotate) UG_GROUP_LAUNCH(3, true); else UG_GROUP_LAUNCH(3, false); }
                 else if (group == 2) { if (rotate) UG_GROUP_LAUNCH(2, true); else UG_GROUP_LAUNCH(2, false); }
                 else throw std::logic_error("msm: group size");

@@ -1,0 +1,353 @@
+// sort.hip -- grouping of an MSM schedule's (bucket, entry) pairs by bucket: a hand-written LSD radix partition for gfx950.
+//
+// The reference's multiMulByScalarMSM (call sites src/groth16.cpp:55-64,154; the routine itself lives in the un-vendored
+// ffiasm submodule) walks its scalars window by window on the CPU and adds each base into a bucket array in cache. On the
+// GPU the same grouping is a sort: every (scalar, window) digit becomes a pair (bucket id, entry = index | table | sign), and
+// the accumulation kernel (msm.hip) wants the pairs of one bucket next to each other. Round 1 and 2 used the library sort
+// for it; this file replaces it on the per-proof path:
+//
+//   radix_hist_kernel     one read of the SCALARS (not of a materialised pair array): recodes them into signed window digits
+//                         and counts, for every pass of the sort, how many pairs fall into each digit bin
+//   radix_scan_kernel     exclusive scan of those counts: where each bin of each pass starts
+//   radix_pass_kernel     one pass = one stable partition by up to 8 key bits. A tile of 256 lanes x <= 16 pairs is ranked
+//                         inside the workgroup (wave-level match on the digit bits, per-wave counters in LDS), reordered
+//                         through LDS so that pairs of one bin leave in runs, and scattered; the offset of a tile within a
+//                         bin comes from a decoupled look-back over the tiles before it (one 32-bit status word per tile and
+//                         bin: 2 status bits + 30 count bits, so flag and value travel in ONE agent-scope atomic and need no
+//                         fence). The FIRST pass reads the scalars and makes its pairs on the fly -- the pair arrays are
+//                         never written in unsorted form (1.6 GB written and read again per 2^24-scalar schedule before).
+//
+// Keys are sorted on the low `bits` bits only (enough to tell the sentinel, = number of buckets, from every bucket id), in
+// ceil(bits / 8) passes of nearly equal width. Pairs that exist only to fill the last tile carry the key 0xffffffff: they sort
+// behind everything and land beyond the `total` positions any consumer reads.
+#include <cstdlib>
+#include "dev_common.hpp"
+#include "internal.hpp"
+
+namespace ug {
+
+namespace {
+
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_WAVES = SORT_THREADS / 64;
+constexpr int SORT_MAX_IPT = 16;              // pairs per lane and tile (the fused first pass takes one scalar per lane: windows <= 16)
+constexpr int SORT_MAX_BINS = 256;
+constexpr u32 LB_VALUE_MASK = (1u << 30) - 1, LB_AGGREGATE = 1u << 30, LB_PREFIX = 2u << 30;
+constexpr u32 SPIN_LIMIT = 1u << 26;          // a look-back that has not seen its predecessor by then gives up and flags the schedule
+
+struct SortPassArgs {
+    // source: either pair arrays ...
+    const u32* keys_in; const u32* vals_in;
+    // ... or the scalars themselves (first pass): n scalars of 32 bytes, recoded as msm_digits does
+    const u32* scalars; u64 n; int c, windows; u32 buckets, sentinel; int tables;
+    u32* keys_out; u32* vals_out;
+    u64 n_pairs;                      // pairs that exist (the rest of the last tile is padding)
+    int ipt;                          // pairs per lane
+    int shift, bins_log;              // this pass sorts on (key >> shift) & (2^bins_log - 1)
+    const u32* bin_base;              // 2^bins_log exclusive bin starts of this pass
+    u32* lookback;                    // tiles x 2^bins_log status words, zeroed
+    u32* tile_counter;                // zeroed: hands out tile numbers in start order
+    u32* error_flag;
+};
+
+__device__ __forceinline__ bool scalar_geq_r(const u32* s) {
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+        if (s[i] > FrParams::q32[i]) return true;
+        if (s[i] < FrParams::q32[i]) return false;
+    }
+    return true;
+}
+// the signed-digit recoding of one scalar (same rule as the pair form it replaces: digit in (-2^(c-1), 2^(c-1)], a carry into the
+// next window; a zero digit gets the sentinel key); f(window, key, val) is called for every window in order
+template <class Fn>
+__device__ __forceinline__ void recode_scalar(const u32* scalars, u64 i, u64 n, int c, int windows, u32 buckets, u32 sentinel, int tables, Fn&& f) {
+    if (i >= n) {                                     // padding of the last tile
+        for (int w = 0; w < windows; w++) f(w, 0xffffffffu, 0u);
+        return;
+    }
+    u32 s[10];
+    load8(s, scalars + i * 8);
+    s[8] = 0; s[9] = 0;
+    // the group has order r: scalars >= r (never produced by a well-formed witness) are reduced
+    for (int it = 0; it < 6 && scalar_geq_r(s); it++) {
+        u64 borrow = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            u64 d = (u64)s[k] - FrParams::q32[k] - borrow;
+            s[k] = (u32)d; borrow = (d >> 32) & 1;
+        }
+    }
+    u32 carry = 0;
+    const u32 half = 1u << (c - 1), full = 1u << c, mask = full - 1;
+    for (int w = 0; w < windows; w++) {
+        const int bit = w * c, word = bit >> 5, sh = bit & 31;
+        const u64 two = (u64)s[word] | ((u64)s[word + 1] << 32);
+        const u32 raw = ((u32)(two >> sh) & mask) + carry;
+        const u32 set0 = tables ? 0u : (u32)w * buckets;
+        const u32 tag = tables ? (u32)w << TABLE_INDEX_BITS : 0u;
+        u32 key, val;
+        if (raw > half) {
+            const u32 mag = full - raw;
+            carry = 1;
+            key = mag ? set0 + mag - 1 : sentinel;
+            val = (u32)i | tag | 0x80000000u;
+        } else { carry = 0; key = raw ? set0 + raw - 1 : sentinel; val = (u32)i | tag; }
+        f(w, key, val);
+    }
+}
+
+struct SortHistArgs {
+    const u32* keys_in;                // pair form (scalars == nullptr) ...
+    const u32* scalars; u64 n; int c, windows; u32 buckets, sentinel; int tables;       // ... or scalar form
+    u64 n_pairs, n_padded;             // padded: whole tiles (the padding pairs are counted: they take part in every pass)
+    int passes; int shift[4]; int bins_log[4];
+    u32* hist;                         // passes x 256 counters, zeroed
+};
+
+// counts per pass and bin; a grid-stride loop, counters in LDS, one global atomic per (workgroup, pass, bin)
+__global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(SortHistArgs a) {
+    __shared__ u32 h[4 * SORT_MAX_BINS];
+    for (int i = threadIdx.x; i < 4 * SORT_MAX_BINS; i += SORT_THREADS) h[i] = 0;
+    __syncthreads();
+    auto count = [&](u32 key) {
+        for (int p = 0; p < a.passes; p++) atomicAdd(&h[p * SORT_MAX_BINS + ((key >> a.shift[p]) & ((1u << a.bins_log[p]) - 1))], 1u);
+    };
+    const u64 stride = (u64)gridDim.x * SORT_THREADS;
+    if (a.scalars) {
+        const u64 lanes = a.n_padded / (u64)a.windows;            // one scalar (all its windows) per lane turn
+        for (u64 i = (u64)blockIdx.x * SORT_THREADS + threadIdx.x; i < lanes; i += stride)
+            recode_scalar(a.scalars, i, a.n, a.c, a.windows, a.buckets, a.sentinel, a.tables, [&](int, u32 key, u32) { count(key); });
+    } else {
+        for (u64 i = (u64)blockIdx.x * SORT_THREADS + threadIdx.x; i < a.n_padded; i += stride) count(i < a.n_pairs ? a.keys_in[i] : 0xffffffffu);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.passes * SORT_MAX_BINS; i += SORT_THREADS)
+        if (h[i]) atomicAdd(&a.hist[i], h[i]);
+}
+// hist[p][*] -> exclusive starts, in place (one workgroup, one wave per pass would do: a serial loop over 256 bins is nothing)
+__global__ void radix_scan_kernel(u32* hist, int passes) {
+    const int p = threadIdx.x;
+    if (p >= passes) return;
+    u32 run = 0;
+    for (int b = 0; b < SORT_MAX_BINS; b++) { const u32 v = hist[p * SORT_MAX_BINS + b]; hist[p * SORT_MAX_BINS + b] = run; run += v; }
+}
+
+template <bool FROM_SCALARS>
+__global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a) {
+    extern __shared__ u32 lds[];
+    const int ipt = a.ipt;
+    const u32 T = (u32)SORT_THREADS * (u32)ipt;
+    u32* stage_k = lds;                                   // T keys
+    u32* stage_v = lds + T;                               // T values
+    u32* wcnt = lds + 2 * T;                              // SORT_WAVES x 256 per-wave counters, later per-wave starts
+    u32* texcl = wcnt + SORT_WAVES * SORT_MAX_BINS;       // 256: start of each bin inside the tile
+    u32* gbase = texcl + SORT_MAX_BINS;                   // 256: global position of the tile's first pair of a bin, minus its tile position
+    u32* misc = gbase + SORT_MAX_BINS;                    // [0] tile number, [1..4] wave totals of the scan
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const u32 bins = 1u << a.bins_log, dmask = bins - 1;
+
+    if (tid == 0) misc[0] = atomicAdd(a.tile_counter, 1u);           // tiles are numbered in the order they start
+    for (int i = tid; i < SORT_WAVES * SORT_MAX_BINS; i += SORT_THREADS) wcnt[i] = 0;
+    __syncthreads();
+    const u32 tile = misc[0];
+    const u64 e0 = (u64)tile * T;
+
+    // ---- load (or make) the tile's pairs: lane holds pairs j = 0 .. ipt-1; wave-striped, so that (wave, j, lane) is memory order
+    u32 key[SORT_MAX_IPT], val[SORT_MAX_IPT];
+    if constexpr (FROM_SCALARS) {
+        // one scalar per lane, pair j = its window j (any order will do for a first pass)
+        const u64 i = (u64)tile * SORT_THREADS + tid;
+#pragma unroll
+        for (int j = 0; j < SORT_MAX_IPT; j++) { key[j] = 0xffffffffu; val[j] = 0; }
+        recode_scalar(a.scalars, i, a.n, a.c, a.windows, a.buckets, a.sentinel, a.tables, [&](int w, u32 k, u32 v) {
+#pragma unroll
+            for (int j = 0; j < SORT_MAX_IPT; j++) if (j == w) { key[j] = k; val[j] = v; }
+        });
+    } else {
+#pragma unroll
+        for (int j = 0; j < SORT_MAX_IPT; j++) {
+            const u64 idx = e0 + (u64)wave * (64u * (u32)ipt) + (u64)j * 64u + (u64)lane;
+            const bool in = j < ipt && idx < a.n_pairs;
+            key[j] = in ? a.keys_in[idx] : 0xffffffffu;
+            val[j] = in ? a.vals_in[idx] : 0u;
+        }
+    }
+
+    // ---- rank inside the wave, pair slot by pair slot: lanes with the same digit find each other by ballots over the digit bits
+    u32 rank[SORT_MAX_IPT];                                // position of the pair among the wave's pairs of its bin
+    u32* mycnt = wcnt + wave * SORT_MAX_BINS;
+    const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+    for (int j = 0; j < SORT_MAX_IPT; j++) {
+        if (j < ipt) {
+            const u32 d = (key[j] >> a.shift) & dmask;
+            u64 peers = ~0ull;
+            for (int b = 0; b < a.bins_log; b++) {
+                const u64 vote = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? vote : ~vote;
+            }
+            const u32 before = (u32)__popcll(peers & lt_mask), same = (u32)__popcll(peers);
+            const u32 old = mycnt[d];                      // every peer reads the counter ...
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (before == 0) mycnt[d] = old + same;        // ... before its first lane moves it on (one wave: in order)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            rank[j] = old + before;
+        }
+    }
+    __syncthreads();
+
+    // ---- per bin: the waves' starts inside the bin, the tile's total, and the scan of the totals over the bins
+    u32 total = 0;
+    if ((u32)tid < bins) {
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; w++) { const u32 cw = wcnt[w * SORT_MAX_BINS + tid]; wcnt[w * SORT_MAX_BINS + tid] = total; total += cw; }
+    }
+    // exclusive scan of `total` over tid (256 lanes): wave scan by shuffles, wave totals through LDS
+    u32 incl = total;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const u32 up = __shfl_up(incl, off, 64); if (lane >= off) incl += up; }
+    if (lane == 63) misc[1 + wave] = incl;
+    __syncthreads();
+    u32 wave_off = 0;
+    for (int w = 0; w < wave; w++) wave_off += misc[1 + w];
+    const u32 my_excl = wave_off + incl - total;
+    if ((u32)tid < bins) texcl[tid] = my_excl;
+
+    // ---- decoupled look-back, one lane per bin: pairs of this bin in all the tiles before this one
+    if ((u32)tid < bins) {
+        u32* mine = a.lookback + (size_t)tile * bins + tid;
+        u32 prev = 0;
+        if (tile) {
+            __hip_atomic_store(mine, LB_AGGREGATE | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (u32 t = tile; t-- > 0;) {
+                const u32* theirs = a.lookback + (size_t)t * bins + tid;
+                u32 v = 0, spins = 0;
+                do {
+                    v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v >> 30) break;
+                    __builtin_amdgcn_s_sleep(1);
+                } while (++spins < SPIN_LIMIT);
+                if (!(v >> 30)) { atomicOr(a.error_flag, 1u); break; }      // never seen: give up (the schedule is flagged), do not hang
+                prev += v & LB_VALUE_MASK;
+                if ((v >> 30) == 2) break;
+            }
+        }
+        __hip_atomic_store(mine, LB_PREFIX | (prev + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gbase[tid] = a.bin_base[tid] + prev - my_excl;
+    }
+    __syncthreads();
+
+    // ---- reorder through LDS: the tile's pairs in bin order ...
+#pragma unroll
+    for (int j = 0; j < SORT_MAX_IPT; j++) {
+        if (j < ipt) {
+            const u32 d = (key[j] >> a.shift) & dmask;
+            const u32 lp = texcl[d] + wcnt[wave * SORT_MAX_BINS + d] + rank[j];
+            stage_k[lp] = key[j]; stage_v[lp] = val[j];
+        }
+    }
+    __syncthreads();
+    // ... and out: neighbouring lanes hold neighbouring pairs of a bin, i.e. neighbouring addresses
+    for (u32 lp = tid; lp < T; lp += SORT_THREADS) {
+        const u32 k = stage_k[lp];
+        const u32 d = (k >> a.shift) & dmask;
+        const u64 pos = (u64)gbase[d] + lp;
+        a.keys_out[pos] = k;
+        a.vals_out[pos] = stage_v[lp];
+    }
+}
+
+template <class T> void sort_alloc(T*& p, size_t bytes) { if (p) hipFree(p); p = nullptr; UG_HIP(hipMalloc(&p, bytes ? bytes : 4)); }
+
+}  // namespace
+
+// pass plan for keys below 2^bits: ceil(bits / 8) passes of nearly equal width, low bits first
+int radix_plan(int bits, int* shift, int* bins_log) {
+    if (bits < 1) bits = 1;
+    const int passes = (bits + 7) / 8;
+    int at = 0;
+    for (int p = 0; p < passes; p++) {
+        const int w = (bits - at + (passes - p) - 1) / (passes - p);
+        shift[p] = at; bins_log[p] = w; at += w;
+    }
+    return passes;
+}
+
+void RadixSorter::reserve(u64 n_pairs, int ipt_min) {
+    const u64 tiles = n_pairs / ((u64)SORT_THREADS * (u64)(ipt_min < 1 ? 1 : ipt_min)) + 2;
+    if (tiles > tiles_cap) {
+        sort_alloc(lookback, (size_t)tiles * SORT_MAX_BINS * 4);
+        tiles_cap = tiles;
+    }
+    if (!small) sort_alloc(small, (4 * SORT_MAX_BINS + 16) * 4);
+}
+void RadixSorter::release() {
+    if (lookback) hipFree(lookback);
+    if (small) hipFree(small);
+    lookback = small = nullptr; tiles_cap = 0;
+}
+
+// Sorts the schedule's pairs by key. scalars != nullptr and windows <= 16: the pairs are made from the scalars inside the
+// first pass; otherwise they are read from (buf_keys[0], buf_vals[0]). The passes ping-pong between the two buffer pairs
+// (each with room for whole tiles: n_pairs + 8192 entries); returns the index of the pair that holds the result.
+int RadixSorter::sort(const u32* scalars, u64 n, int c, int windows, u32 buckets, u32 sentinel, bool tables, u64 n_pairs, int bits,
+                      u32* const buf_keys[2], u32* const buf_vals[2], u32* error_flag, hipStream_t stream) {
+    int shift[4], bins_log[4];
+    const int passes = radix_plan(bits, shift, bins_log);
+    if (passes > 4) throw std::logic_error("radix sort: key too wide");
+    const bool fused = scalars != nullptr && windows <= SORT_MAX_IPT;
+    const int ipt_first = fused ? windows : SORT_MAX_IPT;
+    reserve(n_pairs, fused ? windows : SORT_MAX_IPT);
+    u32* hist = small;                         // passes x 256
+    u32* counters = small + 4 * SORT_MAX_BINS; // one tile counter per pass
+    UG_HIP(hipMemsetAsync(small, 0, (4 * SORT_MAX_BINS + 16) * 4, stream));
+    // padded pair count: whole tiles of the FIRST pass (later passes see the same pairs: their last tile is padded on the fly)
+    const u64 T0 = (u64)SORT_THREADS * (u64)ipt_first;
+    const u64 tiles0 = (n_pairs + T0 - 1) / T0;
+    const u64 n_padded = fused ? tiles0 * T0 : n_pairs;      // (the pair form pads inside the kernel and does not count the padding ...)
+    {
+        SortHistArgs h;
+        h.keys_in = fused ? nullptr : buf_keys[0];
+        h.scalars = fused ? scalars : nullptr; h.n = n; h.c = c; h.windows = windows; h.buckets = buckets; h.sentinel = sentinel; h.tables = tables ? 1 : 0;
+        h.n_pairs = n_pairs; h.n_padded = fused ? n_padded : ((n_pairs + (u64)SORT_THREADS * SORT_MAX_IPT - 1) / ((u64)SORT_THREADS * SORT_MAX_IPT)) * ((u64)SORT_THREADS * SORT_MAX_IPT);
+        h.passes = passes;
+        for (int p = 0; p < 4; p++) { h.shift[p] = p < passes ? shift[p] : 0; h.bins_log[p] = p < passes ? bins_log[p] : 1; }
+        h.hist = hist;
+        const u64 lanes = fused ? h.n_padded / (u64)windows : h.n_padded;
+        unsigned blocks = (unsigned)std::min<u64>((lanes + SORT_THREADS - 1) / SORT_THREADS, 2048);
+        if (!blocks) blocks = 1;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(blocks), dim3(SORT_THREADS), 0, stream, h);
+        UG_KERNEL_CHECK();
+        hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(64), 0, stream, hist, passes);
+        UG_KERNEL_CHECK();
+    }
+    // every pass moves the same multiset of pairs: the real ones plus the padding of the first pass's last tile
+    const u64 moved = fused ? n_padded : (n_pairs + (u64)SORT_THREADS * SORT_MAX_IPT - 1) / ((u64)SORT_THREADS * SORT_MAX_IPT) * ((u64)SORT_THREADS * SORT_MAX_IPT);
+    int cur = 0;                               // buffer pair that holds the current order (pair form: the input)
+    for (int p = 0; p < passes; p++) {
+        const bool first_fused = fused && p == 0;
+        SortPassArgs a;
+        a.keys_in = buf_keys[cur]; a.vals_in = buf_vals[cur];
+        a.scalars = first_fused ? scalars : nullptr; a.n = n; a.c = c; a.windows = windows; a.buckets = buckets; a.sentinel = sentinel; a.tables = tables ? 1 : 0;
+        const int dst = first_fused ? 0 : 1 - cur;
+        a.keys_out = buf_keys[dst]; a.vals_out = buf_vals[dst];
+        a.n_pairs = first_fused ? n_pairs : moved;           // later passes read the padding of the first one as pairs
+        a.ipt = first_fused ? windows : SORT_MAX_IPT;
+        a.shift = shift[p]; a.bins_log = bins_log[p];
+        a.bin_base = hist + p * SORT_MAX_BINS;
+        a.lookback = lookback; a.tile_counter = counters + p; a.error_flag = error_flag;
+        const u64 T = (u64)SORT_THREADS * (u64)a.ipt;
+        const u64 tiles = (moved + T - 1) / T;
+        if (tiles > tiles_cap) throw std::logic_error("radix sort: look-back table too small");
+        UG_HIP(hipMemsetAsync(lookback, 0, (size_t)tiles * ((size_t)1 << bins_log[p]) * 4, stream));
+        const size_t lds = (2 * T + SORT_WAVES * SORT_MAX_BINS + 2 * SORT_MAX_BINS + 8) * 4;
+        if (first_fused) hipLaunchKernelGGL(radix_pass_kernel<true>, dim3((unsigned)tiles), dim3(SORT_THREADS), lds, stream, a);
+        else hipLaunchKernelGGL(radix_pass_kernel<false>, dim3((unsigned)tiles), dim3(SORT_THREADS), lds, stream, a);
+        UG_KERNEL_CHECK();
+        cur = dst;
+    }
+    return cur;
+}
+
+}  // namespace ug
