@@ -133,8 +133,11 @@ static inline void fe_mul_c(fe *r, const fe *a, const fe *b, const fctx *f) {
  * multiply-accumulate m * q, drop the low word. q < 2^254, so the running top word cannot overflow. The CPU baseline of
  * bench.py runs on this form, so that "port" is not softer than the assembly it stands for (measured on the build host,
  * Xeon 2.1 GHz: 20.3 ns per product against 27-31 ns for the portable form; tests/test_oracle.py checks both against the
- * reference's own field layer and against each other). */
+ * reference's own field layer and against each other).
+ * The single running top word holds as long as b < 2^254 (then t + a_i b + m q < 2^319); an UNREDUCED second operand -- the
+ * prover multiplies zkey coefficients as they come, up to 2^256 - 1 -- takes the portable form, which carries a sixth word. */
 static inline void fe_mul(fe *r, const fe *a, const fe *b, const fctx *f) {
+    if (b->v[3] >> 62) { fe_mul_c(r, a, b, f); return; }
     u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4, lo, hi;
     const u64 *A = a->v, *B = b->v, *Q = f->q;
     const u64 np = f->np;

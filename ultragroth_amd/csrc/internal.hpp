@@ -69,6 +69,20 @@ constexpr int TABLE_MIN_C = 16, TABLE_MAX_C = 24;                      // <= 16 
 
 struct HeavyBucket { u32 bucket, first_seg, last_seg, pad; };  // a bucket cut into many segment pieces
 
+// ---- sort.hip: the hand-written LSD radix partition that groups a schedule's pairs by bucket ------------------------
+int radix_plan(int bits, int* shift, int* bins_log);          // passes; low bits first
+struct RadixSorter {
+    u32* lookback = nullptr;      // tiles x 256 status words of the pass in flight
+    u32* small = nullptr;         // 4 x 256 bin counts / starts, one tile counter per pass
+    u64 tiles_cap = 0;
+    void reserve(u64 n_pairs, int ipt_min);
+    void release();
+    // see sort.hip; returns which of the two buffer pairs holds the sorted pairs
+    int sort(const u32* scalars, u64 n, int c, int windows, u32 buckets, u32 sentinel, bool tables, u64 n_pairs, int bits,
+             u32* const buf_keys[2], u32* const buf_vals[2], u32* error_flag, hipStream_t stream);
+    ~RadixSorter() { release(); }
+};
+
 // Signed-digit decomposition of n scalars, grouped by (window, bucket): shared by every base set that
 // is multiplied by the same scalars (A, B1, B2 and C all use the witness, src/groth16.cpp:55-64).
 struct MsmSchedule {
@@ -86,10 +100,12 @@ struct MsmSchedule {
     u32 heavy_cap = 0;
     u32* medium_list = nullptr;   // device: HeavyBucket[heavy_cap] for buckets of FIX_MAX < pieces <= MEDIUM_MAX
     u32* heavy_offsets = nullptr; // device: first task of each heavy bucket (n_heavy + 1 entries)
-    u32* meta = nullptr;          // device: [n_heavy, n_valid, n_heavy_tasks, n_medium, n_small, ...] -- read by the kernels, never by the host
+    u32* meta = nullptr;          // device: [n_heavy, n_valid, n_heavy_tasks, n_medium, n_small, ., ., sort failure flag] -- read by the
+                                  // kernels; the flag travels to the host with every product's result block
     // workspace
     u32 *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
-    void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+    void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;       // (the library sort's scratch: UG_SORT=cub, kept for A/B runs)
+    RadixSorter sorter;
     u64 capacity_n = 0; u64 capacity_buckets = 0;
     void reserve(const MsmGeometry& g);
     void build(const u32* scalars_dev, const MsmGeometry& g, hipStream_t stream);   // scalars: n x 32 B plain integers
@@ -134,7 +150,8 @@ struct MsmPending {
     int c = 0, bucket_windows = 0;
     u32* host = nullptr;
 };
-constexpr size_t MSM_PENDING_WORDS = 64 * 72;       // room for the largest result block (<= 43 windows of G2 words)
+constexpr size_t MSM_PENDING_WORDS = 64 * 72;       // room for the largest result block (<= 43 windows of G2 words); the LAST word
+                                                    // receives the schedule's failure flag (meta[7])
 MsmPending msm_enqueue_g1(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta, hipStream_t stream,
                           MsmStats* stats, u32* pinned_host);
 MsmPending msm_enqueue_g2(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta, hipStream_t stream,

@@ -841,10 +841,8 @@ void MsmSchedule::reserve(const MsmGeometry& g) {
         u64 padded = total + ((u64)64 << LOG_SEG);          // room for the lane-transposed copy's last tile
         dev_alloc(keys_a, padded * 4); dev_alloc(keys_b, padded * 4);
         dev_alloc(vals_a, padded * 4); dev_alloc(vals_b, padded * 4);
-        size_t need = 0;
-        hipcub::DoubleBuffer<u32> dk(keys_a, keys_b), dv(vals_a, vals_b);
-        UG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, dk, dv, (int)total, 0, 32));
-        if (need > sort_tmp_bytes) { dev_alloc(sort_tmp, need); sort_tmp_bytes = need; }
+        dev_free(sort_tmp); sort_tmp_bytes = 0;                // (the library sort's scratch is sized on its first use)
+        sorter.reserve(total, 12);
         capacity_n = total;
     }
     if (g.total_buckets() > capacity_buckets) {
@@ -876,19 +874,39 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
     u64 total = g.n * g.windows;
     u32 nb = (u32)g.total_buckets();
     u32 sentinel = nb;
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, stream,
-                       scalars_dev, g.n, g.c, g.windows, g.buckets, sentinel, g.tables ? 1 : 0, keys_a, vals_a);
-    UG_KERNEL_CHECK();
     int end_bit = 1;
     while (((u64)1 << end_bit) <= sentinel) end_bit++;
-    hipcub::DoubleBuffer<u32> dk(keys_a, keys_b), dv(vals_a, vals_b);
-    size_t tmp = sort_tmp_bytes;
-    UG_HIP(hipcub::DeviceRadixSort::SortPairs(sort_tmp, tmp, dk, dv, (int)total, 0, end_bit, stream));
-    keys = dk.Current();
-    vals = dv.Current();
+    UG_HIP(hipMemsetAsync(meta, 0, 32, stream));
+    // UG_SORT=cub: the library sort of rounds 1-2 (A/B runs); default: the hand-written partition of sort.hip, whose first
+    // pass reads the scalars themselves (pairs in unsorted form are written only when a scalar has more than 16 windows)
+    static const bool use_cub = getenv("UG_SORT") && !strcmp(getenv("UG_SORT"), "cub");
+    const bool pairs_first = use_cub || g.windows > 16;
+    if (pairs_first) {
+        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, stream,
+                           scalars_dev, g.n, g.c, g.windows, g.buckets, sentinel, g.tables ? 1 : 0, keys_a, vals_a);
+        UG_KERNEL_CHECK();
+    }
+    if (use_cub) {
+        hipcub::DoubleBuffer<u32> dk(keys_a, keys_b), dv(vals_a, vals_b);
+        if (!sort_tmp_bytes) {
+            size_t need = 0;
+            UG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, dk, dv, (int)total, 0, 32));
+            dev_alloc(sort_tmp, need); sort_tmp_bytes = need;
+        }
+        size_t tmp = sort_tmp_bytes;
+        UG_HIP(hipcub::DeviceRadixSort::SortPairs(sort_tmp, tmp, dk, dv, (int)total, 0, end_bit, stream));
+        keys = dk.Current();
+        vals = dv.Current();
+    } else {
+        u32* const bk[2] = {keys_a, keys_b};
+        u32* const bv[2] = {vals_a, vals_b};
+        const int at = sorter.sort(pairs_first ? nullptr : scalars_dev, g.n, g.c, g.windows, g.buckets, sentinel, g.tables, total, end_bit, bk, bv,
+                                   meta + 7, stream);
+        keys = bk[at];
+        vals = bv[at];
+    }
     UG_HIP(hipMemsetAsync(bucket_start, 0, (size_t)nb * 4, stream));
     UG_HIP(hipMemsetAsync(bucket_count, 0, (size_t)nb * 4, stream));
-    UG_HIP(hipMemsetAsync(meta, 0, 32, stream));
     hipLaunchKernelGGL(bucket_bounds_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, stream,
                        keys, total, sentinel, bucket_start, bucket_count, meta);
     UG_KERNEL_CHECK();
@@ -915,6 +933,7 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
 void MsmSchedule::release() {
     dev_free(keys_a); dev_free(keys_b); dev_free(vals_a); dev_free(vals_b); dev_free(sort_tmp);
     dev_free(bucket_start); dev_free(bucket_count); dev_free(small_list); dev_free(heavy_list); dev_free(medium_list); dev_free(heavy_offsets); dev_free(meta);
+    sorter.release();
     capacity_n = capacity_buckets = 0; sort_tmp_bytes = 0; vals = nullptr; keys = nullptr; heavy_cap = 0;
 }
 
@@ -1056,9 +1075,11 @@ void msm_enqueue_multi(const MsmSchedule& s, MsmWorkspace& ws, int count, const 
         UG_KERNEL_CHECK();
         std::swap(cur, nxt);
     }
-    for (int q = 0; q < k; q++)
+    for (int q = 0; q < k; q++) {
         UG_HIP(hipMemcpyAsync(pinned_host[live[q]], cur + (size_t)q * windows * Cfg::PT_WORDS, (size_t)windows * Cfg::PT_WORDS * 4,
                               hipMemcpyDeviceToHost, stream));
+        UG_HIP(hipMemcpyAsync(pinned_host[live[q]] + MSM_PENDING_WORDS - 1, s.meta + 7, 4, hipMemcpyDeviceToHost, stream));
+    }
 }
 template <class Cfg>
 MsmPending msm_enqueue(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta,
@@ -1074,6 +1095,7 @@ XYZZ<typename Cfg::F> msm_collect(const MsmPending& p) {
     typedef typename Cfg::F F;
     XYZZ<F> acc = xyzz_inf<F>();
     if (p.empty) return acc;
+    if (p.host[MSM_PENDING_WORDS - 1]) throw std::runtime_error("msm: the schedule's sort gave up waiting for a tile (look-back timeout)");
     for (int w = p.bucket_windows - 1; w >= 0; w--) {
         for (int k = 0; k < p.c; k++) acc = xyzz_dbl(acc);
         acc = xyzz_add(acc, Cfg::from_words(p.host + (size_t)w * Cfg::PT_WORDS, 1));

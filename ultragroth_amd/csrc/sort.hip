@@ -33,7 +33,7 @@ constexpr int SORT_WAVES = SORT_THREADS / 64;
 constexpr int SORT_MAX_IPT = 16;              // pairs per lane and tile (the fused first pass takes one scalar per lane: windows <= 16)
 constexpr int SORT_MAX_BINS = 256;
 constexpr u32 LB_VALUE_MASK = (1u << 30) - 1, LB_AGGREGATE = 1u << 30, LB_PREFIX = 2u << 30;
-constexpr u32 SPIN_LIMIT = 1u << 26;          // a look-back that has not seen its predecessor by then gives up and flags the schedule
+constexpr u32 SPIN_LIMIT = 1u << 20;          // a look-back that has not seen its predecessor by then gives up and flags the schedule
 
 struct SortPassArgs {
     // source: either pair arrays ...
@@ -41,7 +41,8 @@ struct SortPassArgs {
     // ... or the scalars themselves (first pass): n scalars of 32 bytes, recoded as msm_digits does
     const u32* scalars; u64 n; int c, windows; u32 buckets, sentinel; int tables;
     u32* keys_out; u32* vals_out;
-    u64 n_pairs;                      // pairs that exist (the rest of the last tile is padding)
+    u64 n_pairs;                      // pairs the source holds (the rest of the last tile is padding made on the fly)
+    u32 n_moved;                      // pairs every pass moves (real ones + the first pass's padding): nothing is written beyond
     int ipt;                          // pairs per lane
     int shift, bins_log;              // this pass sorts on (key >> shift) & (2^bins_log - 1)
     const u32* bin_base;              // 2^bins_log exclusive bin starts of this pass
@@ -189,9 +190,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
             }
             const u32 before = (u32)__popcll(peers & lt_mask), same = (u32)__popcll(peers);
             const u32 old = mycnt[d];                      // every peer reads the counter ...
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (before == 0) mycnt[d] = old + same;        // ... before its first lane moves it on (one wave: in order)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (before == 0) mycnt[d] = old + same;        // ... before its first lane moves it on (one wave, LDS accesses in program order)
             rank[j] = old + before;
         }
     }
@@ -252,9 +251,11 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
     for (u32 lp = tid; lp < T; lp += SORT_THREADS) {
         const u32 k = stage_k[lp];
         const u32 d = (k >> a.shift) & dmask;
-        const u64 pos = (u64)gbase[d] + lp;
-        a.keys_out[pos] = k;
-        a.vals_out[pos] = stage_v[lp];
+        const u32 pos = gbase[d] + lp;                     // (mod 2^32: gbase holds a difference)
+        if (pos < a.n_moved) {                             // (padding a later pass made for its own last tile sorts behind everything: dropped)
+            a.keys_out[pos] = k;
+            a.vals_out[pos] = stage_v[lp];
+        }
     }
 }
 
@@ -332,7 +333,8 @@ int RadixSorter::sort(const u32* scalars, u64 n, int c, int windows, u32 buckets
         a.scalars = first_fused ? scalars : nullptr; a.n = n; a.c = c; a.windows = windows; a.buckets = buckets; a.sentinel = sentinel; a.tables = tables ? 1 : 0;
         const int dst = first_fused ? 0 : 1 - cur;
         a.keys_out = buf_keys[dst]; a.vals_out = buf_vals[dst];
-        a.n_pairs = first_fused ? n_pairs : moved;           // later passes read the padding of the first one as pairs
+        a.n_pairs = p == 0 ? n_pairs : moved;                // later passes read the padding of the first one as pairs
+        a.n_moved = (u32)moved;
         a.ipt = first_fused ? windows : SORT_MAX_IPT;
         a.shift = shift[p]; a.bins_log = bins_log[p];
         a.bin_base = hist + p * SORT_MAX_BINS;
