@@ -5,10 +5,9 @@
 //   :100-108 c = a o b
 //   :142-148 h = a o b - c, fromMontgomery
 // The reference's scatter with locks becomes a gather: the coefficient records are sorted by
-// (matrix, row) once at create time (hipcub radix sort on the device) into CSR form, and one lane
+// (matrix, row) once at create time (the radix partition of sort.hip, on the device) into CSR form, and one lane
 // sums one row -- deterministic and atomic-free. Rows are written at their bit-reversed position so
 // that the first NTT pass reads contiguously.
-#include <hipcub/hipcub.hpp>
 #include "dev_common.hpp"
 #include "internal.hpp"
 
@@ -212,36 +211,40 @@ bool CoefMatrix::build(const uint8_t* raw44_dev, u64 ncoefs_, u32 domain_, u32 n
     if (ncoefs >= ((u64)1 << 31)) throw std::invalid_argument("coefficient count exceeds 2^31");
     u32 nrows = 2 * domain;
     u32 *keys_a = nullptr, *keys_b = nullptr, *idx_a = nullptr, *idx_b = nullptr, *bad = nullptr;
-    void* tmp = nullptr;
-    dev_alloc(keys_a, ncoefs * 4); dev_alloc(keys_b, ncoefs * 4);
-    dev_alloc(idx_a, ncoefs * 4); dev_alloc(idx_b, ncoefs * 4);
+    const u64 padded = ncoefs + 8192;                  // the sort moves whole tiles
+    dev_alloc(keys_a, padded * 4); dev_alloc(keys_b, padded * 4);
+    dev_alloc(idx_a, padded * 4); dev_alloc(idx_b, padded * 4);
+    u32* flag = nullptr;
+    dev_alloc(flag, 4);
+    RadixSorter sorter;
     dev_alloc(bad, 4);
     dev_alloc(row_ptr, ((size_t)nrows + 1) * 4);
     dev_alloc(sig, ncoefs * 4);
     dev_alloc(val, ncoefs * 32);
     UG_HIP(hipMemsetAsync(bad, 0, 4, stream));
-    u32 bad_host = 0;
+    u32 bad_host = 0, sort_failed = 0;
     if (ncoefs) {
         hipLaunchKernelGGL(coef_keys_kernel, dim3(grid_for(ncoefs, 256)), dim3(256), 0, stream, raw44_dev, ncoefs, domain, nvars, keys_a, idx_a, bad);
         UG_KERNEL_CHECK();
         int end_bit = 1;
         while (((u64)1 << end_bit) < nrows) end_bit++;
-        hipcub::DoubleBuffer<u32> dk(keys_a, keys_b), dv(idx_a, idx_b);
-        size_t need = 0;
-        UG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, dk, dv, (int)ncoefs, 0, end_bit, stream));
-        dev_alloc(tmp, need);
-        UG_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, need, dk, dv, (int)ncoefs, 0, end_bit, stream));
-        hipLaunchKernelGGL(coef_gather_kernel, dim3(grid_for(ncoefs, 256)), dim3(256), 0, stream, raw44_dev, ncoefs, dv.Current(), sig, val);
+        UG_HIP(hipMemsetAsync(flag, 0, 4, stream));
+        u32* const bk[2] = {keys_a, keys_b};
+        u32* const bv[2] = {idx_a, idx_b};
+        const int at = sorter.sort(nullptr, 0, 0, 0, 0, 0, false, ncoefs, end_bit, bk, bv, flag, stream);      // pair form: (row key, record index)
+        hipLaunchKernelGGL(coef_gather_kernel, dim3(grid_for(ncoefs, 256)), dim3(256), 0, stream, raw44_dev, ncoefs, bv[at], sig, val);
         UG_KERNEL_CHECK();
-        hipLaunchKernelGGL(row_ptr_kernel, dim3(grid_for((u64)nrows + 1, 256)), dim3(256), 0, stream, dk.Current(), ncoefs, nrows, row_ptr);
+        hipLaunchKernelGGL(row_ptr_kernel, dim3(grid_for((u64)nrows + 1, 256)), dim3(256), 0, stream, bk[at], ncoefs, nrows, row_ptr);
         UG_KERNEL_CHECK();
         UG_HIP(hipMemcpyAsync(&bad_host, bad, 4, hipMemcpyDeviceToHost, stream));
+        UG_HIP(hipMemcpyAsync(&sort_failed, flag, 4, hipMemcpyDeviceToHost, stream));
     } else {
         UG_HIP(hipMemsetAsync(row_ptr, 0, ((size_t)nrows + 1) * 4, stream));
     }
     UG_HIP(hipStreamSynchronize(stream));
-    hipFree(keys_a); hipFree(keys_b); hipFree(idx_a); hipFree(idx_b); hipFree(bad);
-    if (tmp) hipFree(tmp);
+    hipFree(keys_a); hipFree(keys_b); hipFree(idx_a); hipFree(idx_b); hipFree(bad); hipFree(flag);
+    sorter.release();
+    if (sort_failed) throw std::runtime_error("coefficient matrix: the sort gave up waiting for a tile (look-back timeout)");
     return bad_host == 0;
 }
 

@@ -1517,6 +1517,108 @@ private:
     double msm_ = 0, fft_ = 0, total_ = 0;
 };
 
+// The same for UltraGroth (src/ultra_groth.cpp:401-462): every rank keeps the whole witness and owns slices of the
+// witness-indexed sets, the round set, the final set and H. Per proof: the 64-byte parts of the round commitment are added on
+// the host, rank 0 closes the round (:173-176), every rank derives the challenge and completes its witness (:33-106), then
+// the final round runs as the Groth16 phases do; rank 0 blinds and serialises. (An UltraGroth rank has one stream: its
+// chain follows its MSMs.)
+class MultiUltraGrothProver : public ProverBase {
+public:
+    MultiUltraGrothProver(const void* zkey, unsigned long long zkeySize, const std::vector<int>& devices) {
+        const int R = (int)devices.size();
+        BinFile f(zkey, zkeySize, "zkey", 1);
+        ZkeyHeader h = loadZkeyHeader(f, true);
+        if (!h.rIsBn254) throw std::invalid_argument("zkey curve not supported");
+        nPublic_ = h.nPublic; domain_ = h.domainSize;
+        ranks_.resize(R);
+        const bool oneShot = g_oneShotProver;
+        std::vector<std::future<void>> jobs;
+        for (int k = 0; k < R; k++)
+            jobs.push_back(std::async(std::launch::async, [&, k, oneShot] {
+                g_oneShotProver = oneShot;
+                ranks_[k].reset(new UltraGrothProver(zkey, zkeySize, devices[k], k, R));
+            }));
+        std::exception_ptr failure;
+        for (auto& j : jobs) { try { j.get(); } catch (...) { if (!failure) failure = std::current_exception(); } }
+        if (failure) { ranks_.clear(); std::rethrow_exception(failure); }
+        for (int c = 0; c < 3; c++) ugCheck(ug_dvec_create(ranks_[c % R]->ctx(), domain_, &full_[c]));
+        slices_.resize(R);
+        for (int k = 0; k < R; k++) {
+            unsigned long long first = 0, cnt = 0;
+            ranks_[k]->hRange(&first, &cnt, nullptr);
+            for (int c = 0; c < 3; c++) ugCheck(ug_dvec_create(ranks_[k]->ctx(), cnt ? cnt : 1, &slices_[k].v[c]));
+        }
+    }
+    ~MultiUltraGrothProver() override {
+        for (auto& s : slices_) for (ug_dvec* v : s.v) ug_dvec_destroy(v);
+        for (ug_dvec* v : full_) ug_dvec_destroy(v);
+    }
+    void prove(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub) override {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int R = (int)ranks_.size();
+        std::vector<std::exception_ptr> errs(R);
+        auto everyRank = [&](const std::function<void(int)>& body) {
+            std::vector<std::thread> th;
+            for (int k = 0; k < R; k++) th.emplace_back([&, k] { try { body(k); } catch (...) { errs[k] = std::current_exception(); } });
+            for (auto& t : th) t.join();
+            for (auto& e : errs) if (e) std::rethrow_exception(e);
+        };
+        // round 1: the commitment to the round witnesses, part by part
+        std::vector<std::array<uint8_t, 64>> cparts(R);
+        everyRank([&](int k) { ranks_[k]->loadWitness(wtns, wtnsSize); ranks_[k]->roundCommit(cparts[k].data()); });
+        for (int k = 1; k < R; k++) if (ug_g1_record_add(cparts[0].data(), cparts[k].data()) != PROVER_OK) throw std::runtime_error("partial sum failed");
+        uint8_t commit[64];
+        ranks_[0]->roundFinish(cparts[0].data(), commit);
+        // final round
+        std::vector<std::array<uint8_t, UG_GROTH16_PARTIALS_SIZE>> parts(R);
+        everyRank([&](int k) {
+            UltraGrothProver& p = *ranks_[k];
+            p.applyCommitment(commit);
+            p.runWitnessMsm(parts[k].data());
+            for (int c = k; c < 3; c += R) p.hpolyChain(c, ug_dvec_device_ptr(full_[c]));
+        });
+        everyRank([&](int k) {
+            UltraGrothProver& p = *ranks_[k];
+            unsigned long long first = 0, cnt = 0;
+            p.hRange(&first, &cnt, nullptr);
+            for (int c = 0; c < 3; c++) ugCheck(ug_dvec_copy(slices_[k].v[c], 0, full_[c], first, cnt));
+            p.hpolyCombine(ug_dvec_device_ptr(slices_[k].v[0]), ug_dvec_device_ptr(slices_[k].v[1]), ug_dvec_device_ptr(slices_[k].v[2]));
+            uint8_t hpart[UG_GROTH16_PARTIALS_SIZE];
+            p.runHMsm(hpart);
+            memcpy(parts[k].data() + 320, hpart + 320, 64);
+        });
+        for (int k = 1; k < R; k++)
+            if (ug_groth16_partials_add(parts[0].data(), parts[k].data()) != PROVER_OK) throw std::runtime_error("partial sum failed");
+        ranks_[0]->finish(parts[0].data(), proof, pub);
+        msm_ = fft_ = 0;
+        for (auto& r : ranks_) { double m = 0, f = 0; r->timings(&m, &f, nullptr); msm_ = std::max(msm_, m); fft_ = std::max(fft_, f); }
+        total_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    unsigned long long proofBufferMinSize() const override { return PROOF_MIN_ULTRA; }
+    unsigned long long publicBufferMinSize() const override { return publicMin((unsigned long long)nPublic_ - 1); }
+    void timings(double* msm, double* fft, double* total) const override {
+        if (msm) *msm = msm_;
+        if (fft) *fft = fft_;
+        if (total) *total = total_;
+    }
+    ug_ctx* ctx() override { return ranks_[0]->ctx(); }
+    std::vector<TableGroup> tableGroups() override { return {}; }
+    void trimWorkspaces() override { for (auto& r : ranks_) r->trimWorkspaces(); }
+
+private:
+    struct Slices { ug_dvec* v[3] = {nullptr, nullptr, nullptr}; };
+    std::vector<std::unique_ptr<UltraGrothProver>> ranks_;
+    ug_dvec* full_[3] = {nullptr, nullptr, nullptr};
+    std::vector<Slices> slices_;
+    uint32_t nPublic_ = 0, domain_ = 0;
+    double msm_ = 0, fft_ = 0, total_ = 0;
+};
+
+ProverBase* newUltraGrothProver(const void* zkey, unsigned long long size) {
+    const std::vector<int> devices = devicesFromEnv();
+    if (devices.size() > 1) return new MultiUltraGrothProver(zkey, size, devices);
+    return new UltraGrothProver(zkey, size, devices.size() == 1 ? devices[0] : deviceFromEnv());
+}
 ProverBase* newGroth16Prover(const void* zkey, unsigned long long size) {
     const std::vector<int> devices = devicesFromEnv();
     if (devices.size() > 1) return new MultiGroth16Prover(zkey, size, devices);
@@ -1822,7 +1924,7 @@ int ultra_groth_prover_create(void** prover_object, const void* zkey_buffer, uns
     API_TRY
     if (prover_object == NULL) throw std::invalid_argument("Null prover object");
     if (zkey_buffer == NULL) throw std::invalid_argument("Null zkey buffer");
-    *prover_object = static_cast<ProverBase*>(new UltraGrothProver(zkey_buffer, zkey_size, deviceFromEnv()));
+    *prover_object = newUltraGrothProver(zkey_buffer, zkey_size);
     API_CATCH
 }
 int groth16_prover_create_zkey_file(void** prover_object, const char* zkey_file_path, char* error_msg,
@@ -1838,7 +1940,7 @@ int ultra_groth_prover_create_zkey_file(void** prover_object, const char* zkey_f
     API_TRY
     if (prover_object == NULL) throw std::invalid_argument("Null prover object");
     FileMap m(zkey_file_path);
-    *prover_object = static_cast<ProverBase*>(new UltraGrothProver(m.data(), m.size(), deviceFromEnv()));
+    *prover_object = newUltraGrothProver(m.data(), m.size());
     API_CATCH
 }
 
