@@ -383,6 +383,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Cfg::ACC_WA
 // mixed addition (3 us) ahead of its use.
 // ROTATE: the K additions are one rolled loop over accumulator 0 with the accumulators rotated between turns (one
 // addition's code instead of K copies of it in the loop body).
+// Measured at 2^24 (round 3, profiles/r03_variants_ab.txt): the launch takes what the three single launches took (44.2 ms
+// against 3 x 14.8): the kernel is bound by the instruction stream of the addition, so what the group saves is the entry
+// list's two extra reads and two launches, not time. With every gather folded into cache (UG_GROUP_FOLD_LOG) it takes 40.4 ms:
+// the gathers' latency is worth 9 %, but neither the rotation nor all K records of an entry fetched together by LDS-DMA
+// (global_load_lds_dwordx4 into a per-wave region, built and verified bit-exact, 43.8 against 43.5 ms, not kept) gets any of
+// it back: the limit is the latency of a random access into 36 GiB (translation + DRAM), one addition's time ahead is all a
+// lane can look with its registers full, and adjacent pieces do not make that access shorter.
 template <int K, bool ROTATE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void segment_accumulate_group_kernel(
         const u32* __restrict__ bases, u64 n_slots, int64_t delta, const u32* __restrict__ keys, const u32* __restrict__ tkeys,
@@ -1001,7 +1008,8 @@ void msm_enqueue_multi(const MsmSchedule& s, MsmWorkspace& ws, int count, const 
             const char* rot = getenv("UG_GROUP_ROTATE");                      // tuning knob, read per launch (the tests take both shapes)
             const bool rotate = rot && atoi(rot) != 0;
             const char* fold = getenv("UG_GROUP_FOLD_LOG");                   // measurement knob (wrong sums): see the kernel
-            const u32 fold_mask = fold ? ((1u << atoi(fold)) - 1) : ~0u;
+            const u32 fold_mask = fold && *fold ? ((1u << atoi(fold)) - 1) : ~0u;
+
             int slot = stats ? stats->begin(stream, g.n * g.windows * (u64)group) : -1;
             if (nseg) {
                 const dim3 grid((unsigned)((nseg + 255) / 256)), block(256);

@@ -30,7 +30,8 @@ namespace {
 
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_WAVES = SORT_THREADS / 64;
-constexpr int SORT_MAX_IPT = 16;              // pairs per lane and tile (the fused first pass takes one scalar per lane: windows <= 16)
+constexpr int SORT_MAX_IPT = 16;              // most pairs a lane holds per tile (32 was measured: the longer unrolled bodies cost every shape 10 %)
+constexpr int SORT_FUSED_MAX_WINDOWS = 16;    // the fused first pass takes whole scalars per lane: windows * scalars_per_lane <= SORT_MAX_IPT
 constexpr int SORT_MAX_BINS = 256;
 constexpr u32 LB_VALUE_MASK = (1u << 30) - 1, LB_AGGREGATE = 1u << 30, LB_PREFIX = 2u << 30;
 constexpr u32 SPIN_LIMIT = 1u << 20;          // a look-back that has not seen its predecessor by then gives up and flags the schedule
@@ -44,6 +45,7 @@ struct SortPassArgs {
     u64 n_pairs;                      // pairs the source holds (the rest of the last tile is padding made on the fly)
     u32 n_moved;                      // pairs every pass moves (real ones + the first pass's padding): nothing is written beyond
     int ipt;                          // pairs per lane
+    int spl;                          // fused first pass: scalars per lane (ipt = spl * windows)
     int shift, bins_log;              // this pass sorts on (key >> shift) & (2^bins_log - 1)
     const u32* bin_base;              // 2^bins_log exclusive bin starts of this pass
     u32* lookback;                    // tiles x 2^bins_log status words, zeroed
@@ -134,7 +136,7 @@ __global__ void radix_scan_kernel(u32* hist, int passes) {
     for (int b = 0; b < SORT_MAX_BINS; b++) { const u32 v = hist[p * SORT_MAX_BINS + b]; hist[p * SORT_MAX_BINS + b] = run; run += v; }
 }
 
-template <bool FROM_SCALARS>
+template <bool FROM_SCALARS, int LBW>
 __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a) {
     extern __shared__ u32 lds[];
     const int ipt = a.ipt;
@@ -157,14 +159,18 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
     // ---- load (or make) the tile's pairs: lane holds pairs j = 0 .. ipt-1; wave-striped, so that (wave, j, lane) is memory order
     u32 key[SORT_MAX_IPT], val[SORT_MAX_IPT];
     if constexpr (FROM_SCALARS) {
-        // one scalar per lane, pair j = its window j (any order will do for a first pass)
-        const u64 i = (u64)tile * SORT_THREADS + tid;
+        // whole scalars per lane, pair j = window j of its first scalar, windows + j of its second (any order will do for a
+        // first pass)
 #pragma unroll
         for (int j = 0; j < SORT_MAX_IPT; j++) { key[j] = 0xffffffffu; val[j] = 0; }
-        recode_scalar(a.scalars, i, a.n, a.c, a.windows, a.buckets, a.sentinel, a.tables, [&](int w, u32 k, u32 v) {
+        for (int sc = 0; sc < a.spl; sc++) {
+            const u64 i = ((u64)tile * SORT_THREADS + tid) * (u64)a.spl + (u64)sc;
+            const int j0 = sc * a.windows;
+            recode_scalar(a.scalars, i, a.n, a.c, a.windows, a.buckets, a.sentinel, a.tables, [&](int w, u32 k, u32 v) {
 #pragma unroll
-            for (int j = 0; j < SORT_MAX_IPT; j++) if (j == w) { key[j] = k; val[j] = v; }
-        });
+                for (int j = 0; j < SORT_MAX_IPT; j++) if (j == j0 + w) { key[j] = k; val[j] = v; }
+            });
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < SORT_MAX_IPT; j++) {
@@ -219,17 +225,27 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
         u32 prev = 0;
         if (tile) {
             __hip_atomic_store(mine, LB_AGGREGATE | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (u32 t = tile; t-- > 0;) {
-                const u32* theirs = a.lookback + (size_t)t * bins + tid;
-                u32 v = 0, spins = 0;
-                do {
-                    v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v >> 30) break;
-                    __builtin_amdgcn_s_sleep(1);
-                } while (++spins < SPIN_LIMIT);
-                if (!(v >> 30)) { atomicOr(a.error_flag, 1u); break; }      // never seen: give up (the schedule is flagged), do not hang
-                prev += v & LB_VALUE_MASK;
-                if ((v >> 30) == 2) break;
+            // LBW tiles back per turn: their status words are read together (one round trip to the memory side instead of LBW in
+            // a row), then taken nearest first; a word that is still empty is waited for
+            bool done = false;
+            for (u32 t = tile; t > 0 && !done;) {
+                u32 v[LBW];
+#pragma unroll
+                for (int q = 0; q < LBW; q++)
+                    v[q] = t > (u32)q ? __hip_atomic_load(a.lookback + (size_t)(t - 1 - q) * bins + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_PREFIX;
+#pragma unroll
+                for (int q = 0; q < LBW; q++) {
+                    if (done) break;
+                    u32 w = v[q], spins = 0;
+                    while (!(w >> 30) && ++spins < SPIN_LIMIT) {
+                        __builtin_amdgcn_s_sleep(1);
+                        w = __hip_atomic_load(a.lookback + (size_t)(t - 1 - q) * bins + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (!(w >> 30)) { atomicOr(a.error_flag, 1u); done = true; break; }      // never seen: give up (the schedule is flagged), do not hang
+                    prev += w & LB_VALUE_MASK;
+                    if ((w >> 30) == 2) done = true;
+                }
+                t = t > (u32)LBW ? t - LBW : 0;
             }
         }
         __hip_atomic_store(mine, LB_PREFIX | (prev + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -263,13 +279,14 @@ template <class T> void sort_alloc(T*& p, size_t bytes) { if (p) hipFree(p); p =
 
 }  // namespace
 
-// pass plan for keys below 2^bits: ceil(bits / 8) passes of nearly equal width, low bits first
+// pass plan for keys below 2^bits: ceil(bits / 8) passes of nearly equal width, low bits first, the narrower digits first (the
+// fused first pass has the smallest tiles: windows pairs per lane)
 int radix_plan(int bits, int* shift, int* bins_log) {
     if (bits < 1) bits = 1;
     const int passes = (bits + 7) / 8;
     int at = 0;
     for (int p = 0; p < passes; p++) {
-        const int w = (bits - at + (passes - p) - 1) / (passes - p);
+        const int w = (bits - at) / (passes - p);
         shift[p] = at; bins_log[p] = w; at += w;
     }
     return passes;
@@ -297,9 +314,15 @@ int RadixSorter::sort(const u32* scalars, u64 n, int c, int windows, u32 buckets
     int shift[4], bins_log[4];
     const int passes = radix_plan(bits, shift, bins_log);
     if (passes > 4) throw std::logic_error("radix sort: key too wide");
-    const bool fused = scalars != nullptr && windows <= SORT_MAX_IPT;
-    const int ipt_first = fused ? windows : SORT_MAX_IPT;
-    reserve(n_pairs, fused ? windows : SORT_MAX_IPT);
+    // tuning knobs: pairs per lane of the pair-form passes, scalars per lane of the fused first pass
+    static const int env_ipt = getenv("UG_SORT_IPT") ? atoi(getenv("UG_SORT_IPT")) : 16;
+    static const int env_spl = getenv("UG_SORT_SPL") ? atoi(getenv("UG_SORT_SPL")) : 1;
+    const int ipt_pairs = env_ipt < 4 ? 4 : env_ipt > SORT_MAX_IPT ? SORT_MAX_IPT : env_ipt;
+    const bool fused = scalars != nullptr && windows <= SORT_FUSED_MAX_WINDOWS;
+    int spl = 1;
+    if (fused) { spl = env_spl < 1 ? 1 : env_spl; while (spl > 1 && spl * windows > SORT_MAX_IPT) spl--; }
+    const int ipt_first = fused ? windows * spl : ipt_pairs;
+    reserve(n_pairs, fused ? std::min(windows * spl, ipt_pairs) : ipt_pairs);
     u32* hist = small;                         // passes x 256
     u32* counters = small + 4 * SORT_MAX_BINS; // one tile counter per pass
     UG_HIP(hipMemsetAsync(small, 0, (4 * SORT_MAX_BINS + 16) * 4, stream));
@@ -311,7 +334,7 @@ int RadixSorter::sort(const u32* scalars, u64 n, int c, int windows, u32 buckets
         SortHistArgs h;
         h.keys_in = fused ? nullptr : buf_keys[0];
         h.scalars = fused ? scalars : nullptr; h.n = n; h.c = c; h.windows = windows; h.buckets = buckets; h.sentinel = sentinel; h.tables = tables ? 1 : 0;
-        h.n_pairs = n_pairs; h.n_padded = fused ? n_padded : ((n_pairs + (u64)SORT_THREADS * SORT_MAX_IPT - 1) / ((u64)SORT_THREADS * SORT_MAX_IPT)) * ((u64)SORT_THREADS * SORT_MAX_IPT);
+        h.n_pairs = n_pairs; h.n_padded = fused ? n_padded : ((n_pairs + (u64)SORT_THREADS * ipt_pairs - 1) / ((u64)SORT_THREADS * ipt_pairs)) * ((u64)SORT_THREADS * ipt_pairs);
         h.passes = passes;
         for (int p = 0; p < 4; p++) { h.shift[p] = p < passes ? shift[p] : 0; h.bins_log[p] = p < passes ? bins_log[p] : 1; }
         h.hist = hist;
@@ -324,7 +347,7 @@ int RadixSorter::sort(const u32* scalars, u64 n, int c, int windows, u32 buckets
         UG_KERNEL_CHECK();
     }
     // every pass moves the same multiset of pairs: the real ones plus the padding of the first pass's last tile
-    const u64 moved = fused ? n_padded : (n_pairs + (u64)SORT_THREADS * SORT_MAX_IPT - 1) / ((u64)SORT_THREADS * SORT_MAX_IPT) * ((u64)SORT_THREADS * SORT_MAX_IPT);
+    const u64 moved = fused ? n_padded : (n_pairs + (u64)SORT_THREADS * ipt_pairs - 1) / ((u64)SORT_THREADS * ipt_pairs) * ((u64)SORT_THREADS * ipt_pairs);
     int cur = 0;                               // buffer pair that holds the current order (pair form: the input)
     for (int p = 0; p < passes; p++) {
         const bool first_fused = fused && p == 0;
@@ -335,7 +358,8 @@ int RadixSorter::sort(const u32* scalars, u64 n, int c, int windows, u32 buckets
         a.keys_out = buf_keys[dst]; a.vals_out = buf_vals[dst];
         a.n_pairs = p == 0 ? n_pairs : moved;                // later passes read the padding of the first one as pairs
         a.n_moved = (u32)moved;
-        a.ipt = first_fused ? windows : SORT_MAX_IPT;
+        a.ipt = first_fused ? ipt_first : ipt_pairs;
+        a.spl = spl;
         a.shift = shift[p]; a.bins_log = bins_log[p];
         a.bin_base = hist + p * SORT_MAX_BINS;
         a.lookback = lookback; a.tile_counter = counters + p; a.error_flag = error_flag;
@@ -344,8 +368,17 @@ int RadixSorter::sort(const u32* scalars, u64 n, int c, int windows, u32 buckets
         if (tiles > tiles_cap) throw std::logic_error("radix sort: look-back table too small");
         UG_HIP(hipMemsetAsync(lookback, 0, (size_t)tiles * ((size_t)1 << bins_log[p]) * 4, stream));
         const size_t lds = (2 * T + SORT_WAVES * SORT_MAX_BINS + 2 * SORT_MAX_BINS + 8) * 4;
-        if (first_fused) hipLaunchKernelGGL(radix_pass_kernel<true>, dim3((unsigned)tiles), dim3(SORT_THREADS), lds, stream, a);
-        else hipLaunchKernelGGL(radix_pass_kernel<false>, dim3((unsigned)tiles), dim3(SORT_THREADS), lds, stream, a);
+        static const int lbw = getenv("UG_SORT_LBW") ? atoi(getenv("UG_SORT_LBW")) : 4;      // tuning knob: look-back window
+        if (lbw >= 16) {
+            if (first_fused) hipLaunchKernelGGL((radix_pass_kernel<true, 16>), dim3((unsigned)tiles), dim3(SORT_THREADS), lds, stream, a);
+            else hipLaunchKernelGGL((radix_pass_kernel<false, 16>), dim3((unsigned)tiles), dim3(SORT_THREADS), lds, stream, a);
+        } else if (lbw >= 8) {
+            if (first_fused) hipLaunchKernelGGL((radix_pass_kernel<true, 8>), dim3((unsigned)tiles), dim3(SORT_THREADS), lds, stream, a);
+            else hipLaunchKernelGGL((radix_pass_kernel<false, 8>), dim3((unsigned)tiles), dim3(SORT_THREADS), lds, stream, a);
+        } else {
+            if (first_fused) hipLaunchKernelGGL((radix_pass_kernel<true, 4>), dim3((unsigned)tiles), dim3(SORT_THREADS), lds, stream, a);
+            else hipLaunchKernelGGL((radix_pass_kernel<false, 4>), dim3((unsigned)tiles), dim3(SORT_THREADS), lds, stream, a);
+        }
         UG_KERNEL_CHECK();
         cur = dst;
     }
