@@ -86,7 +86,10 @@ __global__ void check_kernel(const u32* data, int iters, u32* mismatches) {
     const bool odd = t & 1;
     Fq2 x, y;
     u32* px = reinterpret_cast<u32*>(&x); u32* py = reinterpret_cast<u32*>(&y);
-    for (int i = 0; i < 2 * NL; i++) { px[i] = data[(size_t)pair * 4 * NL + i] & (MASK29 >> 4); py[i] = data[(size_t)pair * 4 * NL + 2 * NL + i] & (MASK29 >> 4); }
+    for (int i = 0; i < 2 * NL; i++) {                                  // canonical-sized inputs: the top limb keeps the value below q
+        const u32 m = (i % NL == NL - 1) ? 0xffffu : (MASK29 >> 4);
+        px[i] = data[(size_t)pair * 4 * NL + i] & m; py[i] = data[(size_t)pair * 4 * NL + 2 * NL + i] & m;
+    }
     XYZZ<Fq2> ref = xyzz_from_affine(x, y);
     XYZZ<H> acc;
     acc.x = odd ? x.b : x.a; acc.y = odd ? y.b : y.a;
@@ -107,7 +110,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool odd = t & 1;
     H x, y;
-    for (int i = 0; i < NL; i++) { x.l[i] = data[(size_t)t * 2 * NL + i] & (MASK29 >> 4); y.l[i] = data[(size_t)t * 2 * NL + NL + i] & (MASK29 >> 4); }
+    for (int i = 0; i < NL; i++) {
+        const u32 m = (i == NL - 1) ? 0xffffu : (MASK29 >> 4);
+        x.l[i] = data[(size_t)t * 2 * NL + i] & m; y.l[i] = data[(size_t)t * 2 * NL + NL + i] & m;
+    }
     XYZZ<H> acc;
     acc.x = x; acc.y = y; acc.zz = odd ? fp_zero<FqParams>() : fp_one<FqParams>(); acc.zzz = acc.zz;
     for (int i = 0; i < iters; i++) {

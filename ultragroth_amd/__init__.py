@@ -231,15 +231,28 @@ class UltraGrothProver(_ProverBase):
     _proof_size = staticmethod(ultra_groth_proof_size)
 
 
+def _one_shot(fn, public_size_fn, proof_size, zkey, wtns):
+    L = load()
+    psz = C.c_ulonglong(proof_size)
+    qsz = C.c_ulonglong(_public_size(getattr(L, public_size_fn), zkey))
+    proof = C.create_string_buffer(max(psz.value, 1))
+    pub = C.create_string_buffer(max(qsz.value, 1))
+    err = C.create_string_buffer(1024)
+    rc = getattr(L, fn)(zkey, len(zkey), wtns, len(wtns), proof, C.byref(psz), pub, C.byref(qsz), err, len(err) - 1)
+    if rc != PROVER_OK:
+        raise ProverError(rc, err.value.decode(errors="replace"))
+    return proof.raw.split(b"\0", 1)[0].decode(), pub.raw.split(b"\0", 1)[0].decode()
+
+
 def groth16_prover(zkey, wtns):
-    """One-shot groth16_prover (src/prover.h:173-185)."""
-    with Groth16Prover(zkey) as p:
-        return p.prove(wtns)
+    """The reference's one-shot entry point groth16_prover (src/prover.h:173-185): create, prove once, destroy -- no window
+    tables are built for it (they cannot pay for one proof)."""
+    return _one_shot("groth16_prover", "groth16_public_size_for_zkey_buf", groth16_proof_size(), zkey, wtns)
 
 
 def ultra_groth_prover(zkey, wtns):
-    with UltraGrothProver(zkey) as p:
-        return p.prove(wtns)
+    """ultra_groth_prover (src/prover.h:187-199)"""
+    return _one_shot("ultra_groth_prover", "ultra_groth_public_size_for_zkey_buf", ultra_groth_proof_size(), zkey, wtns)
 
 
 class Registry:
