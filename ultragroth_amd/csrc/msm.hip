@@ -5,17 +5,20 @@
 // UltraGroth twins src/ultra_groth.cpp:168,201,214,227,234,322). Scalars are 32-byte plain integers.
 //
 // Pipeline (one "schedule" per scalar vector, shared by every base set multiplied by it):
-//   1. msm_digits_kernel     scalar -> signed c-bit digits (carry recoding), one (key, val) pair per window:
+//   1. signed digits         scalar -> signed c-bit digits (carry recoding), one (key, val) pair per window, made inside the first
+//                            pass of the sort (sort.hip; msm_digits_kernel only for scalars of more than 16 windows):
 //                            key = bucket id (one bucket set for all windows when the base set has window tables, else
 //                            window * 2^(c-1) + |digit| - 1), val = index | table << 27 | sign << 31; zero digits get a
 //                            sentinel key and fall off the end of the sort
-//   2. hipcub radix sort     groups pairs by bucket                (coalesced, no atomics)
+//   2. radix partition       sort.hip: hand-written LSD passes with a decoupled look-back group the pairs by bucket
+//                            (UG_SORT=cub: the library sort of rounds 1-2, kept for A/B runs)
 //   3. bucket_bounds / bucket_counts   first entry and entry count of every bucket; buckets cut by segment boundaries are
 //                            listed by size class. Counts stay on the device (meta): no host read-back
 //   4. transpose_entries     lane-transposed copy of the entries: the sorted list is cut into segments (segmap.hpp), one
 //                            lane each, so that every lane of a wave does the same number of additions
-//   5. segment_accumulate    the dominant kernel: gather affine bases, mixed-add into XYZZ registers; whole buckets go to
-//                            bucket_pts, runs cut by a segment boundary to two slots per lane
+//   5. segment_accumulate    the dominant kernels: gather affine bases, mixed-add into XYZZ registers; whole buckets go to
+//                            bucket_pts, runs cut by a segment boundary to two slots per lane. G1 sets that share their scalars
+//                            (A | B1 | C) are one interleaved group: segment_accumulate_group_kernel keeps K accumulators
 //      bucket_fixup / medium_bucket / heavy_partial + heavy_final   add the pieces of cut buckets (a lane, a wave or
 //                            workgroup tasks per bucket: witnesses are full of 0/1 values, i.e. million-entry buckets)
 //   6. bucket_chunk_reduce   running-sum trick on chunks of up to 32 buckets + ec_sum_groups / ec_sum_wave tree
