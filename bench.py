@@ -155,25 +155,14 @@ def cpu_baseline(dev, args, log_domain, circuit=None):
     }
 
 
-# One iFFT/twist/FFT chain costs about this fraction of ALL the witness MSMs of a proof (2^24, measured with
-# tools/phase_times.py: chains a, b 7.1 ms and c 9.0 ms -- it also forms a.b -- against 113 ms; both sides grow ~linearly)
-CHAIN_SHARE = (0.063, 0.063, 0.080)
-
-
 def witness_slice(info, rank, world):
     """Rank k's slice of the witness-indexed sections. Chain k of the H polynomial runs on rank k mod N beside that
-    rank's witness MSMs, so the ranks that carry chains get fewer points: shares s_k = base - chains_k, sum s_k = 1."""
+    rank's witness MSMs, so the ranks that carry chains get fewer points: the split is the library's
+    (ug_groth16_balanced_witness_range, the one ULTRAGROTH_DEVICES uses inside the library), one source for both launch forms."""
     if world == 1 or info["domainSize"] % world:
         return None                              # even split (and no split H polynomial)
-    extra = [sum(CHAIN_SHARE[c] for c in range(3) if c % world == k) for k in range(world)]
-    base = (1.0 + sum(extra)) / world
-    shares = [max(base - e, 0.0) for e in extra]
-    tot = sum(shares)
-    n = info["nVars"]
-    cuts = [0]
-    for k in range(world):
-        cuts.append(n if k == world - 1 else min(n, int(round(n * sum(shares[:k + 1]) / tot))))
-    return cuts[rank], cuts[rank + 1]
+    import ultragroth_amd as ug
+    return ug.ShardedGroth16Prover.balanced_witness_range(info["nVars"], rank, world)
 
 
 def bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_rank):

@@ -174,6 +174,10 @@ int ug_groth16_prover_create_sharded_range(void **prover_object, const void *zke
  * first point of the ranges ug_groth16_shard_ranges reports: out[6] = {witness first, end, C first, end, H first, end}
  * (witness_range: two values as in _create_sharded_range, or NULL for the even split). slice_bytes = the byte counts of the
  * caller's points_a .. points_h buffers: a slice shorter than the rank's range is refused instead of read past its end. */
+/* The witness range [out[0], out[1]) a launcher should give rank `shard_rank` of `shard_count` so that the ranks finish
+ * together: ranks 0..2 also run an iFFT/twist/FFT chain each (ug_groth16_prover_hpoly_chain) and get fewer points. The ranges of
+ * all ranks tile [0, n_vars). (What ULTRAGROTH_DEVICES uses inside the library and bench.py between its processes.) */
+int ug_groth16_balanced_witness_range(unsigned long long n_vars, int shard_rank, int shard_count, unsigned long long out[2]);
 int ug_groth16_shard_ranges(unsigned long long n_vars, unsigned long long n_public, unsigned long long domain_size,
                             int shard_rank, int shard_count, const unsigned long long *witness_range,
                             unsigned long long out[6]);

@@ -177,6 +177,9 @@ int  ug_ctx_wait(ug_ctx* waiter, ug_ctx* signal);
 void ug_ctx_abandon(ug_ctx* ctx);
 /* Test hook, honoured only in processes started with ULTRAGROTH_TEST_HOOKS=1 (UG_ERROR otherwise): the `after`-th next call
  * that passes fault point `site` fails with "injected fault". Lets the tests take the error paths of a running proof. */
+/* diagnostic: the passes (return value, <= 4; -1 on bad arguments) the schedule sort makes for keys below 2^bits, with the
+ * bit offset and width of each pass's digit (csrc/sort.hip). Host arithmetic only. */
+int  ug_sort_plan(int bits, int shift[4], int bins_log[4]);
 #define UG_FAULT_HPOLY_RUN 1
 #define UG_FAULT_SCHEDULE_BUILD 2
 int  ug_test_inject_fault(int site, int after);

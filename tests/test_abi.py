@@ -167,3 +167,43 @@ def test_headers_are_plain_c(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip() == "810 2 invalid proof data 22"
+
+
+def test_sort_plan_covers_the_key_bits():
+    """csrc/sort.hip: ceil(bits / 8) passes, low bits first, digits of at most 8 bits that tile the key exactly, the narrow
+    ones first (the fused first pass has the smallest tiles)"""
+    import ctypes as C
+    from ultragroth_amd import _lib
+    L = _lib.load()
+    for bits in range(1, 33):
+        shift, width = (C.c_int * 4)(), (C.c_int * 4)()
+        passes = L.ug_sort_plan(bits, shift, width)
+        assert passes == (bits + 7) // 8
+        assert [shift[p] for p in range(passes)] == [sum(width[q] for q in range(p)) for p in range(passes)]
+        assert sum(width[p] for p in range(passes)) == bits and all(1 <= width[p] <= 8 for p in range(passes))
+        assert [width[p] for p in range(passes)] == sorted(width[p] for p in range(passes))
+    assert L.ug_sort_plan(0, (C.c_int * 4)(), (C.c_int * 4)()) == -1 and L.ug_sort_plan(33, (C.c_int * 4)(), (C.c_int * 4)()) == -1
+
+
+def test_balanced_witness_ranges_tile_the_witness():
+    """ug_groth16_balanced_witness_range (what ULTRAGROTH_DEVICES and bench.py split the witness-indexed sections by): the ranks'
+    ranges tile [0, nVars) in order for every rank count, ranks that run an NTT chain (0..2) get fewer points than the others,
+    and the C ranges that follow from them stay inside the C section"""
+    import ultragroth_amd as ug
+    for n_vars in (1, 2, 7, 1003, (1 << 20) - 1, (1 << 26) - 1):
+        for world in (1, 2, 3, 4, 5, 8, 16):
+            prev = 0
+            sizes = []
+            for k in range(world):
+                lo, hi = ug.ShardedGroth16Prover.balanced_witness_range(n_vars, k, world)
+                assert lo == prev and hi >= lo
+                prev = hi
+                sizes.append(hi - lo)
+                if n_vars >= 2:
+                    w, c, h = ug.ShardedGroth16Prover.shard_ranges(n_vars, 1, 1 << 10, k, world, (lo, hi))
+                    assert w == (lo, hi) and 0 <= c[0] <= c[1] <= n_vars - 2
+            assert prev == n_vars
+            if world > 3 and n_vars > 1000:
+                assert max(sizes[:3]) < min(sizes[3:])
+    with pytest.raises(ug.ProverError):
+        ug.ShardedGroth16Prover.balanced_witness_range(100, 3, 3)

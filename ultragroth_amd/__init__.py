@@ -350,6 +350,14 @@ class ShardedGroth16Prover:
         return self
 
     @staticmethod
+    def balanced_witness_range(n_vars, rank, world):
+        """ug_groth16_balanced_witness_range: the witness range of a rank when ranks 0..2 also run an NTT chain each"""
+        out = (C.c_ulonglong * 2)()
+        if load().ug_groth16_balanced_witness_range(n_vars, rank, world, out) != PROVER_OK:
+            raise ProverError(PROVER_ERROR, "invalid shard rank / count")
+        return out[0], out[1]
+
+    @staticmethod
     def shard_ranges(n_vars, n_public, domain, rank, world, witness_range=None):
         """((witness first, end), (C first, end), (H first, end)) of a rank"""
         out = (C.c_ulonglong * 6)()

@@ -20,7 +20,7 @@ INNER_SYMBOLS = [
     "ug_msm_g1", "ug_msm_g2", "ug_msm_batch", "ug_msm_batch_enqueue", "ug_ctx_collect", "ug_ctx_wait",
     "ug_hpoly_create", "ug_hpoly_run", "ug_hpoly_chain", "ug_hpoly_combine", "ug_hpoly_debug_abc", "ug_hpoly_destroy",
     "ug_fr_ntt", "ug_field_op", "ug_synth_points", "ug_ctx_timings", "ug_ctx_kernel_stats", "ug_ctx_abandon", "ug_test_inject_fault",
-    "ug_bases_create_group_g1", "ug_bases_members", "ug_msm_group_enqueue", "ug_dvec_device_ptr", "ug_dvec_copy",
+    "ug_bases_create_group_g1", "ug_bases_members", "ug_msm_group_enqueue", "ug_dvec_device_ptr", "ug_dvec_copy", "ug_sort_plan",
     "ug_bases_drop_tables", "ug_bases_table_window", "ug_schedule_trim", "ug_ctx_trim",
 ]
 VERIFIER_SYMBOLS = ["groth16_verify", "ultra_groth_verify"]        # include/verifier.h
@@ -38,7 +38,7 @@ OUTER_SYMBOLS = [
     "ug_registry_destroy",
     "ug_test_set_blinding", "ug_prover_last_timings", "ug_prover_kernel_stats", "ug_prover_last_upload_ms",
     "ug_groth16_prover_create_sharded", "ug_groth16_prover_create_sharded_range", "ug_groth16_prover_create_sharded_slices",
-    "ug_groth16_shard_ranges", "ug_groth16_prover_load_witness_part",
+    "ug_groth16_shard_ranges", "ug_groth16_balanced_witness_range", "ug_groth16_prover_load_witness_part",
     "ug_ultra_groth_prover_create_sharded", "ug_ultra_groth_prover_round_commit", "ug_ultra_groth_prover_round_finish",
     "ug_ultra_groth_prover_apply_commitment", "ug_g1_record_add",
     "ug_groth16_prover_load_witness", "ug_groth16_prover_run",
@@ -82,6 +82,7 @@ def load():
     L.ug_ctx_collect.argtypes = [vp]
     L.ug_dvec_device_ptr.argtypes = [vp]; L.ug_dvec_device_ptr.restype = vp
     L.ug_dvec_copy.argtypes = [vp, u64, vp, u64, u64]
+    L.ug_sort_plan.argtypes = [C.c_int, vp, vp]
     for n in ("ug_bases_create_g1", "ug_bases_create_g2"):
         getattr(L, n).argtypes = [vp, vp, u64, u64, pp]
     L.ug_bases_destroy.argtypes = [vp]; L.ug_bases_destroy.restype = None
@@ -162,6 +163,7 @@ def load():
     L.ug_groth16_prover_load_witness.argtypes = [vp, vp, ull, vp, ull]
     L.ug_groth16_prover_load_witness_part.argtypes = [vp, vp, ull, C.c_int, vp, ull]
     L.ug_groth16_shard_ranges.argtypes = [ull, ull, ull, C.c_int, C.c_int, vp, vp]
+    L.ug_groth16_balanced_witness_range.argtypes = [ull, C.c_int, C.c_int, vp]
     L.ug_groth16_prover_create_sharded_slices.argtypes = [pp, vp, ull, vp, ull, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, ull]
     L.ug_dvec_upload_range.argtypes = [vp, vp, u64, u64, vp]
     L.ug_fr_lookup_table.argtypes = [vp, vp, vp, u64, vp]

@@ -2109,6 +2109,14 @@ int ug_groth16_shard_ranges(unsigned long long n_vars, unsigned long long n_publ
     } catch (...) { return PROVER_ERROR; }
     return PROVER_OK;
 }
+int ug_groth16_balanced_witness_range(unsigned long long n_vars, int shard_rank, int shard_count, unsigned long long out[2]) {
+    try {
+        if (shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count || !out) return PROVER_ERROR;
+        const std::vector<Range> r = balancedWitnessRanges(n_vars, shard_count);
+        out[0] = r[shard_rank].lo; out[1] = r[shard_rank].hi;
+    } catch (...) { return PROVER_ERROR; }
+    return PROVER_OK;
+}
 int ug_groth16_prover_create_sharded_slices(void** prover_object, const void* zkey_header, unsigned long long zkey_header_size,
                                             const void* coefs, unsigned long long n_coefs, const void* points_a, const void* points_b1,
                                             const void* points_b2, const void* points_c, const void* points_h,

@@ -863,6 +863,11 @@ void ug_ctx_abandon(ug_ctx* c) {
     c->pending_msm.clear();
     try { resolve_spans(c); } catch (...) { c->spans_pending.clear(); }
 }
+// the pass plan of the schedule sort for keys below 2^bits (sort.hip: radix_plan): host arithmetic only, for the CPU test-suite
+int ug_sort_plan(int bits, int shift[4], int bins_log[4]) {
+    if (bits < 1 || bits > 32 || !shift || !bins_log) return -1;
+    return radix_plan(bits, shift, bins_log);
+}
 int ug_test_inject_fault(int site, int after) {
     if (!test_hooks_on()) return UG_ERROR;
     g_fault_after.store(after < 1 ? 1 : after);
