@@ -367,7 +367,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # UG_BENCH_FORCE_DIST=1: take the N > 1 code path with a process group of ONE rank (a one-GPU box can then execute the real
+    # RCCL calls of that path -- scatter, all_gather_into_tensor, all_reduce, barrier -- instead of none at all)
+    forced = world == 1 and os.environ.get("UG_BENCH_FORCE_DIST") == "1"
+    if forced:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29655")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or forced:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -379,7 +385,8 @@ def main():
     if args.ultra:
         return bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_rank)
     zkey = None
-    if world == 1:
+    single = dist is None                       # the one-GPU form: the reference's calls on one prover object
+    if single:
         zkey, wtns, info = synth.build_circuit(dev, log_domain, mix=args.mix, g1_only=args.g1_only)
         zkey_bytes = len(zkey)
         t0 = time.perf_counter()
@@ -434,9 +441,31 @@ def main():
 
     my_chains = [k for k in range(3) if k % world == rank] if split_h else []
 
+    # the 384-byte partial blocks of all ranks: ONE collective into one buffer and one copy back to the host (an EC addition is
+    # not an RCCL reduction operator, so the blocks are gathered and added on the host: 5 points per rank)
+    if dist is not None and backend == "nccl":
+        xmit = torch.empty(384, dtype=torch.uint8, device="cuda")
+        recv = torch.empty(384 * world, dtype=torch.uint8, device="cuda")
+        stage = torch.empty(384, dtype=torch.uint8).pin_memory()
+        landed = torch.empty(384 * world, dtype=torch.uint8).pin_memory()
+
+    def exchange_partials(part):
+        if backend == "nccl":
+            stage.copy_(torch.frombuffer(bytearray(part), dtype=torch.uint8))
+            xmit.copy_(stage, non_blocking=True)
+            dist.all_gather_into_tensor(recv, xmit)
+            landed.copy_(recv, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            raw = bytes(landed.numpy())
+            return [raw[384 * r:384 * (r + 1)] for r in range(world)]
+        mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)      # gloo rehearsal
+        allp = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        return [bytes(t.numpy()) for t in allp]
+
     def load():
         """the witness into HBM (outside the timed region: BASELINE contract -- inputs resident when the timed region starts)"""
-        if world == 1 or not split_h:
+        if single or not split_h:
             prover.load_witness(wtns)
             return
         prover.load_witness_part(wtns, 0)        # this rank's slice of the scalars: all its witness MSMs read
@@ -449,7 +478,7 @@ def main():
 
     def step():
         """one proof from the witness resident in HBM: S1-S13 of src/groth16.cpp:48-203"""
-        if world == 1:
+        if single:
             return prover.finish(prover.run())
         if split_h:
             th = None
@@ -468,14 +497,10 @@ def main():
             part = part[:320] + prover.run_h_msm()[320:384]
         else:                                    # the domain does not split evenly: every rank forms h itself
             part = prover.run()
-        mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)
-        if backend == "nccl":
-            mine = mine.cuda()
-        allp = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allp, mine)
-        total = bytes(allp[0].cpu().numpy())
-        for other in allp[1:]:
-            total = prover.add_partials(total, bytes(other.cpu().numpy()))
+        parts = exchange_partials(part)
+        total = parts[0]
+        for other in parts[1:]:
+            total = prover.add_partials(total, other)
         return prover.finish(total) if rank == 0 else None
 
     out = None
@@ -506,9 +531,9 @@ def main():
     # ---- extra figures (N = 1), outside the contract's region: the same K proofs through groth16_prover_prove with the .wtns
     # in HOST memory -- SURVEY.md section 8(d)'s "ms/proof": parse + PCIe copy + device + host -- one call after the other, and
     # from `--host-threads` threads on the one prover object (the witness copy of a call runs beside the kernels of the other)
-    host_threads = max(1, args.host_threads) if world == 1 else 1
+    host_threads = max(1, args.host_threads) if single else 1
     prove_call_ms = upload_ms = pipelined_s = None
-    if world == 1:
+    if single:
         prover.prove(wtns)
         t1 = time.perf_counter()
         upload_ms = 0.0
@@ -548,7 +573,7 @@ def main():
     if args.check:                              # one more step on EVERY rank (it contains collectives), fixed blinding
         ug.set_test_blinding(bytes(range(1, 32)) + bytes(range(31, 62)))
         chk = step()
-        if world == 1:                          # ... and once more through the reference's entry point, witness in host memory
+        if single:                              # ... and once more through the reference's entry point, witness in host memory
             ug.set_test_blinding(bytes(range(1, 32)) + bytes(range(31, 62)))
             if prover.prove(wtns) != chk:
                 chk = ("groth16_prover_prove differs from the phase calls", "")
@@ -600,7 +625,7 @@ def main():
                 continue
             for e in kern:
                 k = pmc.get(e["kernel"])
-                if k and e["traffic"] is None and world == 1 and args.mix == "U" and not args.g1_only:
+                if k and e["traffic"] is None and single and args.mix == "U" and not args.g1_only:
                     e["traffic"] = k["fetch"] + k["write"]
                     e["traffic_source"] = "profiles/%s (separate rocprofv3 --pmc passes on this workload; not measured in this run)" % name
         kern.sort(key=lambda e: -e["ms_per_step"])
@@ -629,7 +654,7 @@ def main():
                                       1 if args.g1_only else 2),
                        "log_domain": log_domain, "mix": args.mix, "overlap": bool(os.environ.get("ULTRAGROTH_OVERLAP", "0") not in ("", "0")),
                        "fused_g1_group": os.environ.get("ULTRAGROTH_FUSED", "1") != "0",
-                       "parallelism": "one GPU" if world == 1 else "base-range shard x%d%s" % (world, ", H-poly chains split over ranks" if split_h else "")},
+                       "parallelism": "one GPU" if single else "base-range shard x%d%s" % (world, ", H-poly chains split over ranks" if split_h else "")},
             "msm_ms_per_proof": msm_ms / args.steps, "fft_ms_per_proof": fft_ms / args.steps,
             "split_region": "device time of the MSM (S1-S4, S10) and FFT (S5-S9) parts of the K timed steps themselves",
             "comm": comm,

@@ -246,6 +246,25 @@ def test_bench_two_ranks_over_rccl():
         assert line["n_gpus"] == 2 and ("bit-exact" in (line.get("check") or line["config"]["workload"]))
 
 
+def test_bench_sharded_path_over_rccl_with_one_rank():
+    """A one-GPU box cannot host two RCCL ranks, but it can run the sharded code path of bench.py over a REAL RCCL process group
+    of one rank (UG_BENCH_FORCE_DIST=1): slices-only creation, the witness in two parts, the chains on their own thread, RCCL
+    scatter of the evaluation slices, all_gather_into_tensor of the partial blocks, all_reduce of the time, barrier -- the very
+    calls the driver's N = 2, 4, 8 runs make -- with --check bit-exact; `comm` shows what the communicator was"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UG_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--log-domain", "16",
+                        "--no-cpu-baseline", "--check"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["check"] == "bit-exact" and d["n_gpus"] == 1
+    assert d["comm"]["backend"] == "nccl" and d["comm"]["world_size"] == 1 and d["comm"]["rccl_version"]
+    assert "base-range shard x1, H-poly chains split over ranks" in d["config"]["parallelism"]
+    assert d["prove_call_ms_per_step"] is None and d["pipelined_proofs_per_s"] is None
+
+
 def test_bench_line_contract_one_gpu():
     """`python bench.py` as the driver runs it at N = 1 (here at 2^16 so that it takes seconds): exactly one JSON line
     with the contract's keys, the `roofline` and `cpu_baseline` objects; the K timed steps run one after the other on the
