@@ -532,6 +532,32 @@ def test_cli_and_api_on_several_devices(device, tmp_path, devices):
         del os.environ["ULTRAGROTH_DEVICES"]
 
 
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0,0"])
+def test_ultragroth_api_on_several_devices(device, devices):
+    """ULTRAGROTH_DEVICES for the UltraGroth entry points (src/prover.h:89-96,140-151): the round commitment's parts added on the
+    host, rank 0 closes the round, every rank derives the challenge and completes its witness, final round as the Groth16 phases;
+    == the oracle's proof, twice on one object, also after a refused witness"""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, uwtns, info = synth.build_ultra_circuit(device, 13)
+    rk, r, s = bytes(range(1, 32)), bytes(range(40, 71)), bytes(range(80, 111))
+    exp = O.ultra_groth_prove(zkey, uwtns, *(int.from_bytes(b, "little") for b in (rk, r, s)))
+    os.environ["ULTRAGROTH_DEVICES"] = devices
+    try:
+        with ug.UltraGrothProver(zkey) as p:
+            for k in range(3):
+                if k == 1:
+                    with pytest.raises(ug.ProverError):
+                        p.prove(uwtns[:-40])
+                ug.set_test_blinding(rk + r + s)
+                try:
+                    assert p.prove(uwtns) == exp
+                finally:
+                    ug.set_test_blinding(b"")
+    finally:
+        del os.environ["ULTRAGROTH_DEVICES"]
+
+
 @pytest.mark.parametrize("log_domain,n_public", [(2, 1), (3, 0), (5, 3), (7, 1), (10, 0)])
 def test_tiny_circuits_and_public_counts(device, log_domain, n_public):
     """smallest domains (single NTT pass, one segment, windows wider than the scalar count) and 0 / several public
