@@ -392,7 +392,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Cfg::ACC_WA
 // the gathers' latency is worth 9 %, but neither the rotation nor all K records of an entry fetched together by LDS-DMA
 // (global_load_lds_dwordx4 into a per-wave region, built and verified bit-exact, 43.8 against 43.5 ms, not kept) gets any of
 // it back: the limit is the latency of a random access into 36 GiB (translation + DRAM), one addition's time ahead is all a
-// lane can look with its registers full, and adjacent pieces do not make that access shorter.
+// lane can look with its registers full, and adjacent pieces do not make that access shorter. Touching the records two or three
+// turns ahead with one-dword LDS-DMA loads (no registers) makes the launch 9 % SLOWER (48.6 ms): vector-memory results retire in
+// order, so the real load behind a touch that misses waits for that miss -- the latency moves, it does not shrink.
 template <int K, bool ROTATE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void segment_accumulate_group_kernel(
         const u32* __restrict__ bases, u64 n_slots, int64_t delta, const u32* __restrict__ keys, const u32* __restrict__ tkeys,
