@@ -657,7 +657,9 @@ def main():
                        "fused_g1_group": os.environ.get("ULTRAGROTH_FUSED", "1") != "0",
                        "parallelism": "one GPU" if single else "base-range shard x%d%s" % (world, ", H-poly chains split over ranks" if split_h else "")},
             "msm_ms_per_proof": msm_ms / args.steps, "fft_ms_per_proof": fft_ms / args.steps,
-            "split_region": "device time of the MSM (S1-S4, S10) and FFT (S5-S9) parts of the K timed steps themselves",
+            "split_region": ("device time of the MSM (S1-S4, S10) and FFT (S5-S9) parts of the K timed steps themselves" if single else
+                             "stream time of rank 0's MSM and FFT parts over the K timed steps; its chains run on a second stream BESIDE "
+                             "its witness MSMs, so the two overlap and their sum exceeds the step"),
             "comm": comm,
             # outside the timed region (N = 1): the reference's call with the .wtns in host memory
             "prove_call_ms_per_step": prove_call_ms,
