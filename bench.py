@@ -480,7 +480,7 @@ def main():
     def step():
         """one proof from the witness resident in HBM: S1-S13 of src/groth16.cpp:48-203"""
         if single:
-            return prover.finish(prover.run())
+            return prover.prove_resident()       # ug_groth16_prover_prove_resident: groth16_prover_prove minus parse and copy
         if split_h:
             th = None
             if my_chains:                        # the H branch has its own stream inside the library: chains beside the MSMs

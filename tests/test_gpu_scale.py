@@ -813,6 +813,35 @@ def test_created_prover_at_2_20_bit_exact(device):
             assert got == (exp[0], exp[1]), "witness %d" % k
 
 
+def test_prove_resident_equals_prove(device, zkey, wtns):
+    """ug_groth16_prover_prove_resident (bench.py's timed step): the witness is loaded once, every call is a whole proof with
+    fresh blinding draws -- byte for byte what groth16_prover_prove returns for the same draws; refused before a witness is there"""
+    import ultragroth_amd as ug
+    r, s = fixed_rs()
+    exp = O.groth16_prove(zkey, wtns, int.from_bytes(r, "little"), int.from_bytes(s, "little"))[:2]
+    with ug.Groth16Prover(zkey) as p:
+        with pytest.raises(ug.ProverError, match="no witness loaded"):
+            p.prove_resident()
+        p.load_witness(wtns)
+        for _ in range(3):
+            ug.set_test_blinding(r + s)
+            try:
+                assert p.prove_resident() == exp
+            finally:
+                ug.set_test_blinding(b"")
+        a, b = p.prove_resident(), p.prove_resident()              # OS entropy: two different, valid-looking proofs of one witness
+        assert a != b and a[1] == exp[1]
+        with pytest.raises(ug.ProverError) as e:
+            p.prove_resident  # noqa: B018
+            L = ug.load()
+            import ctypes as C
+            psz, qsz = C.c_ulonglong(10), C.c_ulonglong(4096)
+            err = C.create_string_buffer(256)
+            rc = L.ug_groth16_prover_prove_resident(p._h, C.create_string_buffer(10), C.byref(psz), C.create_string_buffer(4096), C.byref(qsz), err, 255)
+            raise ug.ProverError(rc, err.value.decode())
+        assert e.value.code == ug.PROVER_ERROR_SHORT_BUFFER
+
+
 def test_overlap_mode_is_bit_exact(device, monkeypatch):
     """ULTRAGROTH_OVERLAP=1: the H branch (mat-vec, NTT chains, h schedule, H MSM) runs on a second stream from a second
     host thread beside the witness MSMs; same proof, also with tables forced for a one-shot call (ULTRAGROTH_TABLES=2)"""

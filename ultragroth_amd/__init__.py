@@ -161,6 +161,18 @@ class _ProverBase:
         if rc != PROVER_OK:
             raise ProverError(rc, err.value.decode(errors="replace"))
 
+    def prove_resident(self):
+        """ug_groth16_prover_prove_resident: one whole proof of the witness load_witness left in HBM"""
+        psz = C.c_ulonglong(self._proof_size())
+        qsz = C.c_ulonglong(self._public_size)
+        proof = C.create_string_buffer(psz.value)
+        pub = C.create_string_buffer(max(qsz.value, 1))
+        err = C.create_string_buffer(1024)
+        rc = load().ug_groth16_prover_prove_resident(self._h, proof, C.byref(psz), pub, C.byref(qsz), err, len(err) - 1)
+        if rc != PROVER_OK:
+            raise ProverError(rc, err.value.decode(errors="replace"))
+        return proof.raw.split(b"\0", 1)[0].decode(), pub.raw.split(b"\0", 1)[0].decode()
+
     def run(self):
         out = C.create_string_buffer(GROTH16_PARTIALS_SIZE)
         err = C.create_string_buffer(1024)

@@ -41,7 +41,7 @@ OUTER_SYMBOLS = [
     "ug_groth16_shard_ranges", "ug_groth16_balanced_witness_range", "ug_groth16_prover_load_witness_part",
     "ug_ultra_groth_prover_create_sharded", "ug_ultra_groth_prover_round_commit", "ug_ultra_groth_prover_round_finish",
     "ug_ultra_groth_prover_apply_commitment", "ug_g1_record_add",
-    "ug_groth16_prover_load_witness", "ug_groth16_prover_run",
+    "ug_groth16_prover_load_witness", "ug_groth16_prover_run", "ug_groth16_prover_prove_resident",
     "ug_groth16_partials_add", "ug_groth16_prover_finish",
     "ug_groth16_prover_run_witness_msm", "ug_groth16_prover_run_h_msm", "ug_groth16_prover_hpoly_chain",
     "ug_groth16_prover_hpoly_combine", "ug_groth16_prover_h_range",
@@ -168,6 +168,7 @@ def load():
     L.ug_dvec_upload_range.argtypes = [vp, vp, u64, u64, vp]
     L.ug_fr_lookup_table.argtypes = [vp, vp, vp, u64, vp]
     L.ug_groth16_prover_run.argtypes = [vp, vp, vp, ull]
+    L.ug_groth16_prover_prove_resident.argtypes = [vp, vp, pull, vp, pull, vp, ull]
     L.ug_groth16_partials_add.argtypes = [vp, vp]
     L.ug_groth16_prover_run_witness_msm.argtypes = [vp, vp, vp, ull]
     L.ug_groth16_prover_run_h_msm.argtypes = [vp, vp, vp, ull]

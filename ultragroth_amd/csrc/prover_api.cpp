@@ -481,6 +481,7 @@ struct ProverBase {        // what the extern "C" layer stores behind the opaque
     virtual void hpolyCombine(void*, void*, void*) { noPhase(); }
     virtual void hRange(unsigned long long*, unsigned long long*, unsigned long long*) const { noPhase(); }
     virtual void finish(const uint8_t*, std::string&, std::string&) { noPhase(); }
+    virtual void proveResident(std::string&, std::string&) { noPhase(); }
     virtual void roundCommit(uint8_t*) { noPhase(); }
     virtual void roundFinish(const uint8_t*, uint8_t*) { noPhase(); }
     virtual void applyCommitment(const uint8_t*) { noPhase(); }
@@ -936,6 +937,13 @@ public:
     // (every caller comes through proveTurn, which this class overrides; kept for the interface)
     void prove(const void* wtns, unsigned long long wtnsSize, std::string& proof, std::string& pub) override {
         proveTurn(wtns, wtnsSize, proof, pub, nullptr, Around());
+    }
+    // one whole proof (S1-S13) of the witness that is already resident (loadWitness): what prove does after its staging --
+    // r and s drawn first, the multiples that need only them formed on host threads beside the device work
+    void proveResident(std::string& proof, std::string& pub) override {
+        std::lock_guard<std::mutex> turn(proveMutex);
+        if (!witnessLoaded_ || !witnessComplete_) throw std::invalid_argument("no witness loaded");
+        proveLoaded(proof, pub);
     }
     // deviceDone (optional) is called once the device part has left the device: nothing after it touches the prover's
     // per-proof state (the public signals are copied first), so the caller may give up its turn there
@@ -2153,6 +2161,20 @@ int ug_groth16_prover_load_witness(void* prover_object, const void* wtns_buffer,
     if (prover_object == NULL) throw std::invalid_argument("Null prover object");
     if (wtns_buffer == NULL) throw std::invalid_argument("Null witness buffer");
     static_cast<ProverBase*>(prover_object)->loadWitness(wtns_buffer, wtns_size);
+    API_CATCH
+}
+int ug_groth16_prover_prove_resident(void* prover_object, char* proof_buffer, unsigned long long* proof_size, char* public_buffer,
+                                     unsigned long long* public_size, char* error_msg, unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL) throw std::invalid_argument("Null prover object");
+    if (!proof_buffer || !proof_size || !public_buffer || !public_size) throw std::invalid_argument("Null buffer");
+    ProverBase* prover = static_cast<ProverBase*>(prover_object);
+    checkBufferSizes(prover->proofBufferMinSize(), proof_size, prover->publicBufferMinSize(), public_size, "Minimum");
+    std::string stringProof, stringPublic;
+    prover->proveResident(stringProof, stringPublic);
+    checkBufferSizes(stringProof.length(), proof_size, stringPublic.length(), public_size, "Required");
+    std::strncpy(proof_buffer, stringProof.c_str(), *proof_size);
+    std::strncpy(public_buffer, stringPublic.c_str(), *public_size);
     API_CATCH
 }
 int ug_groth16_prover_run(void* prover_object, void* partials_out, char* error_msg, unsigned long long error_msg_maxsize) {
