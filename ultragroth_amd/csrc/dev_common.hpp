@@ -28,23 +28,6 @@ __device__ __forceinline__ void load8(u32* w, const u32* p) {
     w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
     w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
 }
-// The same for data that is read exactly ONCE per launch (the base records an MSM gathers: 12 - 36 GiB of tables per product):
-// non-temporal loads, so that the stream does not push the lines a kernel re-uses -- scratch of the G2 accumulation, bucket and
-// slot records, the entry list -- out of L2. UG_NT_GATHER=0 at build time gives plain loads (A/B).
-#ifndef UG_NT_GATHER
-#define UG_NT_GATHER 1
-#endif
-__device__ __forceinline__ void load8_stream(u32* w, const u32* p) {
-#if UG_NT_GATHER
-    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4* q = reinterpret_cast<const u32x4*>(p);
-    const u32x4 a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1);
-    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
-    w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-#else
-    load8(w, p);
-#endif
-}
 __device__ __forceinline__ void store8(u32* p, const u32* w) {
     uint4* q = reinterpret_cast<uint4*>(p);
     q[0] = make_uint4(w[0], w[1], w[2], w[3]);

@@ -70,8 +70,6 @@ struct G1Cfg {
         return true;
     }
     static __device__ __forceinline__ void load_raw(u32* w, const u32* p) { load8(w, p); load8(w + 8, p + 8); }
-    // (non-temporal gathers were measured for G1 and make it slower: the 64-byte pieces of a group record share 128-byte lines)
-    static __device__ __forceinline__ bool load_affine_stream(const u32* p, F& x, F& y, bool) { return load_affine(p, x, y); }
     static __host__ __device__ __forceinline__ void store_affine_mont256(u32* o, const F& x, const F& y) {
         to_mont256(o, x); to_mont256(o + 8, y);
     }
@@ -121,14 +119,6 @@ struct G2Cfg {
     }
     static __device__ __forceinline__ void load_raw(u32* w, const u32* p) {
         load8(w, p); load8(w + 8, p + 8); load8(w + 16, p + 16); load8(w + 24, p + 24);
-    }
-    // the accumulation's gather: a whole 128-byte line that is read once per launch -- non-temporal (nt), so that the stream of
-    // 24 GiB of table records does not push the kernel's scratch spills out of L2
-    static __device__ __forceinline__ bool load_affine_stream(const u32* p, F& x, F& y, bool nt) {
-        if (!nt) return load_affine(p, x, y);
-        u32 w[32];
-        load8_stream(w, p); load8_stream(w + 8, p + 8); load8_stream(w + 16, p + 16); load8_stream(w + 24, p + 24);
-        return decode_affine(w, x, y);
     }
     static __host__ __device__ __forceinline__ void store_affine_mont256(u32* o, const F& x, const F& y) {
         to_mont256(o, x.a); to_mont256(o + 8, x.b); to_mont256(o + 16, y.a); to_mont256(o + 24, y.b);
@@ -317,7 +307,7 @@ template <class Cfg>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Cfg::ACC_WAVES, Cfg::ACC_WAVES))) void segment_accumulate_kernel(const u32* __restrict__ bases, u64 n_bases, int64_t delta,
                                                                  const u32* __restrict__ keys, const u32* __restrict__ tkeys,
                                                                  const u32* __restrict__ tvals, const u32* __restrict__ meta, int log_a, int log_b,
-                                                                 u32* __restrict__ bucket_pts, u32* __restrict__ slot_pts, int nt) {
+                                                                 u32* __restrict__ bucket_pts, u32* __restrict__ slot_pts) {
     typedef typename Cfg::F F;
     const u32 n_valid = meta[1];
     const SegMap map = SegMap::make(n_valid, log_a, log_b);
@@ -370,7 +360,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Cfg::ACC_WA
             const int64_t idx = (int64_t)(val & IDX_MASK) + delta;
             F x, y;
             bool valid = idx >= 0 && (u64)idx < n_bases &&
-                         Cfg::load_affine_stream(bases + ((u64)((val >> TABLE_INDEX_BITS) & 15u) * n_bases + (u64)idx) * Cfg::AFF_WORDS, x, y, nt != 0);
+                         Cfg::load_affine(bases + ((u64)((val >> TABLE_INDEX_BITS) & 15u) * n_bases + (u64)idx) * Cfg::AFF_WORDS, x, y);
             if (valid && (val >> 31)) y = neg<1>(y);
             if (key != cur) close_run(key);
             if (valid) acc = xyzz_madd(acc, x, y);
@@ -1040,15 +1030,13 @@ void msm_enqueue_multi(const MsmSchedule& s, MsmWorkspace& ws, int count, const 
             if (stats) stats->end(slot, stream);
         }
     } else if (group) throw std::logic_error("msm: groups are G1 only");
-    const char* nte = getenv("UG_NT_GATHER");                  // A/B knob (G2 only): 0 = plain loads for the table records
-    const int nt_gather = (Cfg::PT_WORDS == G2Cfg::PT_WORDS && !(nte && atoi(nte) == 0)) ? 1 : 0;
     for (int q = 0; q < (group ? 0 : k); q++) {
         const int j = live[q];
         int slot = stats ? stats->begin(stream, g.n * g.windows) : -1;
         if (nseg) {
             hipLaunchKernelGGL(segment_accumulate_kernel<Cfg>, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, stream,
                                bases[j], n_bases[j], delta[j], s.keys, s.tkeys, s.tvals, s.meta, s.log_seg, s.log_seg_tail,
-                               ws.bucket_pts + q * bucket_stride, ws.slot_pts + q * slot_stride, nt_gather);
+                               ws.bucket_pts + q * bucket_stride, ws.slot_pts + q * slot_stride);
             UG_KERNEL_CHECK();
         }
         if (stats) stats->end(slot, stream);
