@@ -536,7 +536,10 @@ public:
 
     // witnessRange: the slice of the witness-indexed sets (A, B1, B2, C) this rank owns, when the caller balances the
     // ranks itself (ug_groth16_prover_create_sharded_range); nullptr = the even split
-    Groth16Prover(const void* zkey, unsigned long long zkeySize, int device, int rank, int count, const Range* witnessRange = nullptr)
+    // runsChain = false: this rank will never be asked for an H-polynomial chain (hpolyChain / run), so it keeps no coefficient
+    // matrix, twiddles or NTT vectors (ranks 3 and up of a many-device prover)
+    Groth16Prover(const void* zkey, unsigned long long zkeySize, int device, int rank, int count, const Range* witnessRange = nullptr,
+                  bool runsChain = true)
         : rank_(rank), count_(count) {
         if (count < 1 || rank < 0 || rank >= count) throw std::invalid_argument("invalid shard rank / count");
         BinFile f(zkey, zkeySize, "zkey", 1);
@@ -552,6 +555,7 @@ public:
         src.pB2 = checkedSection(f, 7, M * 128);
         src.pC = checkedSection(f, 8, nC * 64);
         src.pH = checkedSection(f, 9, N * 64);
+        src.haveCoefs = runsChain;
         init(src, device, witnessRange);
     }
     // from the header section and this rank's slices (ug_groth16_prover_create_sharded_slices)
@@ -1423,7 +1427,7 @@ public:
         for (int k = 0; k < R; k++)
             jobs.push_back(std::async(std::launch::async, [&, k, oneShot] {
                 g_oneShotProver = oneShot;
-                ranks_[k].reset(new Groth16Prover(zkey, zkeySize, devices[k], k, R, &wr[k]));
+                ranks_[k].reset(new Groth16Prover(zkey, zkeySize, devices[k], k, R, &wr[k], /*runsChain*/ k < 3));
             }));
         std::exception_ptr failure;
         for (auto& j : jobs) { try { j.get(); } catch (...) { if (!failure) failure = std::current_exception(); } }
