@@ -477,11 +477,23 @@ def main():
         for k in my_chains:
             prover.hpoly_chain(k, fulls[k].data_ptr())
 
+    # the collectives of a step run on a stream of their own: torch's default stream is the legacy null stream, and nothing of
+    # the step should be ordered against it
+    comm_stream = torch.cuda.Stream() if (split_h and backend == "nccl") else None
+    sequential_phases = os.environ.get("UG_BENCH_PHASES") == "sequential"       # A/B: the blocking phase calls of rounds 1-3
+    # Where a chain rank starts its chain (measured, tools/run_r3_order.sh, rank 0 of 8 at 2^24: the stream priority class has no
+    # effect on this stack -- a chain queued beside the witness products gets ~40 % of the chip and takes 17 ms instead of 7 --
+    # so on a node where most ranks WAIT for the chains, the chain ranks run theirs first, alone, and queue their products
+    # behind; with few ranks (long products, every rank busy anyway) the chain runs beside the products, which gains what a
+    # memory-bound kernel gains beside an issue-bound one). UG_BENCH_CHAIN_ORDER = first | beside | auto (first from 5 ranks on).
+    chain_order = os.environ.get("UG_BENCH_CHAIN_ORDER", "auto")
+    chain_first = chain_order == "first" or (chain_order == "auto" and world >= 5)
+
     def step():
         """one proof from the witness resident in HBM: S1-S13 of src/groth16.cpp:48-203"""
         if single:
             return prover.prove_resident()       # ug_groth16_prover_prove_resident: groth16_prover_prove minus parse and copy
-        if split_h:
+        if split_h and sequential_phases:
             th = None
             if my_chains:                        # the H branch has its own stream inside the library: chains beside the MSMs
                 th = threading.Thread(target=run_chains)
@@ -496,6 +508,30 @@ def main():
             torch.cuda.synchronize()
             prover.hpoly_combine(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr())
             part = part[:320] + prover.run_h_msm()[320:384]
+        elif split_h:
+            # ONE host thread, both streams of the rank busy: the witness products are queued and left to run; the H branch --
+            # this rank's chains, the slice exchange, combine, the H product, all on the library's second (high-priority)
+            # stream and torch's collectives -- is driven meanwhile, so the ranks that wait for a chain rank's evaluation
+            # vectors spend that time on their witness products, and the H product's latency-bound tail runs beside them
+            if chain_first:
+                run_chains()                     # (returns when this rank's evaluation vectors are complete)
+                prover.witness_msm_begin()
+            else:
+                prover.witness_msm_begin()
+                run_chains()
+            if comm_stream is not None:
+                with torch.cuda.stream(comm_stream):
+                    works = [scatter_slices(bufs[k], fulls.get(k), k % world) for k in range(3)]
+                    for wk in works:
+                        wk.wait()
+                comm_stream.synchronize()        # the slices are here; the witness stream is NOT waited for
+            else:                                # (gloo rehearsal: through host memory, on torch's current stream)
+                for k in range(3):
+                    scatter_slices(bufs[k], fulls.get(k), k % world)
+                torch.cuda.current_stream().synchronize()
+            prover.hpoly_combine(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr())
+            hpart = prover.run_h_msm()
+            part = prover.witness_msm_end()[:320] + hpart[320:384]
         else:                                    # the domain does not split evenly: every rank forms h itself
             part = prover.run()
         parts = exchange_partials(part)

@@ -60,6 +60,9 @@ const char* ug_last_error(void);
 int ug_device_count(void);
 
 int  ug_ctx_create(ug_ctx** ctx, int device);
+/* The same with a stream priority class: +1 = the device's highest, 0 = normal, -1 = its lowest (a tuning knob: on MI355X /
+ * ROCm 7.2 two compute streams of different classes were measured to share the chip exactly as two of the same class do). */
+int  ug_ctx_create_priority(ug_ctx** ctx, int device, int priority_class);
 void ug_ctx_destroy(ug_ctx* ctx);
 /* block until all work queued on the context's stream has finished */
 int  ug_ctx_sync(ug_ctx* ctx);

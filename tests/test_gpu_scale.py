@@ -174,6 +174,56 @@ def test_sharded_prover_with_split_hpoly(device):
         p.close()
 
 
+def test_witness_products_queued_beside_the_h_branch(device):
+    """ug_groth16_prover_witness_msm_begin / _end (what bench.py and the many-device prover do since round 3): the witness
+    products of every rank are queued and left to run while the rank's H branch -- chain, combine, H product, on its second
+    stream -- is driven from the same host thread; rank 0 draws r and s in _begin. Byte for byte the oracle's proof; the call
+    order is checked (begin twice, end without begin, a witness load between the two)."""
+    import torch
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, wtns, info = synth.build_circuit(device, 13, mix="U", seed=0x5EED0077)
+    world, n_dom = 3, info["domainSize"]
+    ranks = [ug.ShardedGroth16Prover(zkey, 0, k, world) for k in range(world)]
+    with pytest.raises(ug.ProverError, match="no witness loaded"):
+        ranks[0].witness_msm_begin()
+    for p in ranks:
+        p.load_witness(wtns)
+    with pytest.raises(ug.ProverError, match="no witness products queued"):
+        ranks[1].witness_msm_end()
+    r_, s_ = fixed_rs()
+    full = torch.empty((3, n_dom, 32), dtype=torch.uint8, device="cuda")
+    for turn in range(2):                                    # twice on the same objects
+        ug.set_test_blinding(r_ + s_)
+        try:
+            for p in ranks:
+                p.witness_msm_begin()                        # rank 0 draws here
+            with pytest.raises(ug.ProverError, match="already queued"):
+                ranks[2].witness_msm_begin()
+            with pytest.raises(ug.ProverError, match="still read the witness"):
+                ranks[1].load_witness_part(wtns, 0)
+            for k in range(3):
+                ranks[k].hpoly_chain(k, full[k].data_ptr())
+            total = None
+            for r, p in enumerate(ranks):
+                first, cnt, _ = p.h_range()
+                bufs = [full[k, first:first + cnt].contiguous() for k in range(3)]
+                torch.cuda.synchronize()
+                p.hpoly_combine(*(b.data_ptr() for b in bufs))
+                hpart = p.run_h_msm()
+                part = p.witness_msm_end()[:320] + hpart[320:384]
+                total = part if total is None else ug.ShardedGroth16Prover.add_partials(total, part)
+            got = ranks[0].finish(total)
+        finally:
+            ug.set_test_blinding(b"")
+        exp = O.groth16_prove(zkey, wtns, int.from_bytes(r_, "little"), int.from_bytes(s_, "little"))
+        assert got == (exp[0], exp[1])
+    # the blocking form on the same objects still gives the same sums
+    assert ranks[1].run_witness_msm()[:320] == (lambda p: (p.witness_msm_begin(), p.witness_msm_end())[1])(ranks[1])[:320]
+    for p in ranks:
+        p.close()
+
+
 def test_sharded_prover_from_slices_and_witness_parts(device):
     """what bench.py does with N > 1 ranks: every rank is created from ITS slices of the point sections only
     (ug_groth16_prover_create_sharded_slices; the slices are the same generator walk entered at the slice), ranks beyond

@@ -31,7 +31,10 @@ print("rank %d of %d at 2^%d: witness slice %s (%d points), chains %s, create %.
 del coefs, slices
 sl = domain // world
 full = torch.empty((domain, 32), dtype=torch.uint8, device="cuda")
-bufs = torch.zeros((3, sl, 32), dtype=torch.uint8, device="cuda")
+# (random slices, top byte small: h = a.b - c is then a vector of full-size scalars, as in a real proof -- with zeros the H
+# product has no entries and takes no time)
+bufs = torch.randint(0, 256, (3, sl, 32), dtype=torch.uint8, device="cuda")
+bufs[:, :, 31] &= 0x0f
 
 
 def timed(name, fn, acc):
@@ -56,3 +59,58 @@ for it in range(3):
     total = part[:320] + hp[320:384]
     timed("finish", lambda: p.finish(total), acc)
 print("  ".join("%s %.2f" % kv for kv in acc.items()), " | sum %.2f ms" % sum(acc.values()))
+
+# The same rank driven as bench.py drives it since round 3: the witness products queued (witness_msm_begin), the H branch on the
+# second stream meanwhile, one host thread. A rank without a chain waits `wait_ms` for the chain ranks' evaluation vectors
+# (their chain + the scatter: argument 4, default 9 ms) -- on its witness products, which is the point.
+wait_ms = float(sys.argv[4]) if len(sys.argv) > 4 else 9.0
+# argument 5: where a chain rank starts its chain -- "products_first" (queued behind nothing, beside the products), "chain_first"
+# (the chain alone, then the products), "chain_thread" (queued half a millisecond BEFORE the products, from a second thread)
+order = sys.argv[5] if len(sys.argv) > 5 else "products_first"
+import threading
+
+
+def run_my_chains():
+    for k in chains:
+        p.hpoly_chain(k, full.data_ptr())
+
+
+p.load_witness_part(wtns, 0)
+if chains:
+    p.load_witness_part(wtns, 1)
+walls = []
+for it in range(4):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    if order == "chain_first":
+        run_my_chains()
+        t_chain = time.perf_counter()
+        p.witness_msm_begin()
+        t_begin = time.perf_counter()
+    elif order == "chain_thread" and chains:
+        th = threading.Thread(target=run_my_chains)
+        th.start()
+        time.sleep(0.0005)
+        p.witness_msm_begin()
+        t_begin = time.perf_counter()
+        th.join()
+        t_chain = time.perf_counter()
+    else:
+        p.witness_msm_begin()
+        t_begin = time.perf_counter()
+        run_my_chains()
+        t_chain = time.perf_counter()
+    if not chains:
+        time.sleep(max(0.0, wait_ms * 1e-3 - (time.perf_counter() - t)))
+    p.hpoly_combine(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr())
+    hp = p.run_h_msm()
+    t_h = time.perf_counter()
+    part = p.witness_msm_end()
+    t_end = time.perf_counter()
+    p.finish(part[:320] + hp[320:384])
+    t_fin = time.perf_counter()
+    walls.append([1e3 * (x - t) for x in (t_begin, t_chain, t_h, t_end, t_fin)])
+w = walls[-1]
+print("order %s, ULTRAGROTH_H_PRIORITY %s" % (order, os.environ.get("ULTRAGROTH_H_PRIORITY", "(default: high)")))
+print("queued form (ms after the start of the step): products queued %.2f  chains done %.2f  H product done %.2f  witness products done %.2f  "
+      "finish %.2f   | wall of the last three steps %s" % (w[0], w[1], w[2], w[3], w[4], " ".join("%.2f" % x[4] for x in walls[1:])))

@@ -403,7 +403,7 @@ class ShardedGroth16Prover:
     def _phase(self, name, *args):
         out = C.create_string_buffer(GROTH16_PARTIALS_SIZE)
         err = C.create_string_buffer(1024)
-        rc = getattr(load(), name)(self._h, *args, *([out] if name.endswith("_msm") else []), err, len(err) - 1)
+        rc = getattr(load(), name)(self._h, *args, *([out] if name.endswith(("_msm", "_msm_end")) else []), err, len(err) - 1)
         if rc != PROVER_OK:
             raise ProverError(rc, err.value.decode(errors="replace"))
         return out.raw
@@ -411,6 +411,15 @@ class ShardedGroth16Prover:
     def run_witness_msm(self):
         """A, B1, B2, C partial sums of this rank (H record at infinity)"""
         return self._phase("ug_groth16_prover_run_witness_msm")
+
+    def witness_msm_begin(self):
+        """run_witness_msm without the wait: the four products are queued on the witness stream; drive the H branch (hpoly_chain,
+        the slice exchange, hpoly_combine, run_h_msm) from this thread meanwhile, then witness_msm_end()"""
+        self._phase("ug_groth16_prover_witness_msm_begin")
+
+    def witness_msm_end(self):
+        """the partial sums of the products witness_msm_begin queued (waits for them)"""
+        return self._phase("ug_groth16_prover_witness_msm_end")
 
     def run_h_msm(self):
         """H partial sum of this rank from the h slice on the device (other records at infinity)"""

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_CSRC, "libultragroth_hip.so")
 
 # every symbol that include/ultragroth_hip.h and include/prover.h declare
 INNER_SYMBOLS = [
-    "ug_last_error", "ug_device_count", "ug_ctx_create", "ug_ctx_destroy", "ug_ctx_sync",
+    "ug_last_error", "ug_device_count", "ug_ctx_create", "ug_ctx_create_priority", "ug_ctx_destroy", "ug_ctx_sync",
     "ug_bases_create_g1", "ug_bases_create_g2", "ug_bases_create_tables_g1", "ug_bases_create_tables_g2", "ug_bases_destroy",
     "ug_msm_table_window", "ug_bases_tables_bytes", "ug_bases_precompute", "ug_ctx_mem_info", "ug_schedule_build_tables",
     "ug_dvec_create", "ug_dvec_upload", "ug_dvec_upload_range", "ug_dvec_upload_idle", "ug_dvec_download", "ug_dvec_gather", "ug_dvec_scatter", "ug_dvec_apply_lookup", "ug_fr_lookup_table", "ug_index_create", "ug_index_destroy", "ug_dvec_gather_index", "ug_dvec_wrap", "ug_dvec_size", "ug_dvec_destroy",
@@ -45,6 +45,7 @@ OUTER_SYMBOLS = [
     "ug_groth16_partials_add", "ug_groth16_prover_finish",
     "ug_groth16_prover_run_witness_msm", "ug_groth16_prover_run_h_msm", "ug_groth16_prover_hpoly_chain",
     "ug_groth16_prover_hpoly_combine", "ug_groth16_prover_h_range",
+    "ug_groth16_prover_witness_msm_begin", "ug_groth16_prover_witness_msm_end",
 ]
 
 
@@ -72,6 +73,7 @@ def load():
     L.ug_last_error.restype = C.c_char_p
     L.ug_device_count.restype = C.c_int
     L.ug_ctx_create.argtypes = [pp, C.c_int]
+    L.ug_ctx_create_priority.argtypes = [pp, C.c_int, C.c_int]
     L.ug_ctx_destroy.argtypes = [vp]; L.ug_ctx_destroy.restype = None
     L.ug_ctx_sync.argtypes = [vp]
     L.ug_ctx_abandon.argtypes = [vp]; L.ug_ctx_abandon.restype = None
@@ -172,6 +174,8 @@ def load():
     L.ug_groth16_partials_add.argtypes = [vp, vp]
     L.ug_groth16_prover_run_witness_msm.argtypes = [vp, vp, vp, ull]
     L.ug_groth16_prover_run_h_msm.argtypes = [vp, vp, vp, ull]
+    L.ug_groth16_prover_witness_msm_begin.argtypes = [vp, vp, ull]
+    L.ug_groth16_prover_witness_msm_end.argtypes = [vp, vp, vp, ull]
     L.ug_groth16_prover_hpoly_chain.argtypes = [vp, C.c_int, vp, vp, ull]
     L.ug_groth16_prover_hpoly_combine.argtypes = [vp, vp, vp, vp, vp, ull]
     L.ug_groth16_prover_h_range.argtypes = [vp, pull, pull, pull]

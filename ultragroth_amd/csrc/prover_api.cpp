@@ -476,6 +476,8 @@ struct ProverBase {        // what the extern "C" layer stores behind the opaque
     virtual void loadWitnessPart(const void*, unsigned long long, int) { noPhase(); }
     virtual void run(uint8_t*) { noPhase(); }
     virtual void runWitnessMsm(uint8_t*, bool = true) { noPhase(); }
+    virtual void witnessMsmBegin() { noPhase(); }
+    virtual void witnessMsmEnd(uint8_t*) { noPhase(); }
     virtual void runHMsm(uint8_t*) { noPhase(); }
     virtual void hpolyChain(int, void*) { noPhase(); }
     virtual void hpolyCombine(void*, void*, void*) { noPhase(); }
@@ -613,8 +615,17 @@ private:
         }
 
         ugCheck(ug_ctx_create(&d_.ctx, device));
-        // the H branch (coefficient mat-vec, NTT chains, h schedule, H MSM) gets its own stream
-        ugCheck(ug_ctx_create(&d_.ctx2, device));
+        // the H branch (coefficient mat-vec, NTT chains, h schedule, H MSM) gets its own stream. ULTRAGROTH_H_PRIORITY = h | n | l
+        // gives it a stream priority class (ug_ctx_create_priority). Measured on MI355X / ROCm 7.2 (tools/run_r3_order.sh, rank 0 of
+        // an 8-way shard at 2^24): the class changes NOTHING -- a chain queued beside the witness products takes 17.4 ms with the
+        // high class and 17.2 ms with the normal one (7.1 ms alone): workgroups of both streams take the slots that retiring
+        // workgroups free in turn. So the default stays normal, and the ORDER of the calls decides who runs first
+        // (MultiGroth16Prover::prove, bench.py).
+        {
+            const char* pe = getenv("ULTRAGROTH_H_PRIORITY");
+            const int cls = pe ? (pe[0] == 'h' ? 1 : pe[0] == 'l' ? -1 : 0) : 0;
+            ugCheck(ug_ctx_create_priority(&d_.ctx2, device, cls));
+        }
         if (const char* mr = getenv("ULTRAGROTH_MAX_RANGE")) {
             uint64_t v = strtoull(mr, nullptr, 10);
             if (v >= 1 && v < MAX_RANGE) maxRange_ = v;
@@ -776,6 +787,8 @@ public:
                                                 ", witness: " + std::to_string(wh.nVars));
         if (!wh.primeIsBn254) throw std::invalid_argument("different wtns curve");
         const uint8_t* data = checkedSection(f, 2, (uint64_t)hdr_.nVars * 32);
+        if (part == 0 && witnessQueued_ == 1)      // (part 1 lies outside the range the queued products read, and goes to the other stream)
+            throw std::invalid_argument("the queued witness products still read the witness (ug_groth16_prover_witness_msm_end)");
         if (part == 0) {
             resetTimings();
             publicPart_.assign(data, data + ((size_t)hdr_.nPublic + 1) * 32);
@@ -810,6 +823,50 @@ public:
         }
         inFlight.done();
         if (standalone) collectTimings(1);
+    }
+    // The same in two calls (ug_groth16_prover_witness_msm_begin / _end): begin queues S1-S4 on the witness stream and returns
+    // without a host wait, so that the caller drives this rank's H branch -- its chains, the exchange of the evaluation slices
+    // with the other ranks, hpolyCombine, runHMsm: all on the second stream -- while the products run; end waits for them.
+    // Rank 0 also draws r and s here (S11, still r then s, before the device work as in proveLoaded) and forms the multiples
+    // that need only them on host threads beside the device; finish() then takes those.
+    void witnessMsmBegin() override {
+        if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
+        if (witnessQueued_) throw std::invalid_argument("the witness products are already queued (ug_groth16_prover_witness_msm_end)");
+        memset(queuedParts_, 0, sizeof queuedParts_);
+        if (rank_ == 0) {
+            if (earlyTerms_.valid()) earlyTerms_.wait();       // (a proof that was begun and never finished: its draw is dropped)
+            drawBlinding(earlyR_); drawBlinding(earlyS_);
+            earlyTerms_ = std::async(std::launch::async, [this] { return blindingTerms(hdr_, earlyR_, earlyS_); });
+        }
+        const uint64_t n = wr_.hi - wr_.lo;
+        if (n == 0 || n > maxRange_) {             // nothing to queue / proved in pieces (partial sums added between them): done here
+            if (n) runWitnessMsm(queuedParts_, true);
+            witnessQueued_ = 2;
+            return;
+        }
+        QueueGuard inFlight(d_.ctx);
+        buildSchedule(d_.sw, wCur_, wr_.lo, n, tableW_);
+        enqueueWitnessProducts(d_, d_.ctx, d_.sw, queuedParts_, queuedParts_ + 64, queuedParts_ + 128, queuedParts_ + 256,
+                               (int64_t)hdr_.nPublic + 1, false);
+        inFlight.done();
+        witnessQueued_ = 1;
+    }
+    void witnessMsmEnd(uint8_t* partials) override {
+        if (!witnessQueued_) throw std::invalid_argument("no witness products queued (ug_groth16_prover_witness_msm_begin)");
+        const int how = witnessQueued_;
+        witnessQueued_ = 0;
+        if (how == 1) {
+            QueueGuard inFlight(d_.ctx);
+            ugCheck(ug_ctx_collect(d_.ctx));
+            inFlight.done();
+            collectTimings(1);
+        }
+        memcpy(partials, queuedParts_, UG_GROTH16_PARTIALS_SIZE);
+    }
+    // a begun proof is given up: wait for the device, drop the queued products (no result is written)
+    void witnessMsmAbandon() {
+        if (witnessQueued_ == 1) ug_ctx_abandon(d_.ctx);
+        witnessQueued_ = 0;
     }
     // S10 on this rank's slice of h (which must be in d_.h); only the H record of partials is written
     void runHMsm(uint8_t* partials) override { runHMsmImpl(partials, true); }
@@ -925,6 +982,11 @@ public:
     }
 
     void finish(const uint8_t* sums, std::string& proof, std::string& pub) override {
+        if (earlyTerms_.valid()) {                 // r, s and their multiples were made beside the device work (witnessMsmBegin)
+            const BlindingTerms terms = earlyTerms_.get();
+            finishWith(sums, earlyR_, earlyS_, terms, proof, pub);
+            return;
+        }
         uint8_t r[32], s[32];
         drawBlinding(r); drawBlinding(s);                                                      // S11 :158-166
         finishWith(sums, r, s, blindingTerms(hdr_, r, s), proof, pub);
@@ -990,6 +1052,11 @@ private:
     ug_dvec* wCur_ = nullptr;          // the witness the device part reads: one of the two buffers (d_.w, d_.w2 own them)
     WitnessBuffers witness_;
     double m1_ = 0, f1_ = 0, m2_ = 0, f2_ = 0, totalMs_ = 0;      // device ms of the MSM / FFT parts per stream
+    // witnessMsmBegin .. witnessMsmEnd: the queued products write here (the queue holds these addresses until it is collected)
+    int witnessQueued_ = 0;            // 1: queued on the witness stream, 2: already complete in queuedParts_
+    uint8_t queuedParts_[UG_GROTH16_PARTIALS_SIZE] = {};
+    uint8_t earlyR_[32] = {}, earlyS_[32] = {};
+    std::future<BlindingTerms> earlyTerms_;
 };
 
 // =================================================================================================================
@@ -1454,46 +1521,50 @@ public:
         { BinFile f(wtns, wtnsSize, "wtns", 2); (void)ranks_[0]->witnessData(f); }
         std::vector<std::array<uint8_t, UG_GROTH16_PARTIALS_SIZE>> parts(R);
         std::vector<std::exception_ptr> errs(R);
-        // phase 1: witness products everywhere, the chains beside them on their ranks
+        // One host thread per rank, and on every rank both streams busy: the witness products are queued first and left to
+        // run (witnessMsmBegin); the rank's chains, the copies of its slices of the three evaluation vectors, its combine and
+        // its H product go to its second, high-priority stream meanwhile. The only edges between ranks are the three "chain c
+        // is complete" events: a rank that waits for them spends that time on its witness products.
+        std::promise<void> chainDone[3];
+        std::shared_future<void> chainReady[3];
+        for (int c = 0; c < 3; c++) chainReady[c] = chainDone[c].get_future().share();
         {
             std::vector<std::thread> th;
             for (int k = 0; k < R; k++)
                 th.emplace_back([&, k] {
+                    Groth16Prover& p = *ranks_[k];
+                    bool told[3] = {false, false, false};
                     try {
-                        Groth16Prover& p = *ranks_[k];
                         p.loadWitnessPart(wtns, wtnsSize, 0);
-                        std::exception_ptr chainErr;
-                        std::thread chains;
-                        const bool mine = k < 3;                        // chains k, k + R, ... of the three
-                        if (mine) chains = std::thread([&] {
-                            try {
-                                p.loadWitnessPart(wtns, wtnsSize, 1);
-                                for (int c = k; c < 3; c += R) p.hpolyChain(c, ug_dvec_device_ptr(full_[c]));
-                            } catch (...) { chainErr = std::current_exception(); }
-                        });
-                        try { p.runWitnessMsm(parts[k].data()); } catch (...) { errs[k] = std::current_exception(); }
-                        if (mine) chains.join();
-                        if (!errs[k] && chainErr) errs[k] = chainErr;
-                    } catch (...) { errs[k] = std::current_exception(); }
-                });
-            for (auto& t : th) t.join();
-        }
-        for (auto& e : errs) if (e) std::rethrow_exception(e);
-        // phase 2: every rank fetches its slices, forms its h slice and multiplies it
-        {
-            std::vector<std::thread> th;
-            for (int k = 0; k < R; k++)
-                th.emplace_back([&, k] {
-                    try {
-                        Groth16Prover& p = *ranks_[k];
+                        // with many ranks most of them wait for the chains: a chain rank then runs its chain first, alone (a
+                        // chain beside the products gets ~40 % of the chip whatever the stream priorities say, 17 ms instead of
+                        // 7 at 2^24 / 8 ranks); with few ranks it runs beside the products (bench.py: UG_BENCH_CHAIN_ORDER)
+                        const bool chainFirst = R >= 5;
+                        if (!chainFirst) p.witnessMsmBegin();
+                        if (k < 3) {                                       // chains k, k + R, ... of the three
+                            p.loadWitnessPart(wtns, wtnsSize, 1);
+                            for (int c = k; c < 3; c += R) {
+                                p.hpolyChain(c, ug_dvec_device_ptr(full_[c]));
+                                told[c] = true;
+                                chainDone[c].set_value();
+                            }
+                        }
+                        if (chainFirst) p.witnessMsmBegin();
+                        for (int c = 0; c < 3; c++) chainReady[c].get();    // (a chain rank's failure is rethrown here)
                         unsigned long long first = 0, cnt = 0;
                         p.hRange(&first, &cnt, nullptr);
                         for (int c = 0; c < 3; c++) ugCheck(ug_dvec_copy(slices_[k].v[c], 0, full_[c], first, cnt));
                         p.hpolyCombine(ug_dvec_device_ptr(slices_[k].v[0]), ug_dvec_device_ptr(slices_[k].v[1]), ug_dvec_device_ptr(slices_[k].v[2]));
                         uint8_t hpart[UG_GROTH16_PARTIALS_SIZE];
                         p.runHMsm(hpart);
+                        p.witnessMsmEnd(parts[k].data());
                         memcpy(parts[k].data() + 320, hpart + 320, 64);
-                    } catch (...) { errs[k] = std::current_exception(); }
+                    } catch (...) {
+                        errs[k] = std::current_exception();
+                        for (int c = k; c < 3; c += R)                     // nobody may wait for a chain that will not come
+                            if (k < 3 && !told[c]) chainDone[c].set_exception(errs[k]);
+                        p.witnessMsmAbandon();
+                    }
                 });
             for (auto& t : th) t.join();
         }
@@ -2192,6 +2263,18 @@ int ug_groth16_prover_run_witness_msm(void* prover_object, void* partials_out, c
     API_TRY
     if (prover_object == NULL || partials_out == NULL) throw std::invalid_argument("Null argument");
     static_cast<ProverBase*>(prover_object)->runWitnessMsm(static_cast<uint8_t*>(partials_out));
+    API_CATCH
+}
+int ug_groth16_prover_witness_msm_begin(void* prover_object, char* error_msg, unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL) throw std::invalid_argument("Null argument");
+    static_cast<ProverBase*>(prover_object)->witnessMsmBegin();
+    API_CATCH
+}
+int ug_groth16_prover_witness_msm_end(void* prover_object, void* partials_out, char* error_msg, unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL || partials_out == NULL) throw std::invalid_argument("Null argument");
+    static_cast<ProverBase*>(prover_object)->witnessMsmEnd(static_cast<uint8_t*>(partials_out));
     API_CATCH
 }
 int ug_groth16_prover_run_h_msm(void* prover_object, void* partials_out, char* error_msg, unsigned long long error_msg_maxsize) {

@@ -251,7 +251,8 @@ int ug_device_count(void) {
     return n;
 }
 
-int ug_ctx_create(ug_ctx** out, int device) {
+int ug_ctx_create(ug_ctx** out, int device) { return ug_ctx_create_priority(out, device, 0); }
+int ug_ctx_create_priority(ug_ctx** out, int device, int priority_class) {
     UG_TRY
     if (!out) throw std::invalid_argument("null ctx pointer");
     int n = 0;
@@ -260,7 +261,13 @@ int ug_ctx_create(ug_ctx** out, int device) {
     ug_ctx* c = new ug_ctx();
     c->device = device;
     c->use();
-    UG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (priority_class) {
+        int least = 0, greatest = 0;                // (numerically: greatest priority = lowest number)
+        UG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        UG_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, priority_class > 0 ? greatest : least));
+    } else {
+        UG_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    }
     UG_HIP(hipEventCreateWithFlags(&c->order_event, hipEventDisableTiming));
     for (int k = 0; k < 4; k++) c->stats[k].create();
     UG_HIP(hipHostMalloc((void**)&c->pinned_results, (size_t)MsmStats::MAX_BATCH * MSM_PENDING_WORDS * 4, hipHostMallocDefault));
