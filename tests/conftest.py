@@ -72,14 +72,8 @@ def _oracle_threads():
 
 @pytest.fixture(scope="session")
 def device():
-    # torch bundles its own HIP runtime: when a test uses both, torch must initialise first (as bench.py does),
-    # otherwise torch finds the runtime already loaded by libultragroth_hip.so and reports no GPUs
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    except Exception:
-        pass
+    # (torch bundles its own HIP runtime; the loader makes sure the process ends up with ONE copy whichever of the two is
+    # imported first: ultragroth_amd/_lib.py _one_hip_runtime, tests/test_abi.py)
     import ultragroth_amd as ug
     d = ug.Device(0)
     yield d

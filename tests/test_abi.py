@@ -207,3 +207,37 @@ def test_balanced_witness_ranges_tile_the_witness():
                 assert max(sizes[:3]) < min(sizes[3:])
     with pytest.raises(ug.ProverError):
         ug.ShardedGroth16Prover.balanced_witness_range(100, 3, 3)
+
+
+@pytest.mark.parametrize("order", ["library_first", "torch_first"])
+def test_one_hip_runtime_whatever_the_import_order(order):
+    """torch bundles a HIP runtime of its own: the loader must leave ONE copy in the process whichever is imported first
+    (round-2 review: library first used to give two runtimes and a torch without devices). Fresh interpreter per order."""
+    import subprocess
+    import sys
+    first, second = ("import ultragroth_amd as ug; ug._lib.load()", "import torch") if order == "library_first" else \
+                    ("import torch", "import ultragroth_amd as ug; ug._lib.load()")
+    code = "%s\n%s\nimport ultragroth_amd._lib as L\nprint('RUNTIMES', len(L.hip_runtimes_loaded()), L.hip_runtimes_loaded())" % (first, second)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "RUNTIMES 1 " in out.stdout, out.stdout
+
+
+@pytest.mark.gpu
+def test_library_first_then_torch_sees_the_device():
+    """the same on the GPU box: the library is loaded and used first, torch afterwards still finds the card and both work"""
+    import subprocess
+    import sys
+    code = ("import ultragroth_amd as ug\n"
+            "d = ug.Device(0)\n"
+            "import torch\n"
+            "assert torch.cuda.is_available() and torch.cuda.device_count() >= 1\n"
+            "x = torch.arange(8, device='cuda').sum().item()\n"
+            "assert x == 28\n"
+            "import ultragroth_amd._lib as L\n"
+            "assert len(L.hip_runtimes_loaded()) == 1, L.hip_runtimes_loaded()\n"
+            "d.close()\nprint('OK')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, (out.stdout + out.stderr)[-2000:]

@@ -210,18 +210,27 @@ def test_eight_sliced_ranks_at_configs3_size(device, huge, monkeypatch):
 
     full = torch.empty((3, n_dom, 32), dtype=torch.uint8, device="cuda")
     total = None
-    chain_ranks, parts = [], []
+    chain_ranks = []
+    r, s = fixed_rs()
     try:
+        # the order of bench.py's step at eight ranks: a chain rank runs its chain first and queues its witness products behind
+        # it (witness_msm_begin: rank 0 draws r and s there); every rank drives its H branch while its products run and
+        # collects them afterwards (witness_msm_end)
         for k in range(3):
             p = create(k)
             chain_ranks.append(p)
             p.load_witness_part(wtns, 0)
-            parts.append(p.run_witness_msm())
             p.load_witness_part(wtns, 1)
             p.hpoly_chain(k, full[k].data_ptr())
-        torch.cuda.synchronize()
+            if k == 0:
+                ug.set_test_blinding(r + s)
+            try:
+                p.witness_msm_begin()
+            finally:
+                ug.set_test_blinding(b"")
         for k, p in enumerate(chain_ranks):
-            blk = parts[k][:320] + h_part(p, k, full)
+            hblk = h_part(p, k, full)
+            blk = p.witness_msm_end()[:320] + hblk
             total = blk if total is None else ug.ShardedGroth16Prover.add_partials(total, blk)
             if k:
                 p.close()
@@ -229,17 +238,14 @@ def test_eight_sliced_ranks_at_configs3_size(device, huge, monkeypatch):
             p = create(k)
             try:
                 p.load_witness_part(wtns, 0)                 # a rank without a chain never sees the rest of the witness
-                blk = p.run_witness_msm()[:320] + h_part(p, k, full)
+                p.witness_msm_begin()
+                hblk = h_part(p, k, full)
+                blk = p.witness_msm_end()[:320] + hblk
             finally:
                 p.close()
             total = ug.ShardedGroth16Prover.add_partials(total, blk)
         _progress("2^%d x8: finishing on rank 0" % HUGE_LOG)
-        r, s = fixed_rs()
-        ug.set_test_blinding(r + s)
-        try:
-            got = chain_ranks[0].finish(total)
-        finally:
-            ug.set_test_blinding(b"")
+        got = chain_ranks[0].finish(total)                   # (with the blinding rank 0 drew when its products were queued)
     finally:
         for p in chain_ranks:
             p.close()

@@ -4,8 +4,10 @@ The product path has no CPU fallback: if the shared library is missing or the HI
 device, every compute entry point fails loudly.
 """
 import ctypes as C
+import importlib.util
 import os
 import subprocess
+import sys
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libultragroth_hip.so")
@@ -58,6 +60,38 @@ def build(jobs=4):
 _lib = None
 
 
+def _one_hip_runtime():
+    """One HIP runtime per process, whatever the import order. A torch wheel bundles its own libamdhip64.so, whose SONAME
+    (libamdhip64.so.7) is the name this library needs: when torch is imported first the dynamic linker hands that copy to this
+    library as well. The other way round used to be a hazard (round-2 review): this library brought in /opt/rocm's copy, torch's
+    own NEEDED entry (`libamdhip64.so`, no version) did not match it, a second runtime was loaded and torch saw no devices. So
+    when a torch with a bundled runtime is installed, that runtime is loaded here, before the library, and both orders end with
+    the same single copy. Programs that never touch Python (the `prover` CLI, cgo / JNI callers) use the system's runtime;
+    ULTRAGROTH_HIP_RUNTIME=system keeps that one here too (a process that then imports torch is on its own)."""
+    if os.environ.get("ULTRAGROTH_HIP_RUNTIME") == "system" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    bundled = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+
+
+def hip_runtimes_loaded():
+    """paths of every libamdhip64 mapped into this process (tests: exactly one)"""
+    seen = []
+    with open("/proc/self/maps") as f:
+        for line in f:
+            path = line.rsplit(" ", 1)[-1].strip()
+            if "libamdhip64" in os.path.basename(path) and path not in seen:
+                seen.append(path)
+    return seen
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -66,6 +100,7 @@ def load():
         raise RuntimeError(
             "libultragroth_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C ultragroth_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    _one_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, u64, i64, u32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_uint32
     pp = C.POINTER(C.c_void_p)
