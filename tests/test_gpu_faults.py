@@ -97,3 +97,61 @@ def test_short_slice_buffers_are_refused(device):
             ug.ShardedGroth16Prover.from_slices(header, None, 0, tuple(bytes(x) for x in cut), 0, k, world, public_size=86)
     p = ug.ShardedGroth16Prover.from_slices(header, None, 0, slices, 0, k, world, public_size=86)
     p.close()
+
+
+def test_queued_witness_products_survive_failures(device):
+    """the two-call form (ug_groth16_prover_witness_msm_begin / _end): a schedule that fails inside _begin leaves nothing queued;
+    an H branch that fails BETWEEN the two calls leaves the queued products collectable; the same objects prove bit-exact
+    afterwards. And the many-device prover (ULTRAGROTH_DEVICES, one rank per listed device, the products queued on every rank):
+    a failing chain on one rank reaches every waiting rank, the queued products are dropped, the next proof is bit-exact."""
+    import os
+    import torch
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, wtns, info = synth.build_circuit(device, 13, mix="U", seed=0x5EED0902)
+    r, s = fixed_rs()
+    exp = O.groth16_prove(zkey, wtns, int.from_bytes(r, "little"), int.from_bytes(s, "little"))[:2]
+    n_dom = info["domainSize"]
+    p = ug.ShardedGroth16Prover(zkey, 0, 0, 1)
+    try:
+        p.load_witness(wtns)
+        full = torch.empty((3, n_dom, 32), dtype=torch.uint8, device="cuda")
+
+        def whole():
+            ug.set_test_blinding(r + s)
+            try:
+                p.witness_msm_begin()
+            finally:
+                ug.set_test_blinding(b"")
+            for k in range(3):
+                p.hpoly_chain(k, full[k].data_ptr())
+            p.hpoly_combine(full[0].data_ptr(), full[1].data_ptr(), full[2].data_ptr())
+            hpart = p.run_h_msm()
+            return p.finish(p.witness_msm_end()[:320] + hpart[320:384])
+        assert whole() == exp
+        ug.inject_fault(ug.FAULT_SCHEDULE_BUILD)                 # inside _begin: the witness schedule
+        with pytest.raises(ug.ProverError, match="injected fault"):
+            p.witness_msm_begin()
+        with pytest.raises(ug.ProverError, match="no witness products queued"):
+            p.witness_msm_end()
+        assert whole() == exp
+        p.witness_msm_begin()
+        ug.inject_fault(ug.FAULT_SCHEDULE_BUILD)                 # the H schedule fails while the witness products are queued
+        p.hpoly_chain(0, full[0].data_ptr())
+        with pytest.raises(ug.ProverError, match="injected fault"):
+            p.run_h_msm()
+        assert len(p.witness_msm_end()) == 384                   # ... they are still there to be collected
+        assert whole() == exp
+    finally:
+        p.close()
+    os.environ["ULTRAGROTH_DEVICES"] = "0,0,0,0"
+    try:
+        with ug.Groth16Prover(zkey) as mp:
+            assert _fixed(ug, r + s, lambda: mp.prove(wtns)) == exp
+            ug.inject_fault(ug.FAULT_SCHEDULE_BUILD, after=2)    # some rank's schedule: that rank gives up, the others finish
+            with pytest.raises(ug.ProverError, match="injected fault"):
+                mp.prove(wtns)
+            for _ in range(2):
+                assert _fixed(ug, r + s, lambda: mp.prove(wtns)) == exp
+    finally:
+        del os.environ["ULTRAGROTH_DEVICES"]
