@@ -57,6 +57,24 @@ def test_f29_field_ops(hm, which, mod):
             assert _fop(hm, which, 4, a) == O.f_op("inv", which, a)
 
 
+@pytest.mark.parametrize("which,mod", [(0, O.R_MOD), (1, O.Q_MOD)])
+def test_f29_inversion_by_divsteps(hm, which, mod):
+    """inv() is the constant-time divsteps ("safegcd") form since round 3: against the oracle's inverse, against the Fermat form it
+    replaced, on a lazily reduced operand (a + 5q), and on the values where a gcd walk is shortest or longest (0, 1, powers of
+    two, q - 1, q - 2^k, the Montgomery constants)"""
+    rng = random.Random(400 + which)
+    R = 1 << 256
+    edge = [0, 1, 2, 3, mod - 1, mod - 2, mod // 2, mod // 2 + 1, R % mod, (R * R) % mod, pow(R, -1, mod)]
+    edge += [(1 << k) % mod for k in range(1, 256, 15)] + [(mod - (1 << k)) % mod for k in range(1, 254, 17)]
+    edge += [pow(3, k, mod) for k in (5, 77, 200)]
+    for a in edge + [rng.randrange(mod) for _ in range(600)]:
+        want = O.f_op("inv", which, a)
+        assert _fop(hm, which, 4, a) == want, hex(a)
+        assert _fop(hm, which, 9, a) == want, hex(a)
+    for a in edge + [rng.randrange(mod) for _ in range(40)]:
+        assert _fop(hm, which, 8, a) == O.f_op("inv", which, a), hex(a)
+
+
 def test_f29_lazy_chain(hm):
     rng = random.Random(6)
     R = 1 << 256

@@ -42,7 +42,8 @@ void g2_store(uint8_t* out, const G2XYZZ& p) {
 
 extern "C" {
 
-// op: 0 mul, 1 add, 2 sub, 3 neg(a), 4 inv(a), 5 sqr(a), 6 from/to normal round trip of a, 7 pack/unpack
+// op: 0 mul, 1 add, 2 sub, 3 neg(a), 4 inv(a), 5 sqr(a), 6 from/to normal round trip of a, 7 pack/unpack,
+//     8 inv_fermat(a) (the a^(q-2) form inv() replaced), 9 inv of the lazily reduced a + 5q
 int ugt_f_op(int which, int op, uint8_t* out, const uint8_t* a, const uint8_t* b) {
     if (which == 0) {
         typedef FrParams P;
@@ -56,6 +57,8 @@ int ugt_f_op(int which, int op, uint8_t* out, const uint8_t* a, const uint8_t* b
             case 5: r = sqr(x); break;
             case 6: { u32 w[8]; to_normal(w, x); r = from_normal<P>(w); break; }
             case 7: { u32 w[8]; Fp<P> c = canon(x); pack256(w, c); r = unpack256<P>(w); break; }
+            case 8: r = inv_fermat(x); break;
+            case 9: r = inv(sub<5>(x, fp_zero<P>())); break;
             default: return 1;
         }
         st(out, r);
@@ -71,6 +74,8 @@ int ugt_f_op(int which, int op, uint8_t* out, const uint8_t* a, const uint8_t* b
             case 5: r = sqr(x); break;
             case 6: { u32 w[8]; to_normal(w, x); r = from_normal<P>(w); break; }
             case 7: { u32 w[8]; Fp<P> c = canon(x); pack256(w, c); r = unpack256<P>(w); break; }
+            case 8: r = inv_fermat(x); break;
+            case 9: r = inv(sub<5>(x, fp_zero<P>())); break;
             default: return 1;
         }
         st(out, r);

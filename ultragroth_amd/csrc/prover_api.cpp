@@ -806,6 +806,7 @@ public:
     // S1-S4 on this rank's slice; partials = A | B1 | B2 | C | H affine records (H left at infinity)
     void runWitnessMsm(uint8_t* partials, bool standalone = true) override {
         if (!witnessLoaded_) throw std::invalid_argument("no witness loaded");
+        if (witnessQueued_ == 1) throw std::invalid_argument("witness products are queued on this prover (ug_groth16_prover_witness_msm_end)");
         // A schedule holds at most 2^31 (scalar, window) entries; ranges above MAX_RANGE scalars (only the
         // reference's largest legal domain, 2^27, needs it) are proved in pieces whose partial sums are added.
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
@@ -933,6 +934,7 @@ public:
     void run(uint8_t* partials) override {
         if (!witnessLoaded_ || !witnessComplete_) throw std::invalid_argument("no witness loaded");
         if (!haveHpoly_) throw std::invalid_argument("this rank was created without the coefficient matrix");
+        if (witnessQueued_) throw std::invalid_argument("witness products are queued on this prover (ug_groth16_prover_witness_msm_end)");
         const uint64_t nw = wr_.hi - wr_.lo, nh = hr_.hi - hr_.lo;
         if (nw > maxRange_ || nh > maxRange_) {                 // proved in pieces: partial sums are added between them
             uint8_t hpart[UG_GROTH16_PARTIALS_SIZE];
