@@ -2,7 +2,7 @@
 # round 3 measurement: what the fused A|B1|C accumulation would take if its gathers never missed (indices folded into cache)
 set -o pipefail
 mkdir -p gpurun_out; rm -f gpurun_out/r3_fold.log
-for f in "" 14 18; do
+for f in ${FOLDS:-"" 14 18}; do
   echo "== FOLD_LOG=$f" >> gpurun_out/r3_fold.log
   UG_GROUP_FOLD_LOG=$f timeout -k 10 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --host-threads 1 >> gpurun_out/r3_fold.log 2>gpurun_out/r3_fold.err || { echo failed; tail -3 gpurun_out/r3_fold.err; exit 1; }
 done
