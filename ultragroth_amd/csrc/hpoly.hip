@@ -48,11 +48,8 @@ __global__ void row_ptr_kernel(const u32* keys, u64 ncoefs, u32 nrows, u32* row_
     row_ptr[r] = (u32)lo;
 }
 
-__global__ __launch_bounds__(256) void matvec_kernel(u32* a_br, u32* b_br, const u32* row_ptr, const u32* sig,
-                                                     const u32* val, const u32* wtns, u32 domain, int logn, int mask) {
-    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= 2 * domain) return;
-    if (!((mask >> (r >= domain ? 1 : 0)) & 1)) return;        // bit 0: rows of A, bit 1: rows of B
+// the sum of one row of the coefficient matrix times the witness (rows r < domain: matrix A, the others: matrix B)
+__device__ __forceinline__ Fr matvec_row(u32 r, const u32* row_ptr, const u32* sig, const u32* val, const u32* wtns) {
     u32 s = row_ptr[r], e = row_ptr[r + 1];
     Fr acc = fp_zero<FrParams>();
     u32 since = 0;
@@ -76,10 +73,47 @@ __global__ __launch_bounds__(256) void matvec_kernel(u32* a_br, u32* b_br, const
             }
         }
     }
-    acc = contract(acc);
+    return contract(acc);
+}
+
+// one lane per row, the result stored at the row's bit-reversed place (domains below 2^8)
+__global__ __launch_bounds__(256) void matvec_kernel(u32* a_br, u32* b_br, const u32* row_ptr, const u32* sig,
+                                                     const u32* val, const u32* wtns, u32 domain, int logn, int mask) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= 2 * domain) return;
+    if (!((mask >> (r >= domain ? 1 : 0)) & 1)) return;        // bit 0: rows of A, bit 1: rows of B
+    Fr acc = matvec_row(r, row_ptr, sig, val, wtns);
     u32 c = r >= domain ? r - domain : r;
     u32* dst = (r >= domain ? b_br : a_br) + (size_t)bit_reverse(c, logn) * 8;
     st_packed(dst, acc);
+}
+
+// The same with the bit reversal done in 16 x 16 tiles through LDS (round 3): the rows go to their bit-reversed places because
+// the NTT that follows is decimation-in-time, and a lane that stores its own row's result writes 32 bytes 2^(logn-1) elements
+// away from its neighbour's -- at 2^24, 33 M scattered 32-byte writes, as many partial lines as the witness gathers read.
+// A workgroup takes the rows c = (i << (logn-4)) | (mid << 4) | j, i, j < 16: lane (i, j) reads row c (the 16 rows of a run are
+// adjacent: 1 KB of coefficients), the results meet in LDS, and lane (j', l) stores the result of row (i = rev4(l), j') at
+// rev(c) = (rev4(j') << (logn-4)) | (rev(mid) << 4) | l -- sixteen adjacent lanes, sixteen adjacent places: 512-byte runs.
+__global__ __launch_bounds__(256) void matvec_tiled_kernel(u32* a_br, u32* b_br, const u32* row_ptr, const u32* sig,
+                                                           const u32* val, const u32* wtns, u32 domain, int logn, int mask) {
+    __shared__ u32 tile[16][16 * 8 + 4];                       // row stride padded: 132 words
+    const u32 tiles_per_matrix = domain >> 8;
+    const u32 m = blockIdx.x >= tiles_per_matrix ? 1u : 0u;    // which matrix
+    if (!((mask >> m) & 1)) return;
+    const u32 mid = blockIdx.x - m * tiles_per_matrix;
+    const u32 i = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const u32 c = (i << (logn - 4)) | (mid << 4) | j;
+    const Fr acc = matvec_row(m * domain + c, row_ptr, sig, val, wtns);
+    u32 w[8];
+    pack256(w, acc);
+#pragma unroll
+    for (int k = 0; k < 8; k++) tile[i][j * 8 + k] = w[k];
+    __syncthreads();
+    const u32 j2 = threadIdx.x >> 4, l = threadIdx.x & 15, i2 = bit_reverse(l, 4);
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = tile[i2][j2 * 8 + k];
+    const u32 pos = (bit_reverse(j2, 4) << (logn - 4)) | (bit_reverse(mid, logn - 8) << 4) | l;
+    store8((m ? b_br : a_br) + (size_t)pos * 8, w);
 }
 
 __global__ void mul_pointwise_kernel(u32* out, const u32* x, const u32* y, u64 n) {
@@ -256,8 +290,13 @@ void CoefMatrix::release() {
 }
 
 void coef_matvec(u32* a_br, u32* b_br, const CoefMatrix& m, const u32* wtns_dev, int mask, hipStream_t stream) {
-    hipLaunchKernelGGL(matvec_kernel, dim3(grid_for((u64)2 * m.domain, 256)), dim3(256), 0, stream,
-                       a_br, b_br, m.row_ptr, m.sig, m.val, wtns_dev, m.domain, m.logn, mask);
+    static const bool tiled = !(getenv("UG_MATVEC_TILED") && atoi(getenv("UG_MATVEC_TILED")) == 0);      // A/B knob
+    if (m.logn >= 8 && tiled)
+        hipLaunchKernelGGL(matvec_tiled_kernel, dim3(2 * (m.domain >> 8)), dim3(256), 0, stream,
+                           a_br, b_br, m.row_ptr, m.sig, m.val, wtns_dev, m.domain, m.logn, mask);
+    else
+        hipLaunchKernelGGL(matvec_kernel, dim3(grid_for((u64)2 * m.domain, 256)), dim3(256), 0, stream,
+                           a_br, b_br, m.row_ptr, m.sig, m.val, wtns_dev, m.domain, m.logn, mask);
     UG_KERNEL_CHECK();
 }
 void fr_mul_pointwise(u32* out, const u32* x, const u32* y, u64 n, hipStream_t stream) {
