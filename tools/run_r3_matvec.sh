@@ -21,3 +21,12 @@ for r in csv.DictReader(open(f)):
         print("   %-50s calls=%3s avg_us=%9.1f" % (r['Name'].replace('ug::(anonymous namespace)::', '').replace('void ', '')[:50], r['Calls'], float(r['AverageNs']) / 1e3))
 PY
 done
+# the NTT launches of the last proof of the last run, in order (three chains per launch: inverse passes 1-3, forward passes 1-3)
+python3 - <<'PY'
+import csv, glob
+f = glob.glob('gpurun_out/prof_mv/*/*kernel_trace.csv')[0]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
+seq = [(r['Kernel_Name'], (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6, r['Grid_Size_Y']) for r in rows if 'ntt_pass' in r['Kernel_Name'] or 'matvec' in r['Kernel_Name']]
+idx = [i for i, s in enumerate(seq) if 'matvec' in s[0]]
+print("   last proof: " + "  ".join("%s%.3f(x%s)" % ("mv " if 'matvec' in s[0] else "", s[1], s[2]) for s in seq[idx[-2]:idx[-1]]))
+PY

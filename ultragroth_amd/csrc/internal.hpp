@@ -30,7 +30,8 @@ struct NttPlan {
     int logn = -1;
     u32* tw_fwd = nullptr;    // omega_n^i,   i < n/2
     u32* tw_inv = nullptr;    // omega_n^-i,  i < n/2
-    u32* twist = nullptr;     // n^-1 * omega_{2n}^i, i < n   (coset twist with the ifft scale folded in)
+    u32* twist = nullptr;     // n^-1 * omega_{2n}^i at place bitrev(i), i < n   (coset twist with the ifft scale folded in; in the
+                              // order of the scattering pass that applies it)
     u32* ninv = nullptr;      // n^-1 (one element)
     void init(int logn, hipStream_t stream);
     void release();

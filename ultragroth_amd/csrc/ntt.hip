@@ -174,14 +174,21 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassBatch batch) 
         __syncthreads();
     }
 
-    for (u32 pos = tid; pos < (u32)E; pos += nth) {
+    // (a scattering last pass walks its tile so that adjacent lanes store to adjacent places: local element (e, t) goes to
+    // bitrev(g) = (bitrev(lo0 + t) << k) | bitrev_k(e), so the lanes take e in bit-reversed order -- 2 KB per wave store
+    // instead of 64 pieces of 32 bytes in as many lines; round 3: 0.94 -> see profiles/r03_variants_ab.txt item 11)
+    const bool by_place = a.scatter_bitrev && s0 != 0;
+    for (u32 idx = tid; idx < (u32)E; idx += nth) {
+        const u32 pos = by_place ? lpos(bit_reverse(idx & ((1u << k) - 1), k), idx >> k) : idx;
         Fr x;
         ld(x.l, pos);
         u32 g = gidx(pos);
-        if (a.post) x = mul(x, ld_packed<FrParams>(a.post + (size_t)g * 8));   // strict, < 2q
+        u32 dst = a.scatter_bitrev ? bit_reverse(g, a.logn) : g;
+        // (post is indexed by the PLACE an element is stored at: a table for a scattering transform is kept in bit-reversed
+        // order, NttPlan::twist, so that its reads are as coalesced as the stores)
+        if (a.post) x = mul(x, ld_packed<FrParams>(a.post + (size_t)dst * 8));  // strict, < 2q
         else if (a.post_const) x = mul(x, ld_packed<FrParams>(a.post_const));
         else x = contract(x);                                                   // < 2.01 q, strict
-        u32 dst = a.scatter_bitrev ? bit_reverse(g, a.logn) : g;
         if (a.fin_a) {
             // fused h = a o b - c, plain integers (last pass of the third chain; S9, src/groth16.cpp:142-148)
             Fr tt = mul(ld_packed<FrParams>(a.fin_a + (size_t)dst * 8), ld_packed<FrParams>(a.fin_b + (size_t)dst * 8));   // < 2q
@@ -288,9 +295,16 @@ void NttPlan::init(int logn_, hipStream_t stream) {
         launch(tw_fwd + off * TW_WORDS, 3 + 2 * st, 2, (u64)1 << st, 1);
         launch(tw_inv + off * TW_WORDS, 4 + 2 * st, 2, (u64)1 << st, 1);
     }
-    launch(twist, 0, 1, n, 0);                 // n^-1 * omega_{2n}^i (packed: one product per element, in the last pass)
+    // n^-1 * omega_{2n}^i (packed: one product per element, in the last pass of the inverse transform), stored at bitrev(i):
+    // that pass scatters element i to place bitrev(i) and multiplies there
+    u32* natural = nullptr;
+    UG_HIP(hipMalloc(&natural, n * 32));
+    launch(natural, 0, 1, n, 0);
+    hipLaunchKernelGGL(bitrev_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, twist, natural, logn);
+    UG_KERNEL_CHECK();
     UG_HIP(hipMemcpyAsync(ninv, d_consts + 8, 32, hipMemcpyDeviceToDevice, stream));
     UG_HIP(hipStreamSynchronize(stream));
+    UG_HIP(hipFree(natural));
     UG_HIP(hipFree(d_consts));
 }
 
@@ -304,7 +318,8 @@ void NttPlan::release() {
 
 // The passes of one DIT transform. `in` holds the input in bit-reversed order unless gather_bitrev is set (then
 // natural order, gathered on the fly); output natural order, or bit-reversed if scatter_bitrev.
-// post (optional) multiplies output element i (natural index) by post[i] in the last pass.
+// post (optional) multiplies the output element stored at place p by post[p] in the last pass (for a scattering transform the
+// table is therefore in bit-reversed order).
 // Buffers: the first pass reads `in` (and fuse->in2); intermediate passes run in place on `mid` = fuse->work when given
 // (then `in` is only read), else `in` itself for a scattering transform (which is clobbered) and `out` otherwise; the last
 // pass writes `out`.
