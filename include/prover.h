@@ -218,9 +218,12 @@ int ug_groth16_prover_run(void *prover_object, void *partials_out,
 int ug_groth16_prover_run_witness_msm(void *prover_object, void *partials_out, char *error_msg, unsigned long long error_msg_maxsize);
 /* run_witness_msm in two calls, so that ONE host thread keeps both of a rank's streams busy: _begin queues the four products on
  * the witness stream and returns without waiting for the device; the caller then drives the H branch (hpoly_chain, the exchange
- * of the evaluation slices with the other ranks, hpoly_combine, run_h_msm -- all on the rank's second stream) while the products run, and _end waits for them and returns their partial sums. Between the two calls no
- * witness may be loaded. On rank 0, _begin also draws the blinding scalars r and s (src/groth16.cpp:158-166, before the device
- * work) and forms the multiples that need only them on host threads; ug_groth16_prover_finish then uses those. */
+ * of the evaluation slices with the other ranks, hpoly_combine, run_h_msm -- all on the rank's second stream) while the
+ * products run, and _end waits for them and returns their partial sums. Between the two calls no witness part 0 may be loaded
+ * and no other witness product started. On rank 0, _begin also draws the blinding scalars r and s (src/groth16.cpp:158-166,
+ * before the device work) and forms the multiples that need only them on host threads; ug_groth16_prover_finish then uses
+ * those. On a node where most ranks wait for the chains (five ranks or more), a chain rank calls hpoly_chain BEFORE _begin:
+ * stream priorities have no effect on this stack, so a chain queued beside the products would take 2.4 times as long. */
 int ug_groth16_prover_witness_msm_begin(void *prover_object, char *error_msg, unsigned long long error_msg_maxsize);
 int ug_groth16_prover_witness_msm_end(void *prover_object, void *partials_out, char *error_msg, unsigned long long error_msg_maxsize);
 int ug_groth16_prover_hpoly_chain(void *prover_object, int which, void *device_out, char *error_msg, unsigned long long error_msg_maxsize);
