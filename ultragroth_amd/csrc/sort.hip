@@ -113,7 +113,12 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(SortHistArgs a
     __shared__ u32 h[4 * SORT_MAX_BINS];
     for (int i = threadIdx.x; i < 4 * SORT_MAX_BINS; i += SORT_THREADS) h[i] = 0;
     __syncthreads();
+    // The sentinel key (a zero digit) is counted in a register and added once per lane: a circom-like witness is mostly zeros and
+    // ones, i.e. nearly every pair of it carries the sentinel, and 256 lanes adding to ONE LDS counter serialise (measured at
+    // 2^24, circom-like mix: 1.3 ms for the witness schedule's histogram against 0.32 ms for uniform scalars).
+    u32 zeros = 0;
     auto count = [&](u32 key) {
+        if (key == a.sentinel) { zeros++; return; }
         for (int p = 0; p < a.passes; p++) atomicAdd(&h[p * SORT_MAX_BINS + ((key >> a.shift[p]) & ((1u << a.bins_log[p]) - 1))], 1u);
     };
     const u64 stride = (u64)gridDim.x * SORT_THREADS;
@@ -124,6 +129,8 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(SortHistArgs a
     } else {
         for (u64 i = (u64)blockIdx.x * SORT_THREADS + threadIdx.x; i < a.n_padded; i += stride) count(i < a.n_pairs ? a.keys_in[i] : 0xffffffffu);
     }
+    if (zeros)
+        for (int p = 0; p < a.passes; p++) atomicAdd(&h[p * SORT_MAX_BINS + ((a.sentinel >> a.shift[p]) & ((1u << a.bins_log[p]) - 1))], zeros);
     __syncthreads();
     for (int i = threadIdx.x; i < a.passes * SORT_MAX_BINS; i += SORT_THREADS)
         if (h[i]) atomicAdd(&a.hist[i], h[i]);
