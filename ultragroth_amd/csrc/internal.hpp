@@ -80,7 +80,8 @@ struct RadixSorter {
     void release();
     // see sort.hip; returns which of the two buffer pairs holds the sorted pairs
     int sort(const u32* scalars, u64 n, int c, int windows, u32 buckets, u32 sentinel, bool tables, u64 n_pairs, int bits,
-             u32* const buf_keys[2], u32* const buf_vals[2], u32* error_flag, hipStream_t stream);
+             u32* const buf_keys[2], u32* const buf_vals[2], u32* error_flag, hipStream_t stream, u32* n_valid_out = nullptr,
+             bool* dropped_out = nullptr);
     ~RadixSorter() { release(); }
 };
 

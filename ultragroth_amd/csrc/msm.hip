@@ -196,7 +196,10 @@ __global__ void msm_digits_kernel(const u32* scalars, u64 n, int c, int windows,
 // meta[0] = number of heavy buckets, meta[1] = number of non-sentinel entries
 // (four entries per lane, one 16-byte load: with one entry per lane the launch was bound by wave dispatch, 0.65 ms for
 // 0.8 GB of keys at 2^24)
-__global__ void bucket_bounds_kernel(const u32* keys, u64 total, u32 sentinel, u32* start, u32* count, u32* meta) {
+// (known != 0: the sort dropped the zero digits, the keys end after meta[1] entries -- what lies behind is not the sentinel but
+// whatever the buffer held)
+__global__ void bucket_bounds_kernel(const u32* keys, u64 total_bound, u32 sentinel, u32* start, u32* count, u32* meta, int known) {
+    const u64 total = known ? (u64)meta[1] : total_bound;
     const u64 p0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (p0 >= total) return;
     u32 k[6];                                   // k[0] = the entry before the four, k[5] = the one after (sentinel past the end)
@@ -893,6 +896,7 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
     // pass reads the scalars themselves (pairs in unsorted form are written only when a scalar has more than 16 windows)
     static const bool use_cub = getenv("UG_SORT") && !strcmp(getenv("UG_SORT"), "cub");
     const bool pairs_first = use_cub || g.windows > 16;
+    bool dropped = false;                 // the sort left out the zero digits and wrote the entry count to meta[1] itself
     if (pairs_first) {
         hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, stream,
                            scalars_dev, g.n, g.c, g.windows, g.buckets, sentinel, g.tables ? 1 : 0, keys_a, vals_a);
@@ -913,14 +917,14 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
         u32* const bk[2] = {keys_a, keys_b};
         u32* const bv[2] = {vals_a, vals_b};
         const int at = sorter.sort(pairs_first ? nullptr : scalars_dev, g.n, g.c, g.windows, g.buckets, sentinel, g.tables, total, end_bit, bk, bv,
-                                   meta + 7, stream);
+                                   meta + 7, stream, meta + 1, &dropped);
         keys = bk[at];
         vals = bv[at];
     }
     UG_HIP(hipMemsetAsync(bucket_start, 0, (size_t)nb * 4, stream));
     UG_HIP(hipMemsetAsync(bucket_count, 0, (size_t)nb * 4, stream));
     hipLaunchKernelGGL(bucket_bounds_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, stream,
-                       keys, total, sentinel, bucket_start, bucket_count, meta);
+                       keys, total, sentinel, bucket_start, bucket_count, meta, dropped ? 1 : 0);
     UG_KERNEL_CHECK();
     hipLaunchKernelGGL(bucket_counts_kernel, dim3((nb + 1023) / 1024), dim3(1024), 0, stream, bucket_start, bucket_count, nb,
                        log_seg, log_seg_tail, meta, heavy_list, medium_list, heavy_cap, small_list);

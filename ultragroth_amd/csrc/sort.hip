@@ -48,6 +48,8 @@ struct SortPassArgs {
     int spl;                          // fused first pass: scalars per lane (ipt = spl * windows)
     int shift, bins_log;              // this pass sorts on (key >> shift) & (2^bins_log - 1)
     const u32* bin_base;              // 2^bins_log exclusive bin starts of this pass
+    const u32* n_valid;               // drop mode (see RadixSorter::sort): the pairs that exist after the first pass -- on the device
+    int drop;                         // drop mode, first pass: pairs with key >= sentinel (zero digits, padding) are not written at all
     u32* lookback;                    // tiles x 2^bins_log status words, zeroed
     u32* tile_counter;                // zeroed: hands out tile numbers in start order
     u32* error_flag;
@@ -106,6 +108,7 @@ struct SortHistArgs {
     u64 n_pairs, n_padded;             // padded: whole tiles (the padding pairs are counted: they take part in every pass)
     int passes; int shift[4]; int bins_log[4];
     u32* hist;                         // passes x 256 counters, zeroed
+    int drop;                          // keys >= sentinel are not counted at all (the first pass will not write them)
 };
 
 // counts per pass and bin; a grid-stride loop, counters in LDS, one global atomic per (workgroup, pass, bin)
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(SortHistArgs a
     // 2^24, circom-like mix: 1.3 ms for the witness schedule's histogram against 0.32 ms for uniform scalars).
     u32 zeros = 0;
     auto count = [&](u32 key) {
+        if (a.drop && key >= a.sentinel) return;
         if (key == a.sentinel) { zeros++; return; }
         for (int p = 0; p < a.passes; p++) atomicAdd(&h[p * SORT_MAX_BINS + ((key >> a.shift[p]) & ((1u << a.bins_log[p]) - 1))], 1u);
     };
@@ -136,11 +140,12 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(SortHistArgs a
         if (h[i]) atomicAdd(&a.hist[i], h[i]);
 }
 // hist[p][*] -> exclusive starts, in place (one workgroup, one wave per pass would do: a serial loop over 256 bins is nothing)
-__global__ void radix_scan_kernel(u32* hist, int passes) {
+__global__ void radix_scan_kernel(u32* hist, int passes, u32* n_valid_out) {
     const int p = threadIdx.x;
     if (p >= passes) return;
     u32 run = 0;
     for (int b = 0; b < SORT_MAX_BINS; b++) { const u32 v = hist[p * SORT_MAX_BINS + b]; hist[p * SORT_MAX_BINS + b] = run; run += v; }
+    if (p == 0 && n_valid_out) *n_valid_out = run;      // drop mode: every counted pair is a pair that stays
 }
 
 template <bool FROM_SCALARS, int LBW>
@@ -162,6 +167,11 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
     __syncthreads();
     const u32 tile = misc[0];
     const u64 e0 = (u64)tile * T;
+    // drop mode, passes after the first: the pair count is the device's (what the first pass kept); tiles beyond it have nothing
+    // to do (tiles are numbered in start order, so these are simply the last numbers handed out: nobody waits for them)
+    const u64 n_pairs = (!FROM_SCALARS && a.n_valid) ? (u64)*a.n_valid : a.n_pairs;
+    const u32 n_moved = (!FROM_SCALARS && a.n_valid) ? *a.n_valid : a.n_moved;
+    if (!FROM_SCALARS && e0 >= n_pairs) return;
 
     // ---- load (or make) the tile's pairs: lane holds pairs j = 0 .. ipt-1; wave-striped, so that (wave, j, lane) is memory order
     u32 key[SORT_MAX_IPT], val[SORT_MAX_IPT];
@@ -182,7 +192,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
 #pragma unroll
         for (int j = 0; j < SORT_MAX_IPT; j++) {
             const u64 idx = e0 + (u64)wave * (64u * (u32)ipt) + (u64)j * 64u + (u64)lane;
-            const bool in = j < ipt && idx < a.n_pairs;
+            const bool in = j < ipt && idx < n_pairs;
             key[j] = in ? a.keys_in[idx] : 0xffffffffu;
             val[j] = in ? a.vals_in[idx] : 0u;
         }
@@ -196,15 +206,18 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
     for (int j = 0; j < SORT_MAX_IPT; j++) {
         if (j < ipt) {
             const u32 d = (key[j] >> a.shift) & dmask;
-            u64 peers = ~0ull;
+            const bool keep = !(FROM_SCALARS && a.drop) || key[j] < a.sentinel;      // (drop mode: zero digits and padding take no part)
+            u64 peers = __ballot(keep);
             for (int b = 0; b < a.bins_log; b++) {
                 const u64 vote = __ballot((d >> b) & 1u);
                 peers &= ((d >> b) & 1u) ? vote : ~vote;
             }
-            const u32 before = (u32)__popcll(peers & lt_mask), same = (u32)__popcll(peers);
-            const u32 old = mycnt[d];                      // every peer reads the counter ...
-            if (before == 0) mycnt[d] = old + same;        // ... before its first lane moves it on (one wave, LDS accesses in program order)
-            rank[j] = old + before;
+            if (keep) {
+                const u32 before = (u32)__popcll(peers & lt_mask), same = (u32)__popcll(peers);
+                const u32 old = mycnt[d];                  // every peer reads the counter ...
+                if (before == 0) mycnt[d] = old + same;    // ... before its first lane moves it on (one wave, LDS accesses in program order)
+                rank[j] = old + before;
+            }
         }
     }
     __syncthreads();
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
     // ---- reorder through LDS: the tile's pairs in bin order ...
 #pragma unroll
     for (int j = 0; j < SORT_MAX_IPT; j++) {
-        if (j < ipt) {
+        if (j < ipt && (!(FROM_SCALARS && a.drop) || key[j] < a.sentinel)) {
             const u32 d = (key[j] >> a.shift) & dmask;
             const u32 lp = texcl[d] + wcnt[wave * SORT_MAX_BINS + d] + rank[j];
             stage_k[lp] = key[j]; stage_v[lp] = val[j];
@@ -271,11 +284,12 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
     }
     __syncthreads();
     // ... and out: neighbouring lanes hold neighbouring pairs of a bin, i.e. neighbouring addresses
-    for (u32 lp = tid; lp < T; lp += SORT_THREADS) {
+    const u32 staged = (FROM_SCALARS && a.drop) ? misc[1] + misc[2] + misc[3] + misc[4] : T;      // drop mode: the pairs the tile kept
+    for (u32 lp = tid; lp < staged; lp += SORT_THREADS) {
         const u32 k = stage_k[lp];
         const u32 d = (k >> a.shift) & dmask;
         const u32 pos = gbase[d] + lp;                     // (mod 2^32: gbase holds a difference)
-        if (pos < a.n_moved) {                             // (padding a later pass made for its own last tile sorts behind everything: dropped)
+        if (pos < n_moved) {                               // (padding a later pass made for its own last tile sorts behind everything: dropped)
             a.keys_out[pos] = k;
             a.vals_out[pos] = stage_v[lp];
         }
@@ -316,8 +330,13 @@ void RadixSorter::release() {
 // Sorts the schedule's pairs by key. scalars != nullptr and windows <= 16: the pairs are made from the scalars inside the
 // first pass; otherwise they are read from (buf_keys[0], buf_vals[0]). The passes ping-pong between the two buffer pairs
 // (each with room for whole tiles: n_pairs + 8192 entries); returns the index of the pair that holds the result.
+// n_valid_out (optional, device): DROP MODE -- when the pairs are made from the scalars, those with key >= sentinel (zero digits;
+// the padding of the last tile) are never written: the first pass compacts them away, the later passes move only what is left,
+// and the number of pairs that remain is stored at *n_valid_out (before any pass runs). A circom-like witness is mostly zeros
+// and small values: more than half of its (scalar, window) pairs are zero digits that the other form carries through every pass
+// only to cut them off at the end. *dropped_out tells whether the mode was taken (it needs the scalar form).
 int RadixSorter::sort(const u32* scalars, u64 n, int c, int windows, u32 buckets, u32 sentinel, bool tables, u64 n_pairs, int bits,
-                      u32* const buf_keys[2], u32* const buf_vals[2], u32* error_flag, hipStream_t stream) {
+                      u32* const buf_keys[2], u32* const buf_vals[2], u32* error_flag, hipStream_t stream, u32* n_valid_out, bool* dropped_out) {
     int shift[4], bins_log[4];
     const int passes = radix_plan(bits, shift, bins_log);
     if (passes > 4) throw std::logic_error("radix sort: key too wide");
@@ -326,6 +345,9 @@ int RadixSorter::sort(const u32* scalars, u64 n, int c, int windows, u32 buckets
     static const int env_spl = getenv("UG_SORT_SPL") ? atoi(getenv("UG_SORT_SPL")) : 1;
     const int ipt_pairs = env_ipt < 4 ? 4 : env_ipt > SORT_MAX_IPT ? SORT_MAX_IPT : env_ipt;
     const bool fused = scalars != nullptr && windows <= SORT_FUSED_MAX_WINDOWS;
+    static const bool drop_ok = !(getenv("UG_SORT_DROP") && atoi(getenv("UG_SORT_DROP")) == 0);      // A/B knob
+    const bool drop = fused && n_valid_out != nullptr && drop_ok;
+    if (dropped_out) *dropped_out = drop;
     int spl = 1;
     if (fused) { spl = env_spl < 1 ? 1 : env_spl; while (spl > 1 && spl * windows > SORT_MAX_IPT) spl--; }
     const int ipt_first = fused ? windows * spl : ipt_pairs;
@@ -345,12 +367,13 @@ int RadixSorter::sort(const u32* scalars, u64 n, int c, int windows, u32 buckets
         h.passes = passes;
         for (int p = 0; p < 4; p++) { h.shift[p] = p < passes ? shift[p] : 0; h.bins_log[p] = p < passes ? bins_log[p] : 1; }
         h.hist = hist;
+        h.drop = drop ? 1 : 0;
         const u64 lanes = fused ? h.n_padded / (u64)windows : h.n_padded;
         unsigned blocks = (unsigned)std::min<u64>((lanes + SORT_THREADS - 1) / SORT_THREADS, 2048);
         if (!blocks) blocks = 1;
         hipLaunchKernelGGL(radix_hist_kernel, dim3(blocks), dim3(SORT_THREADS), 0, stream, h);
         UG_KERNEL_CHECK();
-        hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(64), 0, stream, hist, passes);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(64), 0, stream, hist, passes, drop ? n_valid_out : (u32*)nullptr);
         UG_KERNEL_CHECK();
     }
     // every pass moves the same multiset of pairs: the real ones plus the padding of the first pass's last tile
@@ -369,6 +392,7 @@ int RadixSorter::sort(const u32* scalars, u64 n, int c, int windows, u32 buckets
         a.spl = spl;
         a.shift = shift[p]; a.bins_log = bins_log[p];
         a.bin_base = hist + p * SORT_MAX_BINS;
+        a.n_valid = drop ? n_valid_out : nullptr; a.drop = drop ? 1 : 0;
         a.lookback = lookback; a.tile_counter = counters + p; a.error_flag = error_flag;
         const u64 T = (u64)SORT_THREADS * (u64)a.ipt;
         const u64 tiles = (moved + T - 1) / T;
