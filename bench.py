@@ -270,6 +270,14 @@ def bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_r
         dist.all_gather(allp, mine)
         return [bytes(t.cpu().numpy()) for t in allp]
 
+    comm_stream = torch.cuda.Stream() if (split_h and cuda) else None
+    chain_order = os.environ.get("UG_BENCH_CHAIN_ORDER", "auto")          # as on the Groth16 path (main())
+    chain_first = chain_order == "first" or (chain_order == "auto" and world >= 5)
+
+    def run_chains():
+        for k in my_chains:
+            prover.hpoly_chain(k, fulls[k].data_ptr())
+
     def step():
         prover.load_witness(uwtns)
         total = bytes(64)
@@ -278,28 +286,41 @@ def bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_r
         commitment = to_comm(prover.round_finish(total) if rank == 0 else bytes(64))
         dist.broadcast(commitment, src=0)
         prover.apply_commitment(bytes(commitment.cpu().numpy()))
-        part = prover.run_witness_msm()
         if split_h:
-            for k in my_chains:                 # (the UltraGroth prover has one stream: its chains follow its MSMs)
-                prover.hpoly_chain(k, fulls[k].data_ptr())
-            for k in range(3):
-                src = k % world
-                if cuda:
-                    dist.scatter(bufs[k], [fulls[k][q * sl:(q + 1) * sl] for q in range(world)] if rank == src else None, src=src)
-                else:                           # gloo rehearsal: through host memory
+            # the final round as on the Groth16 path: witness products queued (A | B1, B2, the gathered final set), the H branch
+            # on the library's second stream beside them; a chain rank of a large node runs its chain first
+            if chain_first:
+                run_chains()
+                prover.witness_msm_begin()
+            else:
+                prover.witness_msm_begin()
+                run_chains()
+            if comm_stream is not None:
+                with torch.cuda.stream(comm_stream):
+                    works = [dist.scatter(bufs[k], [fulls[k][q * sl:(q + 1) * sl] for q in range(world)] if rank == k % world else None,
+                                          src=k % world, async_op=True) for k in range(3)]
+                    for wk in works:
+                        wk.wait()
+                comm_stream.synchronize()
+            else:                               # gloo rehearsal: through host memory
+                for k in range(3):
+                    src = k % world
                     o = torch.empty(bufs[k].shape, dtype=torch.uint8)
                     dist.scatter(o, [fulls[k][q * sl:(q + 1) * sl].cpu() for q in range(world)] if rank == src else None, src=src)
                     bufs[k].copy_(o)
-            torch.cuda.synchronize()
+                torch.cuda.current_stream().synchronize()
             prover.hpoly_combine(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr())
+            hpart = prover.run_h_msm()
+            part = prover.witness_msm_end()[:320] + hpart[320:384]
         else:                                   # the domain does not split evenly: every rank forms h itself
+            part = prover.run_witness_msm()
             for k in range(3):
                 prover.hpoly_chain(k, fulls[k].data_ptr())
             first, cnt, _ = prover.h_range()
             sl_bufs = [fulls[k][first:first + cnt].contiguous() for k in range(3)]
             torch.cuda.synchronize()
             prover.hpoly_combine(*(b.data_ptr() for b in sl_bufs))
-        part = part[:320] + prover.run_h_msm()[320:384]
+            part = part[:320] + prover.run_h_msm()[320:384]
         acc = None
         for other in gather_all(part):
             acc = other if acc is None else ug.ShardedGroth16Prover.add_partials(acc, other)

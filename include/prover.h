@@ -247,7 +247,8 @@ int ug_groth16_prover_finish(void *prover_object, const void *partials_sum,
  *   ug_ultra_groth_prover_round_finish       ONE rank: draws the round randomness, blinds the sum -> the commitment pi_r
  *     -- exchange: the commitment goes to every rank --
  *   ug_ultra_groth_prover_apply_commitment   every rank: Fiat-Shamir challenge, lookup signals written into its witness
- *   ug_groth16_prover_run_witness_msm        every rank: A | B1 | B2 | final-set partial sums
+ *   ug_groth16_prover_run_witness_msm        every rank: A | B1 | B2 | final-set partial sums (or _witness_msm_begin ... _end around
+ *                                            the H-branch calls below, as for Groth16: an UltraGroth rank has two streams too)
  *   ug_groth16_prover_hpoly_chain / _h_range / _hpoly_combine / _run_h_msm    as for Groth16 (or replicate the block)
  *     -- exchange: partial blocks added (ug_groth16_partials_add) --
  *   ug_groth16_prover_finish                 the rank that closed the round: r, s, blinding, proof.json / public.json

@@ -839,6 +839,63 @@ def test_sharded_ultragroth_equals_oracle(device, world, split_h):
         p.close()
 
 
+@pytest.mark.parametrize("world,chain_first", [(2, False), (4, True)])
+def test_sharded_ultragroth_queued_final_round(device, world, chain_first):
+    """the final round as bench.py --ultra and the many-device UltraGroth prover drive it since round 3: every rank's witness
+    products (A | B1, B2, the gathered final set) queued with ug_groth16_prover_witness_msm_begin, its H branch -- chains, combine,
+    H product, on the rank's second stream -- driven meanwhile, _end afterwards; chain first or beside the products. == the oracle,
+    twice on the same objects; the blocking call is refused while products are queued"""
+    import torch
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, uwtns, info = synth.build_ultra_circuit(device, 13)
+    rk, r, s = bytes(range(1, 32)), bytes(range(40, 71)), bytes(range(80, 111))
+    exp = O.ultra_groth_prove(zkey, uwtns, int.from_bytes(rk, "little"), int.from_bytes(r, "little"), int.from_bytes(s, "little"))
+    ranks = [ug.ShardedUltraGrothProver(zkey, 0, k, world) for k in range(world)]
+    n_dom = info["domainSize"]
+    sl = n_dom // world
+    full = torch.empty((3, n_dom, 32), dtype=torch.uint8, device="cuda")
+    try:
+        for turn in range(2):
+            ug.set_test_blinding(rk + r + s)
+            try:
+                for p in ranks:
+                    p.load_witness(uwtns)
+                with pytest.raises(ug.ProverError, match="round commitment has not been applied"):
+                    ranks[0].witness_msm_begin()
+                total = bytes(64)
+                for p in ranks:
+                    total = ug.ShardedUltraGrothProver.add_records(total, p.round_commit())
+                commitment = ranks[0].round_finish(total)
+                for p in ranks:
+                    p.apply_commitment(commitment)
+                if not chain_first:
+                    for p in ranks:
+                        p.witness_msm_begin()
+                for k in range(3):
+                    ranks[k % world].hpoly_chain(k, full[k].data_ptr())
+                if chain_first:
+                    for p in ranks:
+                        p.witness_msm_begin()
+                with pytest.raises(ug.ProverError, match="queued"):
+                    ranks[world - 1].run_witness_msm()
+                acc = None
+                for q, p in enumerate(ranks):
+                    bufs = [full[k, q * sl:(q + 1) * sl].contiguous() for k in range(3)]
+                    torch.cuda.current_stream().synchronize()
+                    p.hpoly_combine(*(b.data_ptr() for b in bufs))
+                    hpart = p.run_h_msm()
+                    part = p.witness_msm_end()[:320] + hpart[320:384]
+                    acc = part if acc is None else ug.ShardedGroth16Prover.add_partials(acc, part)
+                got = ranks[0].finish(acc)
+            finally:
+                ug.set_test_blinding(b"")
+            assert got == exp, turn
+    finally:
+        for p in ranks:
+            p.close()
+
+
 def test_created_prover_at_2_20_bit_exact(device):
     """the largest size the oracle still proves in seconds: 2^20 constraints through a created prover (window tables of
     the cost-model width, batched witness MSMs, three-pass NTTs), uniform scalars, twice with different witnesses"""

@@ -1097,6 +1097,10 @@ public:
         for (uint32_t i : finalIdx_) if (i >= M) throw std::range_error("final round index outside the witness");
 
         ugCheck(ug_ctx_create(&d_.ctx, device));
+        // the H branch (H polynomial, its schedule, the H product) has a stream of its own, as in Groth16Prover: a rank of a
+        // many-GPU prover drives it beside its queued witness products (witnessMsmBegin), and ULTRAGROTH_OVERLAP=1 lets it run
+        // beside them on one GPU as well; by default the second stream is ordered behind the first on the device
+        ugCheck(ug_ctx_create(&d_.ctx2, device));
         if (fusedGroups()) {                            // A and B1 share the witness scalars: one interleaved group
             const void* hosts[2] = {pA + wr_.lo * 64, pB1 + wr_.lo * 64};
             const uint64_t counts[2] = {wr_.hi - wr_.lo, wr_.hi - wr_.lo}, firsts[2] = {wr_.lo, wr_.lo};
@@ -1110,16 +1114,16 @@ public:
         // slices count from 0
         ugCheck(ug_bases_create_g1(d_.ctx, pFinalC + c2.lo * 64, c2.hi - c2.lo, 0, &d_.C));
         ugCheck(ug_bases_create_g1(d_.ctx, pRoundC + c1.lo * 64, c1.hi - c1.lo, 0, &d_.roundC));
-        ugCheck(ug_bases_create_g1(d_.ctx, pH + hr_.lo * 64, hr_.hi - hr_.lo, hr_.lo, &d_.H));
-        ugCheck(ug_hpoly_create(d_.ctx, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
+        ugCheck(ug_bases_create_g1(d_.ctx2, pH + hr_.lo * 64, hr_.hi - hr_.lo, hr_.lo, &d_.H));
+        ugCheck(ug_hpoly_create(d_.ctx2, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
         ugCheck(ug_dvec_create(d_.ctx, M, &d_.w));
         wCur_ = d_.w;
         witness_.attach(d_.ctx, M, &d_.w, &d_.w2);
-        ugCheck(ug_dvec_create(d_.ctx, N, &d_.h));
+        ugCheck(ug_dvec_create(d_.ctx2, N, &d_.h));
         uint64_t auxN = std::max<uint64_t>(roundIdx_.size(), finalIdx_.size());
         ugCheck(ug_dvec_create(d_.ctx, auxN ? auxN : 1, &d_.aux));
         ugCheck(ug_schedule_create(d_.ctx, &d_.sw));
-        ugCheck(ug_schedule_create(d_.ctx, &d_.sh));
+        ugCheck(ug_schedule_create(d_.ctx2, &d_.sh));
         ugCheck(ug_schedule_create(d_.ctx, &d_.saux));
         ugCheck(ug_index_create(d_.ctx, roundIdx_.data(), roundIdx_.size(), &d_.roundIdx));
         ugCheck(ug_index_create(d_.ctx, finalIdx_.data(), finalIdx_.size(), &d_.finalIdx));
@@ -1141,7 +1145,7 @@ public:
     void trimWorkspaces() override {
         std::lock_guard<std::mutex> turn(proveMutex);
         ug_schedule_trim(d_.sw); ug_schedule_trim(d_.sh); ug_schedule_trim(d_.saux);
-        ug_ctx_trim(d_.ctx);
+        ug_ctx_trim(d_.ctx); ug_ctx_trim(d_.ctx2);
         witness_.trim(wCur_);
     }
 
@@ -1178,7 +1182,7 @@ public:
         chunks_.swap(sl.chunks); freq_.swap(sl.freq); wIdx_.swap(sl.wIdx); pIdx_.swap(sl.pIdx);
         publicPart_.swap(sl.publicPart);
         uploadMs = sl.uploadMs;
-        ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1));
+        ugCheck(ug_ctx_timings(d_.ctx, nullptr, nullptr, 1)); ugCheck(ug_ctx_timings(d_.ctx2, nullptr, nullptr, 1));
         witnessLoaded_ = true; committed_ = false; haveRoundScalar_ = false;
         if (trace_) fprintf(stderr, "[ultragroth] %-28s %8.3f ms\n", "parse uwtns + witness upload", uploadMs);
         tPhase_ = std::chrono::steady_clock::now();
@@ -1236,6 +1240,7 @@ public:
     // final round (execute_final_round :187-399), this rank's slices: A | B1 | B2 | C2 records of the partials block
     void runWitnessMsm(uint8_t* partials, bool = true) override {
         if (!committed_) throw std::invalid_argument("the round commitment has not been applied");
+        if (witnessQueued_) throw std::invalid_argument("witness products are queued on this prover (ug_groth16_prover_witness_msm_end)");
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
         buildSchedule(d_.sw, wCur_, wr_.lo, wr_.hi - wr_.lo, tableW_);
         enqueueWitnessProducts(d_, d_.ctx, d_.sw, partials, partials + 64, partials + 128, nullptr, 0, false);      // MSM1-3 :201,214,227
@@ -1247,20 +1252,55 @@ public:
         ugCheck(ug_msm_g1(d_.ctx, d_.C, d_.saux, 0, partials + 256));                       // MSM4 :234
         mark("C MSM");
     }
+    // The same in two calls, as Groth16Prover: _begin queues MSM1-3, the gather of the final witnesses and MSM4 on the witness
+    // stream and returns; the caller drives the H branch (second stream) meanwhile; _end waits and returns the four sums.
+    void witnessMsmBegin() override {
+        if (!committed_) throw std::invalid_argument("the round commitment has not been applied");
+        if (witnessQueued_) throw std::invalid_argument("the witness products are already queued (ug_groth16_prover_witness_msm_end)");
+        memset(queuedParts_, 0, sizeof queuedParts_);
+        QueueGuard inFlight(d_.ctx);
+        queueFinalRoundProducts(queuedParts_);
+        inFlight.done();
+        witnessQueued_ = 1;
+    }
+    void witnessMsmEnd(uint8_t* partials) override {
+        if (!witnessQueued_) throw std::invalid_argument("no witness products queued (ug_groth16_prover_witness_msm_begin)");
+        witnessQueued_ = 0;
+        QueueGuard inFlight(d_.ctx);
+        ugCheck(ug_ctx_collect(d_.ctx));
+        inFlight.done();
+        collectTimings(1);
+        memcpy(partials, queuedParts_, UG_GROTH16_PARTIALS_SIZE);
+    }
+    void witnessMsmAbandon() {
+        if (witnessQueued_ == 1) ug_ctx_abandon(d_.ctx);
+        witnessQueued_ = 0;
+    }
+    // MSM1-3 (:201,214,227), the gather of the final witnesses (:439-445) and MSM4 (:234), queued on the witness stream
+    void queueFinalRoundProducts(uint8_t* sums) {
+        buildSchedule(d_.sw, wCur_, wr_.lo, wr_.hi - wr_.lo, tableW_);
+        enqueueWitnessProducts(d_, d_.ctx, d_.sw, sums, sums + 64, sums + 128, nullptr, 0, false);
+        ugCheck(ug_dvec_gather_index(d_.aux, wCur_, d_.finalIdx));
+        buildSchedule(d_.saux, d_.aux, 0, finalIdx_.size(), tableC2_);
+        const ug_bases* setC[1] = {d_.C};
+        void* outC[1] = {sums + 256};
+        ugCheck(ug_msm_batch_enqueue(d_.ctx, 1, setC, d_.saux, nullptr, outC));
+    }
     void hpolyChain(int which, void* deviceOut) override {
         if (!committed_) throw std::invalid_argument("the round commitment has not been applied");
         ug_dvec* v = nullptr;
-        ugCheck(ug_dvec_wrap(d_.ctx, deviceOut, hdr_.domainSize, &v));
+        ugCheck(ug_dvec_wrap(d_.ctx2, deviceOut, hdr_.domainSize, &v));
         int rc = ug_hpoly_chain(d_.hp, wCur_, which, v);
         ug_dvec_destroy(v);
         ugCheck(rc);
+        ugCheck(ug_ctx_sync(d_.ctx2));               // the vector is complete when the call returns (the caller sends it on)
     }
     void hpolyCombine(void* da, void* db, void* dc) override {
         uint64_t cnt = hr_.hi - hr_.lo;
         ug_dvec *a = nullptr, *b = nullptr, *c = nullptr;
-        ugCheck(ug_dvec_wrap(d_.ctx, da, cnt, &a));
-        ugCheck(ug_dvec_wrap(d_.ctx, db, cnt, &b));
-        ugCheck(ug_dvec_wrap(d_.ctx, dc, cnt, &c));
+        ugCheck(ug_dvec_wrap(d_.ctx2, da, cnt, &a));
+        ugCheck(ug_dvec_wrap(d_.ctx2, db, cnt, &b));
+        ugCheck(ug_dvec_wrap(d_.ctx2, dc, cnt, &c));
         int rc = ug_hpoly_combine(d_.hp, a, b, c, hr_.lo, cnt, d_.h);
         ug_dvec_destroy(a); ug_dvec_destroy(b); ug_dvec_destroy(c);
         ugCheck(rc);
@@ -1274,9 +1314,15 @@ public:
     void runHMsm(uint8_t* partials) override {
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
         buildSchedule(d_.sh, d_.h, hr_.lo, hr_.hi - hr_.lo, tableH_);
-        ugCheck(ug_msm_g1(d_.ctx, d_.H, d_.sh, 0, partials + 320));
+        ugCheck(ug_msm_g1(d_.ctx2, d_.H, d_.sh, 0, partials + 320));
         mark("H MSM");
-        ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
+        collectTimings(witnessQueued_ == 1 ? 2 : 3);          // (queued witness products: their stream is read when they are collected)
+    }
+    // device time of both streams since the witness was adopted; which: 1 = witness stream, 2 = H branch (each waits for its stream)
+    void collectTimings(int which) {
+        if (which & 1) ugCheck(ug_ctx_timings(d_.ctx, &m1_, &f1_, 0));
+        if (which & 2) ugCheck(ug_ctx_timings(d_.ctx2, &m2_, &f2_, 0));
+        msmMs_ = m1_ + m2_; fftMs_ = f1_ + f2_;
     }
     // on the rank that ran roundFinish, with the summed partials: r and s (:345-346), the blinded proof, the JSON texts
     void finish(const uint8_t* sums, std::string& proof, std::string& pub) override {
@@ -1323,7 +1369,7 @@ public:
         // ULTRAGROTH_TRACE=1: host wall-clock per phase on stderr (where the non-MSM, non-FFT time of a proof goes)
         trace_ = getenv("ULTRAGROTH_TRACE") && atoi(getenv("ULTRAGROTH_TRACE")) != 0;
         adopt(*lease);
-        QueueGuard inFlight(d_.ctx);                     // (declared before `terms`: the host threads join first, then the device is drained)
+        QueueGuard inFlight(d_.ctx, d_.ctx2);            // (declared before `terms`: the host threads join first, then the device is drained)
         uint8_t part[64], commit[64];
         roundCommit(part);
         roundFinish(part, commit);
@@ -1345,21 +1391,21 @@ public:
         } else {
             // the whole final round queued on the stream, ONE host wait: MSM1-3 (:201,214,227), the gather of the final
             // witnesses (:439-445) and MSM4 (:234), the FFT block (:243-320), MSM5 (:322)
+            // (two streams since round 3: the H branch has its own; by default it is ordered behind the witness products on the
+            // device, ULTRAGROTH_OVERLAP=1 drops that edge -- the witness is complete either way: the lookup writes end with a
+            // host wait)
             memset(sums, 0, sizeof sums);
-            buildSchedule(d_.sw, wCur_, wr_.lo, wr_.hi - wr_.lo, tableW_);
-            enqueueWitnessProducts(d_, d_.ctx, d_.sw, sums, sums + 64, sums + 128, nullptr, 0, false);
-            ugCheck(ug_dvec_gather_index(d_.aux, wCur_, d_.finalIdx));
-            buildSchedule(d_.saux, d_.aux, 0, finalIdx_.size(), tableC2_);
-            const ug_bases* setC[1] = {d_.C};
-            void* outC[1] = {sums + 256};
-            ugCheck(ug_msm_batch_enqueue(d_.ctx, 1, setC, d_.saux, nullptr, outC));
+            queueFinalRoundProducts(sums);
+            const char* ov = getenv("ULTRAGROTH_OVERLAP");
+            if (!(ov && atoi(ov) != 0)) ugCheck(ug_ctx_wait(d_.ctx2, d_.ctx));
             ugCheck(ug_hpoly_run(d_.hp, wCur_, d_.h));
             buildSchedule(d_.sh, d_.h, hr_.lo, hr_.hi - hr_.lo, tableH_);
             const ug_bases* setH[1] = {d_.H};
             void* outH[1] = {sums + 320};
-            ugCheck(ug_msm_batch_enqueue(d_.ctx, 1, setH, d_.sh, nullptr, outH));
+            ugCheck(ug_msm_batch_enqueue(d_.ctx2, 1, setH, d_.sh, nullptr, outH));
+            ugCheck(ug_ctx_collect(d_.ctx2));
             ugCheck(ug_ctx_collect(d_.ctx));
-            ugCheck(ug_ctx_timings(d_.ctx, &msmMs_, &fftMs_, 0));
+            collectTimings(3);
         }
         inFlight.done();
         finishWith(sums, r, s, terms.get(), proof, pub);
@@ -1404,7 +1450,7 @@ private:
     std::vector<uint8_t> vk_;
     void mark(const char* what) {
         if (!trace_) return;
-        ug_ctx_sync(d_.ctx);
+        ug_ctx_sync(d_.ctx); ug_ctx_sync(d_.ctx2);
         auto now = std::chrono::steady_clock::now();
         fprintf(stderr, "[ultragroth] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - tPhase_).count());
         tPhase_ = now;
@@ -1422,6 +1468,11 @@ private:
     int tableW_ = 0, tableC1_ = 0, tableC2_ = 0, tableH_ = 0;      // fixed-base table widths per schedule group (0: classic)
     DeviceProver d_;
     double msmMs_ = 0, fftMs_ = 0, totalMs_ = 0;
+    double m1_ = 0, f1_ = 0, m2_ = 0, f2_ = 0;                     // device ms per stream (witness stream, H branch)
+    int witnessQueued_ = 0;                                        // witnessMsmBegin .. witnessMsmEnd
+    uint8_t queuedParts_[UG_GROTH16_PARTIALS_SIZE] = {};
+public:
+    ug_ctx* ctx2() { return d_.ctx2; }                             // the H branch's context
 };
 
 
@@ -1605,8 +1656,8 @@ private:
 // The same for UltraGroth (src/ultra_groth.cpp:401-462): every rank keeps the whole witness and owns slices of the
 // witness-indexed sets, the round set, the final set and H. Per proof: the 64-byte parts of the round commitment are added on
 // the host, rank 0 closes the round (:173-176), every rank derives the challenge and completes its witness (:33-106), then
-// the final round runs as the Groth16 phases do; rank 0 blinds and serialises. (An UltraGroth rank has one stream: its
-// chain follows its MSMs.)
+// the final round runs as the Groth16 phases do (witness products queued, the H branch on its second stream beside them);
+// rank 0 blinds and serialises.
 class MultiUltraGrothProver : public ProverBase {
 public:
     MultiUltraGrothProver(const void* zkey, unsigned long long zkeySize, const std::vector<int>& devices) {
@@ -1626,12 +1677,12 @@ public:
         std::exception_ptr failure;
         for (auto& j : jobs) { try { j.get(); } catch (...) { if (!failure) failure = std::current_exception(); } }
         if (failure) { ranks_.clear(); std::rethrow_exception(failure); }
-        for (int c = 0; c < 3; c++) ugCheck(ug_dvec_create(ranks_[c % R]->ctx(), domain_, &full_[c]));
+        for (int c = 0; c < 3; c++) ugCheck(ug_dvec_create(ranks_[c % R]->ctx2(), domain_, &full_[c]));      // (the H branch's stream)
         slices_.resize(R);
         for (int k = 0; k < R; k++) {
             unsigned long long first = 0, cnt = 0;
             ranks_[k]->hRange(&first, &cnt, nullptr);
-            for (int c = 0; c < 3; c++) ugCheck(ug_dvec_create(ranks_[k]->ctx(), cnt ? cnt : 1, &slices_[k].v[c]));
+            for (int c = 0; c < 3; c++) ugCheck(ug_dvec_create(ranks_[k]->ctx2(), cnt ? cnt : 1, &slices_[k].v[c]));
         }
     }
     ~MultiUltraGrothProver() override {
@@ -1654,23 +1705,40 @@ public:
         for (int k = 1; k < R; k++) if (ug_g1_record_add(cparts[0].data(), cparts[k].data()) != PROVER_OK) throw std::runtime_error("partial sum failed");
         uint8_t commit[64];
         ranks_[0]->roundFinish(cparts[0].data(), commit);
-        // final round
+        // final round: as MultiGroth16Prover -- the witness products of every rank queued (witnessMsmBegin), its H branch driven
+        // beside them on its second stream; the only edges between the ranks are the three "chain c is complete" events
         std::vector<std::array<uint8_t, UG_GROTH16_PARTIALS_SIZE>> parts(R);
+        std::promise<void> chainDone[3];
+        std::shared_future<void> chainReady[3];
+        for (int c = 0; c < 3; c++) chainReady[c] = chainDone[c].get_future().share();
         everyRank([&](int k) {
             UltraGrothProver& p = *ranks_[k];
-            p.applyCommitment(commit);
-            p.runWitnessMsm(parts[k].data());
-            for (int c = k; c < 3; c += R) p.hpolyChain(c, ug_dvec_device_ptr(full_[c]));
-        });
-        everyRank([&](int k) {
-            UltraGrothProver& p = *ranks_[k];
-            unsigned long long first = 0, cnt = 0;
-            p.hRange(&first, &cnt, nullptr);
-            for (int c = 0; c < 3; c++) ugCheck(ug_dvec_copy(slices_[k].v[c], 0, full_[c], first, cnt));
-            p.hpolyCombine(ug_dvec_device_ptr(slices_[k].v[0]), ug_dvec_device_ptr(slices_[k].v[1]), ug_dvec_device_ptr(slices_[k].v[2]));
-            uint8_t hpart[UG_GROTH16_PARTIALS_SIZE];
-            p.runHMsm(hpart);
-            memcpy(parts[k].data() + 320, hpart + 320, 64);
+            bool told[3] = {false, false, false};
+            try {
+                p.applyCommitment(commit);
+                const bool chainFirst = R >= 5;                         // (see MultiGroth16Prover::prove)
+                if (!chainFirst) p.witnessMsmBegin();
+                for (int c = k; c < 3; c += R) {
+                    p.hpolyChain(c, ug_dvec_device_ptr(full_[c]));
+                    told[c] = true;
+                    chainDone[c].set_value();
+                }
+                if (chainFirst) p.witnessMsmBegin();
+                for (int c = 0; c < 3; c++) chainReady[c].get();        // (a chain rank's failure is rethrown here)
+                unsigned long long first = 0, cnt = 0;
+                p.hRange(&first, &cnt, nullptr);
+                for (int c = 0; c < 3; c++) ugCheck(ug_dvec_copy(slices_[k].v[c], 0, full_[c], first, cnt));
+                p.hpolyCombine(ug_dvec_device_ptr(slices_[k].v[0]), ug_dvec_device_ptr(slices_[k].v[1]), ug_dvec_device_ptr(slices_[k].v[2]));
+                uint8_t hpart[UG_GROTH16_PARTIALS_SIZE];
+                p.runHMsm(hpart);
+                p.witnessMsmEnd(parts[k].data());
+                memcpy(parts[k].data() + 320, hpart + 320, 64);
+            } catch (...) {
+                for (int c = k; c < 3; c += R)                          // nobody may wait for a chain that will not come
+                    if (!told[c]) chainDone[c].set_exception(std::current_exception());
+                p.witnessMsmAbandon();
+                throw;
+            }
         });
         for (int k = 1; k < R; k++)
             if (ug_groth16_partials_add(parts[0].data(), parts[k].data()) != PROVER_OK) throw std::runtime_error("partial sum failed");
