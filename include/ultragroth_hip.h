@@ -172,6 +172,10 @@ int  ug_msm_batch_enqueue(ug_ctx* ctx, int count, const ug_bases* const* bases, 
 int  ug_bases_create_group_g1(ug_ctx* ctx, int members, const void* const* host_points, const uint64_t* n, const uint64_t* first,
                               uint64_t group_first, uint64_t slots, int table_c, ug_bases** out);
 int  ug_bases_members(const ug_bases* bases);
+/* 1 when every one of the n records of `record_bytes` bytes at host_points is the point at infinity (all zero): such a set's products
+ * are the point at infinity, no kernel runs for them (ug_bases_create_* mark the set themselves), and a prover keeps it out of a
+ * base group. Stops at the first other record, i.e. at once for any real section. */
+int  ug_points_all_infinity(const void* host_points, uint64_t n, uint64_t record_bytes);
 int  ug_msm_group_enqueue(ug_ctx* ctx, const ug_bases* group, const ug_schedule* schedule, void* const* outs);
 int  ug_ctx_collect(ug_ctx* ctx);
 int  ug_ctx_wait(ug_ctx* waiter, ug_ctx* signal);

@@ -22,7 +22,7 @@ INNER_SYMBOLS = [
     "ug_msm_g1", "ug_msm_g2", "ug_msm_batch", "ug_msm_batch_enqueue", "ug_ctx_collect", "ug_ctx_wait",
     "ug_hpoly_create", "ug_hpoly_run", "ug_hpoly_chain", "ug_hpoly_combine", "ug_hpoly_debug_abc", "ug_hpoly_destroy",
     "ug_fr_ntt", "ug_field_op", "ug_synth_points", "ug_ctx_timings", "ug_ctx_kernel_stats", "ug_ctx_abandon", "ug_test_inject_fault",
-    "ug_bases_create_group_g1", "ug_bases_members", "ug_msm_group_enqueue", "ug_dvec_device_ptr", "ug_dvec_copy", "ug_sort_plan",
+    "ug_bases_create_group_g1", "ug_bases_members", "ug_points_all_infinity", "ug_msm_group_enqueue", "ug_dvec_device_ptr", "ug_dvec_copy", "ug_sort_plan",
     "ug_bases_drop_tables", "ug_bases_table_window", "ug_schedule_trim", "ug_ctx_trim",
 ]
 VERIFIER_SYMBOLS = ["groth16_verify", "ultra_groth_verify"]        # include/verifier.h
@@ -115,6 +115,7 @@ def load():
     L.ug_test_inject_fault.argtypes = [C.c_int, C.c_int]
     L.ug_bases_create_group_g1.argtypes = [vp, C.c_int, vp, vp, vp, u64, u64, C.c_int, pp]
     L.ug_bases_members.argtypes = [vp]
+    L.ug_points_all_infinity.argtypes = [vp, u64, u64]
     L.ug_msm_group_enqueue.argtypes = [vp, vp, vp, vp]
     L.ug_ctx_collect.argtypes = [vp]
     L.ug_dvec_device_ptr.argtypes = [vp]; L.ug_dvec_device_ptr.restype = vp

@@ -637,6 +637,10 @@ private:
         const uint64_t nw = wr_.hi - wr_.lo, nh = hr_.hi - hr_.lo;
         const uint64_t otherBytes = nw * (64 * 2 + 128) + (cHi - cLo) * 64 + nh * 64 + (haveHpoly_ ? hdr_.nCoefs * 80 + N * 32 * 5 + N * 100 : 0) +
                                     M * 32 + N * 32;
+        // (a section of nothing but points at infinity -- B1 and C of a "G1 MSM + NTT only" circuit, BASELINE configs[1] -- stays
+        // out of the group: as a set of its own it is marked empty and its product costs nothing)
+        const bool anyEmpty = ug_points_all_infinity(pA, nw, 64) || ug_points_all_infinity(pB1, nw, 64) || ug_points_all_infinity(pC, cHi - cLo, 64);
+        groupG1_ = fusedGroups() && !anyEmpty;
         std::vector<int> ahead = planTableWidthsAhead(d_.ctx, tableGroups(), otherBytes);
         bool withTables = true;
         auto create = [&](ug_ctx* ctx, bool g2, const uint8_t* pts, uint64_t n, uint64_t first, int width, ug_bases** out) {
@@ -647,7 +651,7 @@ private:
             }
             ugCheck(g2 ? ug_bases_create_g2(ctx, pts, n, first, out) : ug_bases_create_g1(ctx, pts, n, first, out));
         };
-        if (fusedGroups()) {
+        if (groupG1_) {
             // A, B1 and C (with its index shift folded into the slot numbers) as one interleaved group
             const void* hosts[3] = {pA, pB1, pC};
             const uint64_t counts[3] = {nw, nw, cHi - cLo}, firsts[3] = {wr_.lo, wr_.lo, cLo + hdr_.nPublic + 1};
@@ -688,7 +692,7 @@ private:
 public:
     std::vector<TableGroup> tableGroups() override {
         std::vector<TableGroup> groups(2);
-        if (d_.G || (!d_.A && fusedGroups())) { groups[0].g1 = {d_.G}; groups[0].n1 = {3 * (wr_.hi - wr_.lo)}; }      // (also before the sets exist)
+        if (d_.G || (!d_.A && groupG1_)) { groups[0].g1 = {d_.G}; groups[0].n1 = {3 * (wr_.hi - wr_.lo)}; }      // (also before the sets exist)
         else { groups[0].g1 = {d_.A, d_.B1, d_.C}; groups[0].n1 = {wr_.hi - wr_.lo, wr_.hi - wr_.lo, cHi_ - cLo_}; }
         groups[0].g2 = {d_.B2}; groups[0].n2 = {wr_.hi - wr_.lo};
         groups[0].scalars = wr_.hi - wr_.lo; groups[0].c = &tableW_;
@@ -1051,6 +1055,7 @@ private:
     uint64_t cLo_ = 0, cHi_ = 0;       // this rank's slice of the C section
     DeviceProver d_;
     bool witnessLoaded_ = false, witnessComplete_ = false, haveHpoly_ = true;
+    bool groupG1_ = true;              // A | B1 | C kept as one interleaved group (not when a member is all infinity, or ULTRAGROTH_FUSED=0)
     ug_dvec* wCur_ = nullptr;          // the witness the device part reads: one of the two buffers (d_.w, d_.w2 own them)
     WitnessBuffers witness_;
     double m1_ = 0, f1_ = 0, m2_ = 0, f2_ = 0, totalMs_ = 0;      // device ms of the MSM / FFT parts per stream

@@ -146,6 +146,8 @@ struct ug_bases {
     int table_c = 0;          // window width of the precomputed tables (0: none, pts holds the n points only)
     int members = 1;          // > 1: a group -- n = slots * members records, record slot * members + m is member m's point of
     u64 slots = 0;            //      scalar global_first + slot (ug_bases_create_group_g1)
+    bool empty = false;       // every record is the point at infinity (e.g. the B2 section of a circuit without B-side wires): its
+                              // products are the point at infinity and no kernel is launched for them
 };
 struct ug_dvec {
     ug_ctx* ctx; u64 n; u32* data; bool owns;
@@ -313,6 +315,14 @@ int ug_ctx_wait(ug_ctx* waiter, ug_ctx* signal) {
 // go straight into table 0, and the table kernel is queued on the context's stream without a host wait, so that the upload
 // of the caller's next section (staged through the uploader's own streams) runs beside it. Everything queued on the
 // context later is ordered behind the tables; ug_ctx_sync ends the build.
+static bool host_all_zero(const void* p, size_t bytes) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    size_t i = 0;
+    for (; i < bytes && ((uintptr_t)(b + i) & 7); i++) if (b[i]) return false;
+    for (; i + 8 <= bytes; i += 8) { uint64_t w; memcpy(&w, b + i, 8); if (w) return false; }
+    for (; i < bytes; i++) if (b[i]) return false;
+    return true;
+}
 static int bases_create(ug_ctx* c, const void* host, u64 n, u64 global_first, bool g2, int table_c, ug_bases** out) {
     UG_TRY
     if (!c || !out || (!host && n)) throw std::invalid_argument("null argument");
@@ -324,6 +334,7 @@ static int bases_create(ug_ctx* c, const void* host, u64 n, u64 global_first, bo
     }
     ug_bases* b = new ug_bases{c, g2, n, global_first, nullptr, 0};
     const size_t rec = g2 ? 128 : 64, bytes = (size_t)n * rec;
+    b->empty = n != 0 && host_all_zero(host, bytes);          // (stops at the first point that is not infinity: the first record, normally)
     if (hipMalloc(&b->pts, bytes ? bytes * (size_t)windows : 4) != hipSuccess) {
         (void)hipGetLastError();
         delete b;
@@ -403,6 +414,9 @@ int ug_bases_create_group_g1(ug_ctx* c, int members, const void* const* host, co
     UG_CATCH
 }
 int ug_bases_members(const ug_bases* b) { return b ? b->members : 0; }
+int ug_points_all_infinity(const void* host_points, uint64_t n, uint64_t record_bytes) {
+    return (host_points && n) ? (host_all_zero(host_points, (size_t)n * (size_t)record_bytes) ? 1 : 0) : 0;
+}
 int ug_msm_table_window(uint64_t n) { return MsmGeometry::table_window(n); }
 uint64_t ug_bases_tables_bytes(uint64_t n, int g2, int c) {
     if (c < TABLE_MIN_C || c > TABLE_MAX_C) return 0;
@@ -742,7 +756,7 @@ int ug_msm_g1(ug_ctx* c, const ug_bases* b, const ug_schedule* s, int64_t index_
     ScopedTimer tm(c, &c->msm_ms);
     int64_t delta = (int64_t)s->first - index_shift - (int64_t)b->global_first;
     if (!c->pending_msm.empty()) throw std::logic_error("collect the queued MSMs first (ug_ctx_collect)");
-    G1XYZZ r = msm_g1(s->sched, c->ws_g1, b->pts, b->n, delta, c->stream, &c->stats[0]);      // synchronises the stream
+    G1XYZZ r = msm_g1(s->sched, c->ws_g1, b->pts, b->empty ? 0 : b->n, delta, c->stream, &c->stats[0]);      // synchronises the stream
     tm.stop();
     sync_and_resolve(c);
     affine_out_g1((uint8_t*)out, r);
@@ -757,7 +771,7 @@ int ug_msm_g2(ug_ctx* c, const ug_bases* b, const ug_schedule* s, int64_t index_
     ScopedTimer tm(c, &c->msm_ms);
     int64_t delta = (int64_t)s->first - index_shift - (int64_t)b->global_first;
     if (!c->pending_msm.empty()) throw std::logic_error("collect the queued MSMs first (ug_ctx_collect)");
-    G2XYZZ r = msm_g2(s->sched, c->ws_g2, b->pts, b->n, delta, c->stream, &c->stats[1]);      // synchronises the stream
+    G2XYZZ r = msm_g2(s->sched, c->ws_g2, b->pts, b->empty ? 0 : b->n, delta, c->stream, &c->stats[1]);      // synchronises the stream
     tm.stop();
     sync_and_resolve(c);
     affine_out_g2((uint8_t*)out, r);
@@ -796,7 +810,7 @@ int ug_msm_batch_enqueue(ug_ctx* c, int count, const ug_bases* const* bases, con
             const u32* pts[MSM_BATCH_MAX]; u64 nb[MSM_BATCH_MAX]; int64_t delta[MSM_BATCH_MAX]; u32* host[MSM_BATCH_MAX]; MsmPending pend[MSM_BATCH_MAX];
             for (int q = 0; q < n; q++) {
                 const ug_bases* b = bases[idx[q]];
-                pts[q] = b->pts; nb[q] = b->n;
+                pts[q] = b->pts; nb[q] = b->empty ? 0 : b->n;      // (an all-infinity set takes no part: msm_enqueue_multi)
                 delta[q] = (int64_t)s->first - (index_shifts ? index_shifts[idx[q]] : 0) - (int64_t)b->global_first;
                 host[q] = c->pinned_results + (first_slot + idx[q]) * MSM_PENDING_WORDS;
             }
