@@ -111,6 +111,6 @@ for it in range(4):
     t_fin = time.perf_counter()
     walls.append([1e3 * (x - t) for x in (t_begin, t_chain, t_h, t_end, t_fin)])
 w = walls[-1]
-print("order %s, ULTRAGROTH_H_PRIORITY %s" % (order, os.environ.get("ULTRAGROTH_H_PRIORITY", "(default: high)")))
+print("order %s, ULTRAGROTH_H_PRIORITY %s" % (order, os.environ.get("ULTRAGROTH_H_PRIORITY", "(default: normal)")))
 print("queued form (ms after the start of the step): products queued %.2f  chains done %.2f  H product done %.2f  witness products done %.2f  "
       "finish %.2f   | wall of the last three steps %s" % (w[0], w[1], w[2], w[3], w[4], " ".join("%.2f" % x[4] for x in walls[1:])))
