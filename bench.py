@@ -193,7 +193,7 @@ def bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_r
             **extra,
         }))
 
-    if world == 1:
+    if dist is None:                             # (UG_BENCH_FORCE_DIST=1: the sharded path below over a process group of one rank)
         t0 = time.perf_counter()
         prover = ug.UltraGrothProver(zkey)
         create_s = time.perf_counter() - t0
@@ -264,7 +264,24 @@ def bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_r
         t = torch.frombuffer(bytearray(b), dtype=torch.uint8)
         return t.cuda() if cuda else t
 
+    # the small blocks of a proof (64-byte commitment parts, 384-byte partial sums) of all ranks: one collective into one
+    # preallocated buffer and one copy back through pinned memory, as on the Groth16 path
+    if cuda:
+        xmit = {n: torch.empty(n, dtype=torch.uint8, device="cuda") for n in (64, 384)}
+        recv = {n: torch.empty(n * world, dtype=torch.uint8, device="cuda") for n in (64, 384)}
+        stage = {n: torch.empty(n, dtype=torch.uint8).pin_memory() for n in (64, 384)}
+        landed = {n: torch.empty(n * world, dtype=torch.uint8).pin_memory() for n in (64, 384)}
+
     def gather_all(b):
+        n = len(b)
+        if cuda and n in xmit:
+            stage[n].copy_(torch.frombuffer(bytearray(b), dtype=torch.uint8))
+            xmit[n].copy_(stage[n], non_blocking=True)
+            dist.all_gather_into_tensor(recv[n], xmit[n])
+            landed[n].copy_(recv[n], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            raw = bytes(landed[n].numpy())
+            return [raw[n * q:n * (q + 1)] for q in range(world)]
         mine = to_comm(b)
         allp = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allp, mine)

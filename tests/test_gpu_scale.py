@@ -315,6 +315,22 @@ def test_bench_sharded_path_over_rccl_with_one_rank():
     assert d["prove_call_ms_per_step"] is None and d["pipelined_proofs_per_s"] is None
 
 
+def test_bench_ultragroth_sharded_path_over_rccl_with_one_rank():
+    """the same for `bench.py --ultra`: the sharded UltraGroth step -- all_gather_into_tensor of the commitment parts, broadcast of
+    the commitment, the queued final round, RCCL scatter of the evaluation slices, all_gather_into_tensor of the partial blocks --
+    over a real RCCL process group of one rank, --check bit-exact"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UG_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29642")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--ultra", "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--log-domain", "14", "--check"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["config"]["protocol"] == "ultragroth" and "bit-exact" in d["config"]["workload"]
+    assert "section-range shard x1, H-poly chains split over ranks" in d["config"]["parallelism"]
+
+
 def test_bench_line_contract_one_gpu():
     """`python bench.py` as the driver runs it at N = 1 (here at 2^16 so that it takes seconds): exactly one JSON line
     with the contract's keys, the `roofline` and `cpu_baseline` objects; the K timed steps run one after the other on the
