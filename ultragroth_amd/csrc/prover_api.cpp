@@ -1514,9 +1514,11 @@ std::vector<int> devicesFromEnv() {
 }
 
 // One iFFT/twist/FFT chain costs about this fraction of ALL the witness MSMs of a proof (2^24, tools/phase_times.py), so a
-// rank that also runs chains gets fewer points (the same split bench.py makes for its ranks)
+// rank that also runs chains gets fewer points (the same split bench.py makes for its ranks). (End of round 3: a chain is 5.9 ms
+// since the tiled mat-vec, 7.1 before; with 0.063 / 0.063 / 0.080 a chain rank of eight ended after 21.1 ms, a plain one after
+// 22.1: per point a rank's products cost 6.0 ms per million on top of 4.5 ms that do not depend on the slice.)
 std::vector<Range> balancedWitnessRanges(uint64_t nVars, int count) {
-    static const double CHAIN_SHARE[3] = {0.063, 0.063, 0.080};
+    static const double CHAIN_SHARE[3] = {0.058, 0.058, 0.070};
     std::vector<double> extra(count, 0.0), share(count);
     for (int c = 0; c < 3; c++) extra[c % count] += CHAIN_SHARE[c];
     double base = 1.0, tot = 0;
