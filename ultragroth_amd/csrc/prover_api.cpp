@@ -722,6 +722,7 @@ public:
     }
     // phase call (the caller drives the phases of one proof from one thread and holds no lock): staged like a proof's
     void loadWitness(const void* wtns, unsigned long long wtnsSize) override {
+        if (witnessQueued_ == 1) throw std::invalid_argument("the queued witness products still read the witness (ug_groth16_prover_witness_msm_end)");
         WitnessLease lease(witness_);
         stage(*lease, wtns, wtnsSize);
         std::lock_guard<std::mutex> turn(proveMutex);
@@ -1195,6 +1196,7 @@ public:
     // ---- phases (a sharded proof calls them one by one, see include/prover.h; proveTurn() below strings them together) ----
     // (the caller drives the phases of one proof from one thread and holds no lock)
     void loadWitness(const void* wtns, unsigned long long wtnsSize) override {
+        if (witnessQueued_ == 1) throw std::invalid_argument("the queued witness products still read the witness (ug_groth16_prover_witness_msm_end)");
         WitnessLease lease(witness_);
         stage(*lease, wtns, wtnsSize);
         std::lock_guard<std::mutex> turn(proveMutex);
