@@ -106,6 +106,17 @@ def test_msm_g1_edge_scalars(device, zkey, n):
     assert device.msm_g1(pts, sc, n) == O.g1_msm(pts, sc, n)
 
 
+def test_msm_all_zero_and_all_one_scalars(device, zkey):
+    """no entry at all (every digit is zero: the sort's drop mode leaves an empty schedule) and one entry per scalar, all in one bucket"""
+    n = 700
+    pts = _sec(zkey, "zkey", 5)[:64 * n]
+    assert device.msm_g1(pts, bytes(32 * n), n) == bytes(64)
+    ones = O.to_le(1) * n
+    assert device.msm_g1(pts, ones, n) == O.g1_msm(pts, ones, n)
+    pts2 = _sec(zkey, "zkey", 7)[:128 * 200]
+    assert device.msm_g2(pts2, bytes(32 * 200), 200) == bytes(128)
+
+
 def test_msm_heavy_bucket_and_duplicates(device, zkey):
     """many equal scalars on equal points: one giant bucket (block-parallel path) and the doubling branch"""
     rng = random.Random(5)
