@@ -26,6 +26,29 @@
  * G2 records are (x.a, x.b, y.a, y.b), 128 bytes; an all-zero record is the point at infinity; MSM
  * scalars and witness values are plain integers. Inputs may be unaligned (zkey sections start at
  * 4 mod 8); outputs are written with memcpy semantics.
+ *
+ * Environment variables read by libultragroth_hip.so (all optional; every setting of the first two groups gives correct
+ * results):
+ *
+ *   deployment         ULTRAGROTH_DEVICE=n        device of a prover made by the reference's create calls (default 0)
+ *                      ULTRAGROTH_DEVICES=a,b,..  one proof sharded over the listed devices behind the reference's API
+ *                      ULTRAGROTH_TABLES=0|1|2    fixed-base window tables: never | created provers (default) | one-shot calls too
+ *                      ULTRAGROTH_OVERLAP=0|1|2   H branch behind (default) / beside the witness products on one device
+ *                      ULTRAGROTH_FUSED=0         A, B1, C as separate base sets instead of one interleaved group
+ *                      ULTRAGROTH_SHARD=PxB       many-device layout: P base-point ranges x B bucket classes
+ *                      ULTRAGROTH_MAX_RANGE=n     scalars per schedule (tests: the piecewise path without a 2^27 circuit)
+ *                      ULTRAGROTH_UPLOAD_THREADS=n, ULTRAGROTH_H_PRIORITY=h|n|l, ULTRAGROTH_TRACE=1 (phase times on stderr)
+ *   tuning knobs       UG_MSM_C, UG_TABLE_C       window width of the classic / table schedules (default: cost model)
+ *                      UG_SEG_LANES_LOG, UG_SEG_TAPER   segment length of the accumulation (default 2^20 lanes, tapered end)
+ *                      UG_REDUCE_G1_LOG, UG_REDUCE_G2_LOG   lanes the bucket reduction keeps busy (default 17, 16)
+ *                      UG_UPLOAD_PRIORITY=l|n|h   stream class of the witness staging lanes (default l)
+ *   test hooks         ULTRAGROTH_TEST_HOOKS=1 enables ug_test_set_blinding / ULTRAGROTH_TEST_BLINDING and ug_test_inject_fault;
+ *                      without it those calls fail and the variables are ignored
+ *   measurement        NOT in this library: UG_SORT=cub (library sort, links hipcub), UG_GROUP_FOLD_LOG (gathers folded into
+ *                      cache: WRONG sums), UG_SORT_IPT / _SPL / _LBW / _DROP, UG_NTT_BATCH, UG_MATVEC_TILED exist only in the
+ *                      -DUG_MEASURE build (`make -C ultragroth_amd/csrc MEASURE=1 measure` -> libultragroth_hip_measure.so,
+ *                      loaded with ULTRAGROTH_LIB=<path> by the Python mirror); tests/test_abi.py checks that the product
+ *                      library holds none of these names and no hipcub symbol.
  */
 #ifndef ULTRAGROTH_HIP_H
 #define ULTRAGROTH_HIP_H

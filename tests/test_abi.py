@@ -115,6 +115,22 @@ def test_blinding_hook_is_gated():
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.split() == ["0", "0"]
 
 
+def test_product_library_holds_no_measurement_code():
+    """the A/B and measurement switches of finished experiments (one of them, UG_GROUP_FOLD_LOG, gives wrong sums) and the
+    library sort exist only in the -DUG_MEASURE build (include/ultragroth_hip.h, csrc/dev_common.hpp: measure_env): the
+    product library contains neither their names nor a hipcub / rocprim symbol"""
+    import subprocess
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"UG_GROUP_FOLD_LOG", b"UG_GROUP_ROTATE", b"UG_SORT_IPT", b"UG_SORT_SPL", b"UG_SORT_LBW", b"UG_SORT_DROP",
+                 b"UG_NTT_BATCH", b"UG_MATVEC_TILED", b"UG_SORT\0"):
+        assert name not in blob, name
+    syms = subprocess.run(["nm", "-C", _lib.LIB_PATH], capture_output=True, text=True).stdout.lower()
+    assert "hipcub" not in syms and "rocprim" not in syms
+    # ... while the knobs the header's table lists as part of the product are there
+    for name in (b"UG_TABLE_C", b"UG_SEG_LANES_LOG", b"ULTRAGROTH_DEVICES", b"ULTRAGROTH_TEST_HOOKS"):
+        assert name in blob, name
+
+
 def test_no_silent_cpu_fallback(lib, zkey):
     """without a GPU the compute entry points fail loudly"""
     if ug.device_count() > 0:

@@ -237,15 +237,12 @@ def test_msm_batch_equals_single_products(device, zkey, wtns):
         assert device.msm_batch([(b2, True)], s) == [got[2]]
 
 
-@pytest.mark.parametrize("rotate", ["0", "1"])
-def test_msm_group_equals_single_products(device, zkey, wtns, rotate, monkeypatch):
+def test_msm_group_equals_single_products(device, zkey, wtns):
     """ug_bases_create_group_g1 + ug_msm_group_enqueue: A, B1 and C of the fixture as ONE interleaved array of three-point
     records (C with its index shift folded into the slots: the first nPublic + 1 slots hold infinity for it), one
     accumulation launch with three accumulators per lane == the three separate products == the oracle; with and without
-    window tables, on sub-ranges (a sharded rank's slice, C cut by the slice), the two-member form (UltraGroth's A, B1), and
-    both code shapes of the kernel (UG_GROUP_ROTATE)"""
+    window tables, on sub-ranges (a sharded rank's slice, C cut by the slice), and the two-member form (UltraGroth's A, B1)"""
     import ultragroth_amd as ug
-    monkeypatch.setenv("UG_GROUP_ROTATE", rotate)
     info = O.zkey_info(zkey)
     n, shift = info["nVars"], info["nPublic"] + 1
     A, B1, Cs = _sec(zkey, "zkey", 5), _sec(zkey, "zkey", 6), _sec(zkey, "zkey", 8)

@@ -10,7 +10,8 @@ import subprocess
 import sys
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libultragroth_hip.so")
+# ULTRAGROTH_LIB: another build of the same library (tools: the -DUG_MEASURE build, libultragroth_hip_measure.so)
+LIB_PATH = os.environ.get("ULTRAGROTH_LIB") or os.path.join(_CSRC, "libultragroth_hip.so")
 
 # every symbol that include/ultragroth_hip.h and include/prover.h declare
 INNER_SYMBOLS = [

@@ -1,6 +1,7 @@
 // dev_common.hpp -- shared device-side helpers: error handling, packed 32-byte element I/O.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include "ec.hpp"
@@ -20,6 +21,17 @@ struct HipError : public std::runtime_error {
     } while (0)
 
 #define UG_KERNEL_CHECK() UG_HIP(hipGetLastError())
+
+// Environment switches come in two kinds (the table in include/ultragroth_hip.h lists both):
+//   tuning knobs        getenv(): every setting gives correct results, the default is the measured best
+//   measurement switches  measure_env(): A/B switches of finished experiments and settings that give WRONG results (folded
+//                       gathers). They exist only in a -DUG_MEASURE build (`make MEASURE=1` -> libultragroth_hip_measure.so);
+//                       the product library reads none of them.
+#ifdef UG_MEASURE
+inline const char* measure_env(const char* name) { return getenv(name); }
+#else
+inline const char* measure_env(const char*) { return nullptr; }
+#endif
 
 // ---- 32-byte packed elements in HBM: two 16-byte vector accesses -----------------------------------
 __device__ __forceinline__ void load8(u32* w, const u32* p) {

@@ -290,7 +290,7 @@ void CoefMatrix::release() {
 }
 
 void coef_matvec(u32* a_br, u32* b_br, const CoefMatrix& m, const u32* wtns_dev, int mask, hipStream_t stream) {
-    static const bool tiled = !(getenv("UG_MATVEC_TILED") && atoi(getenv("UG_MATVEC_TILED")) == 0);      // A/B knob
+    static const bool tiled = !(measure_env("UG_MATVEC_TILED") && atoi(measure_env("UG_MATVEC_TILED")) == 0);      // A/B switch (-DUG_MEASURE)
     if (m.logn >= 8 && tiled)
         hipLaunchKernelGGL(matvec_tiled_kernel, dim3(2 * (m.domain >> 8)), dim3(256), 0, stream,
                            a_br, b_br, m.row_ptr, m.sig, m.val, wtns_dev, m.domain, m.logn, mask);

@@ -27,7 +27,9 @@
 //
 // Arithmetic volume dominates: each of the n * windows gathered bases costs one mixed addition
 // (G1: 8 mul + 2 sqr in Fq, G2: the same in Fq2). Algorithmic HBM bytes: 96 n (G1) / 160 n (G2).
-#include <hipcub/hipcub.hpp>
+#ifdef UG_MEASURE
+#include <hipcub/hipcub.hpp>      // the library sort of rounds 1-2, kept for A/B runs (UG_SORT=cub) in -DUG_MEASURE builds only
+#endif
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -387,22 +389,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Cfg::ACC_WA
 // addition runs as fast as at three (profiles/r02_ubench_madd.txt). Only ONE 16-register record is in flight: the loads
 // rotate through the members -- while member m is added, member m + 1 (or member 0 of the next entry) is on its way, a whole
 // mixed addition (3 us) ahead of its use.
-// ROTATE: the K additions are one rolled loop over accumulator 0 with the accumulators rotated between turns (one
-// addition's code instead of K copies of it in the loop body).
 // Measured at 2^24 (round 3, profiles/r03_variants_ab.txt): the launch takes what the three single launches took (44.2 ms
 // against 3 x 14.8): the kernel is bound by the instruction stream of the addition, so what the group saves is the entry
-// list's two extra reads and two launches, not time. With every gather folded into cache (UG_GROUP_FOLD_LOG) it takes 40.4 ms:
-// the gathers' latency is worth 9 %, but neither the rotation nor all K records of an entry fetched together by LDS-DMA
+// list's two extra reads and two launches, not time. With every gather folded into cache (UG_GROUP_FOLD_LOG, a -DUG_MEASURE
+// build) it takes 40.4 ms: the gathers' latency is worth 9 %, but neither a rolled loop over rotating accumulators (one
+// addition's code instead of K copies; measured in round 3, removed) nor all K records of an entry fetched together by LDS-DMA
 // (global_load_lds_dwordx4 into a per-wave region, built and verified bit-exact, 43.8 against 43.5 ms, not kept) gets any of
 // it back: the limit is the latency of a random access into 36 GiB (translation + DRAM), one addition's time ahead is all a
 // lane can look with its registers full, and adjacent pieces do not make that access shorter. Touching the records two or three
 // turns ahead with one-dword LDS-DMA loads (no registers) makes the launch 9 % SLOWER (48.6 ms): vector-memory results retire in
 // order, so the real load behind a touch that misses waits for that miss -- the latency moves, it does not shrink.
-template <int K, bool ROTATE>
+#ifdef UG_MEASURE
+#define UG_FOLD_PARAM , u32 fold_mask
+#else
+#define UG_FOLD_PARAM
+#endif
+template <int K>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void segment_accumulate_group_kernel(
         const u32* __restrict__ bases, u64 n_slots, int64_t delta, const u32* __restrict__ keys, const u32* __restrict__ tkeys,
         const u32* __restrict__ tvals, const u32* __restrict__ meta, int log_a, int log_b, u32* __restrict__ bucket_pts,
-        u32* __restrict__ slot_pts, size_t bucket_stride, size_t slot_stride, u32 fold_mask) {
+        u32* __restrict__ slot_pts, size_t bucket_stride, size_t slot_stride UG_FOLD_PARAM) {
     typedef G1Cfg Cfg;
     typedef Fq F;
     const u32 n_valid = meta[1];
@@ -420,10 +426,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     XYZZ<F> acc[K];
     StaticFor<0, K>::up([&](auto m) { acc[m] = xyzz_inf<F>(); });
     const u32 IDX_MASK = (1u << TABLE_INDEX_BITS) - 1;
-    // (fold_mask: measurement only -- UG_GROUP_FOLD_LOG folds every gather into the first 2^log records of table 0, i.e. into
-    // cache: what the launch would take without DRAM misses; sums are then wrong, ~0u leaves the addresses alone)
     auto record = [&](u32 val, int64_t idx, int m) -> const u32* {
+#ifdef UG_MEASURE
+        // measurement builds only -- UG_GROUP_FOLD_LOG folds every gather into the first 2^log records of table 0, i.e. into cache:
+        // what the launch would take without DRAM misses; the sums are then WRONG (~0u leaves the addresses alone)
         if (fold_mask != ~0u) return bases + (((u64)idx & fold_mask) * K + (u64)m) * Cfg::AFF_WORDS;
+#endif
         return bases + (((u64)((val >> TABLE_INDEX_BITS) & 15u) * n_slots + (u64)idx) * K + (u64)m) * Cfg::AFF_WORDS;
     };
     auto flush = [&](bool to_slot, size_t slot, u32 bucket) {
@@ -455,29 +463,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             cur = key;
             first_run = false;
         }
-        if constexpr (ROTATE) {
-#pragma unroll 1
-            for (int m = 0; m < K; m++) {
-                F x, y;
-                const bool valid = in && Cfg::decode_affine(raw, x, y);
-                if (m + 1 < K) { if (in) Cfg::load_raw(raw, record(val, idx, m + 1)); }
-                else if (more && nin) Cfg::load_raw(raw, record(nval, nidx, 0));
-                if (valid && (val >> 31)) y = neg<1>(y);
-                if (valid) acc[0] = xyzz_madd(acc[0], x, y);
-                XYZZ<F> turn = acc[0];
-                StaticFor<0, K - 1>::up([&](auto q) { acc[q] = acc[q + 1]; });
-                acc[K - 1] = turn;
-            }
-        } else {
-            StaticFor<0, K>::up([&](auto m) {
-                F x, y;
-                const bool valid = in && Cfg::decode_affine(raw, x, y);
-                if (m + 1 < K) { if (in) Cfg::load_raw(raw, record(val, idx, m + 1)); }
-                else if (more && nin) Cfg::load_raw(raw, record(nval, nidx, 0));
-                if (valid && (val >> 31)) y = neg<1>(y);
-                if (valid) acc[m] = xyzz_madd(acc[m], x, y);
-            });
-        }
+        StaticFor<0, K>::up([&](auto m) {
+            F x, y;
+            const bool valid = in && Cfg::decode_affine(raw, x, y);
+            if (m + 1 < K) { if (in) Cfg::load_raw(raw, record(val, idx, m + 1)); }
+            else if (more && nin) Cfg::load_raw(raw, record(nval, nidx, 0));
+            if (valid && (val >> 31)) y = neg<1>(y);
+            if (valid) acc[m] = xyzz_madd(acc[m], x, y);
+        });
     }
     const bool end_open = hi < n_valid && keys[hi] == cur;
     if (first_run && start_open) flush(true, (size_t)2 * t, 0);
@@ -876,7 +869,8 @@ void MsmSchedule::reserve(const MsmGeometry& g) {
 
 void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_t stream) {
     // limits first: reserve() hands `total` to the sort as an int
-    if (g.n * (u64)g.windows >= ((u64)1 << 31)) throw std::invalid_argument("msm: n * windows exceeds 2^31 entries");
+    // (2^30: a look-back status word of the sort carries a 30-bit pair count, sort.hip -- one bin may hold every pair)
+    if (g.n * (u64)g.windows > ((u64)1 << 30)) throw std::invalid_argument("msm: n * windows exceeds 2^30 entries");
     if (g.n > ((u64)1 << TABLE_INDEX_BITS)) throw std::invalid_argument("msm: more than 2^27 scalars in one schedule");
     geo = g;
     reserve(g);
@@ -892,9 +886,13 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
     int end_bit = 1;
     while (((u64)1 << end_bit) <= sentinel) end_bit++;
     UG_HIP(hipMemsetAsync(meta, 0, 32, stream));
-    // UG_SORT=cub: the library sort of rounds 1-2 (A/B runs); default: the hand-written partition of sort.hip, whose first
-    // pass reads the scalars themselves (pairs in unsorted form are written only when a scalar has more than 16 windows)
+    // the hand-written partition of sort.hip, whose first pass reads the scalars themselves (pairs in unsorted form are written
+    // only when a scalar has more than 16 windows). -DUG_MEASURE builds: UG_SORT=cub takes the library sort of rounds 1-2 (A/B runs)
+#ifdef UG_MEASURE
     static const bool use_cub = getenv("UG_SORT") && !strcmp(getenv("UG_SORT"), "cub");
+#else
+    constexpr bool use_cub = false;
+#endif
     const bool pairs_first = use_cub || g.windows > 16;
     bool dropped = false;                 // the sort left out the zero digits and wrote the entry count to meta[1] itself
     if (pairs_first) {
@@ -902,6 +900,7 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
                            scalars_dev, g.n, g.c, g.windows, g.buckets, sentinel, g.tables ? 1 : 0, keys_a, vals_a);
         UG_KERNEL_CHECK();
     }
+#ifdef UG_MEASURE
     if (use_cub) {
         hipcub::DoubleBuffer<u32> dk(keys_a, keys_b), dv(vals_a, vals_b);
         if (!sort_tmp_bytes) {
@@ -913,7 +912,9 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
         UG_HIP(hipcub::DeviceRadixSort::SortPairs(sort_tmp, tmp, dk, dv, (int)total, 0, end_bit, stream));
         keys = dk.Current();
         vals = dv.Current();
-    } else {
+    } else
+#endif
+    {
         u32* const bk[2] = {keys_a, keys_b};
         u32* const bv[2] = {vals_a, vals_b};
         const int at = sorter.sort(pairs_first ? nullptr : scalars_dev, g.n, g.c, g.windows, g.buckets, sentinel, g.tables, total, end_bit, bk, bv,
@@ -996,7 +997,7 @@ void msm_enqueue_multi(const MsmSchedule& s, MsmWorkspace& ws, int count, const 
         pend[j].g2 = Cfg::PT_WORDS == G2Cfg::PT_WORDS;
         pend[j].c = g.c; pend[j].bucket_windows = g.bucket_windows(); pend[j].host = pinned_host[j];
         if (g.n == 0 || n_bases[group ? 0 : j] == 0) continue;
-        if ((size_t)pend[j].bucket_windows * Cfg::PT_WORDS > MSM_PENDING_WORDS) throw std::logic_error("msm: result block too large");
+        if ((size_t)pend[j].bucket_windows * Cfg::PT_WORDS > MSM_PENDING_WORDS - 1) throw std::logic_error("msm: result block too large");
         pend[j].empty = false;
         live[k++] = j;
     }
@@ -1014,21 +1015,24 @@ void msm_enqueue_multi(const MsmSchedule& s, MsmWorkspace& ws, int count, const 
                  task_stride = (size_t)tasks_max * Cfg::PT_WORDS;
     if constexpr (Cfg::PT_WORDS == G1Cfg::PT_WORDS) {
         if (group) {                                 // (all K products are live, or none: they share the slot count)
-            const char* rot = getenv("UG_GROUP_ROTATE");                      // tuning knob, read per launch (the tests take both shapes)
-            const bool rotate = rot && atoi(rot) != 0;
-            const char* fold = getenv("UG_GROUP_FOLD_LOG");                   // measurement knob (wrong sums): see the kernel
+#ifdef UG_MEASURE
+            const char* fold = getenv("UG_GROUP_FOLD_LOG");                   // measurement knob (WRONG sums): see the kernel
             const u32 fold_mask = fold && *fold ? ((1u << atoi(fold)) - 1) : ~0u;
-
+#define UG_FOLD_ARG , fold_mask
+#else
+#define UG_FOLD_ARG
+#endif
             int slot = stats ? stats->begin(stream, g.n * g.windows * (u64)group) : -1;
             if (nseg) {
                 const dim3 grid((unsigned)((nseg + 255) / 256)), block(256);
-#define UG_GROUP_LAUNCH(K_, R_) hipLaunchKernelGGL((segment_accumulate_group_kernel<K_, R_>), grid, block, 0, stream, bases[0], n_bases[0], \
+#define UG_GROUP_LAUNCH(K_) hipLaunchKernelGGL((segment_accumulate_group_kernel<K_>), grid, block, 0, stream, bases[0], n_bases[0], \
                                                    delta[0], s.keys, s.tkeys, s.tvals, s.meta, s.log_seg, s.log_seg_tail, ws.bucket_pts, ws.slot_pts,   \
-                                                   bucket_stride, slot_stride, fold_mask)
-                if (group == 3) { if (rotate) UG_GROUP_LAUNCH(3, true); else UG_GROUP_LAUNCH(3, false); }
-                else if (group == 2) { if (rotate) UG_GROUP_LAUNCH(2, true); else UG_GROUP_LAUNCH(2, false); }
+                                                   bucket_stride, slot_stride UG_FOLD_ARG)
+                if (group == 3) UG_GROUP_LAUNCH(3);
+                else if (group == 2) UG_GROUP_LAUNCH(2);
                 else throw std::logic_error("msm: group size");
 #undef UG_GROUP_LAUNCH
+#undef UG_FOLD_ARG
                 UG_KERNEL_CHECK();
             }
             if (stats) stats->end(slot, stream);

@@ -873,6 +873,7 @@ public:
     void witnessMsmAbandon() {
         if (witnessQueued_ == 1) ug_ctx_abandon(d_.ctx);
         witnessQueued_ = 0;
+        if (earlyTerms_.valid()) { earlyTerms_.wait(); earlyTerms_ = std::future<BlindingTerms>(); }     // the abandoned proof's r, s are dropped with it
     }
     // S10 on this rank's slice of h (which must be in d_.h); only the H record of partials is written
     void runHMsm(uint8_t* partials) override { runHMsmImpl(partials, true); }

@@ -314,7 +314,8 @@ int radix_plan(int bits, int* shift, int* bins_log) {
 }
 
 void RadixSorter::reserve(u64 n_pairs, int ipt_min) {
-    const u64 tiles = n_pairs / ((u64)SORT_THREADS * (u64)(ipt_min < 1 ? 1 : ipt_min)) + 2;
+    // (later passes move the pair count rounded up to the FIRST pass's tile, at most 256 * 16 - 1 pairs more, in tiles of their own)
+    const u64 tiles = (n_pairs + (u64)SORT_THREADS * SORT_MAX_IPT) / ((u64)SORT_THREADS * (u64)(ipt_min < 1 ? 1 : ipt_min)) + 2;
     if (tiles > tiles_cap) {
         sort_alloc(lookback, (size_t)tiles * SORT_MAX_BINS * 4);
         tiles_cap = tiles;
@@ -340,12 +341,12 @@ int RadixSorter::sort(const u32* scalars, u64 n, int c, int windows, u32 buckets
     int shift[4], bins_log[4];
     const int passes = radix_plan(bits, shift, bins_log);
     if (passes > 4) throw std::logic_error("radix sort: key too wide");
-    // tuning knobs: pairs per lane of the pair-form passes, scalars per lane of the fused first pass
-    static const int env_ipt = getenv("UG_SORT_IPT") ? atoi(getenv("UG_SORT_IPT")) : 16;
-    static const int env_spl = getenv("UG_SORT_SPL") ? atoi(getenv("UG_SORT_SPL")) : 1;
+    // measurement switches (-DUG_MEASURE builds): pairs per lane of the pair-form passes, scalars per lane of the fused first pass
+    static const int env_ipt = measure_env("UG_SORT_IPT") ? atoi(measure_env("UG_SORT_IPT")) : 16;
+    static const int env_spl = measure_env("UG_SORT_SPL") ? atoi(measure_env("UG_SORT_SPL")) : 1;
     const int ipt_pairs = env_ipt < 4 ? 4 : env_ipt > SORT_MAX_IPT ? SORT_MAX_IPT : env_ipt;
     const bool fused = scalars != nullptr && windows <= SORT_FUSED_MAX_WINDOWS;
-    static const bool drop_ok = !(getenv("UG_SORT_DROP") && atoi(getenv("UG_SORT_DROP")) == 0);      // A/B knob
+    static const bool drop_ok = !(measure_env("UG_SORT_DROP") && atoi(measure_env("UG_SORT_DROP")) == 0);      // A/B switch
     const bool drop = fused && n_valid_out != nullptr && drop_ok;
     if (dropped_out) *dropped_out = drop;
     int spl = 1;
@@ -399,7 +400,7 @@ int RadixSorter::sort(const u32* scalars, u64 n, int c, int windows, u32 buckets
         if (tiles > tiles_cap) throw std::logic_error("radix sort: look-back table too small");
         UG_HIP(hipMemsetAsync(lookback, 0, (size_t)tiles * ((size_t)1 << bins_log[p]) * 4, stream));
         const size_t lds = (2 * T + SORT_WAVES * SORT_MAX_BINS + 2 * SORT_MAX_BINS + 8) * 4;
-        static const int lbw = getenv("UG_SORT_LBW") ? atoi(getenv("UG_SORT_LBW")) : 4;      // tuning knob: look-back window
+        static const int lbw = measure_env("UG_SORT_LBW") ? atoi(measure_env("UG_SORT_LBW")) : 4;      // A/B switch: look-back window
         if (lbw >= 16) {
             if (first_fused) hipLaunchKernelGGL((radix_pass_kernel<true, 16>), dim3((unsigned)tiles), dim3(SORT_THREADS), lds, stream, a);
             else hipLaunchKernelGGL((radix_pass_kernel<false, 16>), dim3((unsigned)tiles), dim3(SORT_THREADS), lds, stream, a);

@@ -947,7 +947,7 @@ int ug_hpoly_run(ug_hpoly* hp, const ug_dvec* w, ug_dvec* h_out) {
         tm.stop();
         return UG_OK;
     }
-    static const bool batched = !(getenv("UG_NTT_BATCH") && atoi(getenv("UG_NTT_BATCH")) == 0);      // tuning knob (A/B)
+    static const bool batched = !(measure_env("UG_NTT_BATCH") && atoi(measure_env("UG_NTT_BATCH")) == 0);      // A/B switch (-DUG_MEASURE)
     NttPass pa[NTT_MAX_PASSES], pb[NTT_MAX_PASSES], pc[NTT_MAX_PASSES];
     NttFusion cinv; cinv.in2 = hp->b; cinv.work = hp->c;
     NttFusion cfwd; cfwd.work = hp->c; cfwd.fin_a = hp->a; cfwd.fin_b = hp->b;
