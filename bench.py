@@ -368,14 +368,14 @@ def bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_r
         chk = step()
         ug.set_test_blinding(b"")
     ok = True
+    dist.barrier()
+    dist.destroy_process_group()          # before rank 0's host-side comparison (the CPU oracle proves the circuit): nobody waits in a collective
     if rank == 0:
         if args.check:
             ok = chk == expected()
             workload += " [check: %s]" % ("bit-exact" if ok else "MISMATCH")
         line(float(t.item()), msm_ms, fft_ms, create_s,
              "section-range shard x%d%s" % (world, ", H-poly chains split over ranks" if split_h else ""))
-    dist.barrier()
-    dist.destroy_process_group()
     if not ok:
         sys.exit(3)
 
@@ -654,6 +654,20 @@ def main():
                 chk = ("groth16_prover_prove differs from the phase calls", "")
         ug.set_test_blinding(b"")
 
+    # The process group ends HERE, before rank 0 assembles the line: what follows on rank 0 (the --check comparison, which
+    # synthesises the whole circuit once more; at N = 1 the CPU baseline) is host work of tens of seconds, and the other ranks
+    # must not sit in a collective -- spinning on their GPUs -- while it runs: they are done and exit.
+    comm = None
+    if dist is not None:
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:
+            ver = None
+        comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": ver,
+                "devices_visible": torch.cuda.device_count()}
+        dist.barrier()
+        dist.destroy_process_group()
+
     rc = 0
     if rank == 0:
         (acc_ms, launches, entries), (g2_ms, g2_launches, g2_entries), (ntt_ms, ntt_launches, ntt_points) = kstats[:3]
@@ -712,14 +726,6 @@ def main():
         roofline["note"] = ("the kernel with the largest share of a step; integer-issue-bound kernels: issue_bound gives modmul work against the "
                             "v_mad_u64_u32 peak (DESIGN.md)")
         ms_per_step = 1e3 * elapsed / args.steps
-        comm = None
-        if dist is not None:
-            try:
-                ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
-            except Exception:
-                ver = None
-            comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": ver,
-                    "devices_visible": torch.cuda.device_count()}
         res = {
             "metric": "proofs/s", "value": args.steps / elapsed, "unit": "proofs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -748,7 +754,12 @@ def main():
             "host_peak_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 2),
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline:
+        # the CPU baseline is a figure of the N = 1 line (run contract: "on rank 0 at N = 1 only"); the N > 1 lines of a scaling run
+        # carry null and say why, and no rank waits for forty seconds of OpenMP
+        if world > 1:
+            res["cpu_baseline"] = None
+            res["cpu_baseline_note"] = "measured at N = 1 only (run contract); see the N = 1 line of the same build"
+        elif not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(dev, args, log_domain, (zkey, wtns) if zkey is not None else None)
         if args.check:
             from oracle import closed_form
@@ -761,9 +772,6 @@ def main():
             res["check"] = "bit-exact" if ok else "MISMATCH"
             rc = 0 if ok else 3
         print(json.dumps(res))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
     if rc:
         sys.exit(rc)
 

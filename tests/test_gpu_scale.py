@@ -296,6 +296,43 @@ def test_bench_two_ranks_over_rccl():
         assert line["n_gpus"] == 2 and ("bit-exact" in (line.get("check") or line["config"]["workload"]))
 
 
+def test_bench_driver_line_with_five_ranks_over_gloo():
+    """The driver's own launch line for a many-GPU run -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W`, no other flag -- with N = 5 ranks sharing
+    the one device over gloo (RCCL refuses two ranks on one device, and this pool allows six GPU processes: five ranks beside
+    the test runner; N = 8 itself is the driver's to launch), at 2^16 so that it takes seconds. More than three ranks means
+    ranks without a chain, chain-first order, slices of different length. The whole JSON contract of the line is asserted;
+    `cpu_baseline` is null at N > 1 (the run contract measures it at N = 1 only) and says so; every rank has left its process
+    group before rank 0 prints."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UG_BENCH_BACKEND="gloo", UG_BENCH_ONE_DEVICE="1", OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "5", "--master-addr", "127.0.0.1",
+                        "--master-port", "29633", os.path.join(root, "bench.py"), "--gpus", "5", "--steps", "2", "--warmup", "1",
+                        "--log-domain", "16"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "comm"):
+        assert key in d, key
+    assert d["metric"] == "proofs/s" and d["n_gpus"] == 5 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert abs(d["value"] * d["ms_per_step"] - 1e3) < 1e-3
+    assert d["comm"] == {"backend": "gloo", "world_size": 5, "rccl_version": None, "devices_visible": d["comm"]["devices_visible"]}
+    assert d["cpu_baseline"] is None and "N = 1" in d["cpu_baseline_note"]
+    assert "x5" in d["config"]["parallelism"] and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["launches"] > 0 and 0 < rf["frac"] < 1
+    # the same launch with --check: the five ranks' proof is the single-device proof, byte for byte
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "5", "--master-addr", "127.0.0.1",
+                        "--master-port", "29634", os.path.join(root, "bench.py"), "--gpus", "5", "--steps", "1", "--warmup", "1",
+                        "--log-domain", "16", "--check"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])["check"] == "bit-exact"
+
+
 def test_bench_sharded_path_over_rccl_with_one_rank():
     """A one-GPU box cannot host two RCCL ranks, but it can run the sharded code path of bench.py over a REAL RCCL process group
     of one rank (UG_BENCH_FORCE_DIST=1): slices-only creation, the witness in two parts, the chains on their own thread, RCCL
