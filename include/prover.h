@@ -189,6 +189,31 @@ int ug_groth16_prover_create_sharded_slices(void **prover_object, const void *zk
                                             int device, int shard_rank, int shard_count,
                                             const unsigned long long *witness_range,
                                             char *error_msg, unsigned long long error_msg_maxsize);
+/* THE LAYOUT OF A MANY-DEVICE PROVER. The witness products can be cut over the ranks in two ways, and in
+ * any product of the two: by BASE-POINT RANGE (a rank holds a contiguous range of the points and scalars: the functions above)
+ * and by BUCKET CLASS (the ranks of a group hold the SAME range with its whole window tables, and each takes the bucket ids of
+ * its residues mod 2^q_log: it sorts, accumulates and reduces a share of the entries at the full range's window width).
+ * ug_groth16_shard_layout gives rank `shard_rank` of `shard_count` its part of the layout the library would use itself
+ * (ULTRAGROTH_DEVICES): point_ranges = the number of base-point ranges P (shard_count / P ranks share each; P = shard_count is
+ * the base-point form), 0 = chosen here -- ULTRAGROTH_SHARD=PxB, else bucket classes from four ranks on in as few ranges as let a
+ * range's window tables fit a device of hbm_bytes (0 = 256 GiB). The shares are balanced for the ranks that also run an
+ * H-polynomial chain (bit k of out[11]: chain k); the H product is cut by range, and with five ranks or more the chain ranks
+ * take none of it (their H range is empty).
+ *   out[12] = { witness first, end | C first, end | H first, end | q_log (0 = no classes), first residue, residues |
+ *               first, end of the scalars whose special (lowest) buckets the rank owns | chains bitmask }
+ * A pure function of its arguments and ULTRAGROTH_SHARD: every rank of a launcher computes the same layout.
+ * ug_groth16_prover_create_sharded_layout: as _create_sharded_slices (the slices are those of out[0..5]), with the layout. */
+int ug_groth16_shard_layout(unsigned long long n_vars, unsigned long long n_public, unsigned long long domain_size,
+                            int shard_rank, int shard_count, int point_ranges, unsigned long long hbm_bytes,
+                            unsigned long long out[12]);
+int ug_groth16_prover_create_sharded_layout(void **prover_object, const void *zkey_header, unsigned long long zkey_header_size,
+                                            const void *coefs, unsigned long long n_coefs,
+                                            const void *points_a, const void *points_b1, const void *points_b2,
+                                            const void *points_c, const void *points_h,
+                                            const unsigned long long slice_bytes[5],
+                                            int device, int shard_rank, int shard_count,
+                                            const unsigned long long layout[12],
+                                            char *error_msg, unsigned long long error_msg_maxsize);
 /* upload the witness (wtns file buffer) to the device; returns PROVER_INVALID_WITNESS_LENGTH etc. */
 int ug_groth16_prover_load_witness(void *prover_object, const void *wtns_buffer, unsigned long long wtns_size,
                                    char *error_msg, unsigned long long error_msg_maxsize);

@@ -166,6 +166,16 @@ int  ug_ctx_trim(ug_ctx* ctx);
 int  ug_schedule_build(ug_schedule* s, const ug_dvec* scalars, uint64_t first, uint64_t count);
 /* the same for base sets that hold window tables of width c (ug_bases_precompute); count <= 2^27 */
 int  ug_schedule_build_tables(ug_schedule* s, const ug_dvec* scalars, uint64_t first, uint64_t count, int c);
+/* BUCKET CLASSES (a many-device prover that shards the witness products by bucket instead of by base point; DESIGN.md section 7,
+ * no counterpart in the reference): every later build of the schedule keeps only the (scalar, window) digits whose bucket
+ * b = |digit| - 1 has b mod 2^q_log in [first_residue, first_residue + residues) -- except the lowest `specials` (<= 64) bucket ids
+ * of every window, the digits small witness values pile up in: those are kept iff their scalar's index (in the scalar vector) lies in
+ * [special_first, special_first + special_count). Schedules built over the SAME scalars and base sets whose residue ranges tile
+ * [0, 2^q_log) and whose special ranges tile the scalars give products that ADD UP to the product of the plain schedule: each
+ * holds its share of the entries at the plain schedule's window width and reduces only its share of the buckets. q_log = 0
+ * switches the classes off. Needs a window of at least q_log + 4 bits (ug_schedule_build* fail otherwise). */
+int  ug_schedule_set_classes(ug_schedule* s, int q_log, uint32_t first_residue, uint32_t residues, uint32_t specials,
+                             uint64_t special_first, uint64_t special_count);
 void ug_schedule_destroy(ug_schedule* s);
 
 /* out = sum over the schedule's scalars s_i (global index i) of s_i * P_{i - index_shift}; points whose

@@ -169,6 +169,84 @@ def test_msm_window_tables_g2(device, zkey, n, c):
     assert device.msm_g2(pts, sc, n, table_c=c) == O.g2_msm(pts, sc, n)
 
 
+def _class_tilings(rng, q_log, parts, n):
+    """`parts` residue ranges that tile [0, 2^q_log) and as many scalar ranges that tile [0, n), both uneven"""
+    Q = 1 << q_log
+    sizes = [Q // parts + (1 if k < Q % parts else 0) for k in range(parts)]
+    for _ in range(4 * parts):                      # uneven, every range within 1 .. 31 residues (a result block holds 63 points)
+        a, b = rng.randrange(parts), rng.randrange(parts)
+        d = rng.randrange(0, 8)
+        if a != b and sizes[a] - d >= 1 and sizes[b] + d <= 31:
+            sizes[a] -= d; sizes[b] += d
+    cuts = [sum(sizes[:k]) for k in range(1, parts)]
+    res = list(zip([0] + cuts, cuts + [Q]))
+    scuts = sorted(rng.randrange(0, n + 1) for _ in range(parts - 1))
+    sp = list(zip([0] + scuts, scuts + [n]))
+    return res, sp
+
+
+@pytest.mark.parametrize("table_c,q_log,parts,specials", [(16, 3, 8, 16), (16, 7, 5, 16), (18, 2, 3, 0), (17, 4, 16, 64), (20, 6, 4, 1)])
+def test_msm_bucket_classes_add_up(device, zkey, table_c, q_log, parts, specials):
+    """ug_schedule_set_classes (bucket-range sharding of a many-device prover): schedules over the SAME
+    scalars and bases that own disjoint residue ranges of the bucket ids -- and disjoint scalar ranges of the special (lowest)
+    buckets -- give products that add up to the plain product == the oracle: G1, G2 and the interleaved A | B1 | C group,
+    several table widths, edge scalars, and the skewed cases the specials exist for (every scalar 1; every scalar
+    r - 1, which puts ALL entries of a window into one bucket of one class)"""
+    info = O.zkey_info(zkey)
+    n, shift = 1000, info["nPublic"] + 1
+    rng = random.Random(1000 * q_log + parts + table_c)
+    A, B1, B2, Cs = (_sec(zkey, "zkey", k) for k in (5, 6, 7, 8))
+    mixes = [_scalar_mix(rng, n), [1] * n, [O.R_MOD - 1] * n, [rng.choice([0, 1, 2, 3, 255, 2**32 - 1, O.R_MOD - 2]) for _ in range(n)]]
+    g1 = device.bases(A[:64 * n], n, table_c=table_c)
+    g2 = device.bases(B2[:128 * n], n, g2=True, table_c=table_c)
+    grp = device.bases_group([(A[:64 * n], n, 0), (B1[:64 * n], n, 0), (Cs[:64 * (n - shift)], n - shift, shift)], 0, n, table_c=table_c)
+    for vals in mixes:
+        sc = b"".join(O.to_le(v) for v in vals)
+        v = device.dvec(n, sc)
+        exp1, exp2 = O.g1_msm(A[:64 * n], sc, n), O.g2_msm(B2[:128 * n], sc, n)
+        expg = [exp1, O.g1_msm(B1[:64 * n], sc, n), O.g1_msm(Cs[:64 * (n - shift)], sc[32 * shift:], n - shift)]
+        res, sp = _class_tilings(rng, q_log, parts, n)
+        sum1, sum2, sumg = bytes(64), bytes(128), [bytes(64)] * 3
+        for (r0, r1), (s0, s1) in zip(res, sp):
+            sch = device.schedule(v, 0, n, table_c=table_c, classes=(q_log, r0, r1 - r0, specials, s0, s1 - s0))
+            sum1 = O.g1_add(sum1, device.msm(g1, sch))
+            sum2 = O.g2_add(sum2, device.msm(g2, sch, g2=True))
+            sumg = [O.g1_add(a, b) for a, b in zip(sumg, device.msm_group(grp, sch))]
+        assert sum1 == exp1 and sum2 == exp2 and sumg == expg, (vals[:4], res, sp)
+    # a sub-range of the scalars, as a rank of a P x B layout holds it (the special range given in the vector's indices)
+    lo, cnt = 100, 800
+    sc = b"".join(O.to_le(x) for x in mixes[0])
+    v = device.dvec(n, sc)
+    b = device.bases(A[64 * lo:64 * (lo + cnt)], cnt, global_first=lo, table_c=table_c)
+    exp = O.g1_msm(A[64 * lo:64 * (lo + cnt)], sc[32 * lo:32 * (lo + cnt)], cnt)
+    res, sp = _class_tilings(rng, q_log, parts, cnt)
+    acc = bytes(64)
+    for (r0, r1), (s0, s1) in zip(res, sp):
+        acc = O.g1_add(acc, device.msm(b, device.schedule(v, lo, cnt, table_c=table_c, classes=(q_log, r0, r1 - r0, specials, lo + s0, s1 - s0))))
+    assert acc == exp
+
+
+def test_msm_bucket_classes_errors(device, zkey):
+    import ultragroth_amd as ug
+    v = device.dvec(10, b"".join(O.to_le(i + 1) for i in range(10)))
+    with pytest.raises(ug.DeviceError, match="residues outside"):
+        device.schedule(v, 0, 10, table_c=16, classes=(3, 6, 3, 0, 0, 10))
+    with pytest.raises(ug.DeviceError, match="more than 64 special"):
+        device.schedule(v, 0, 10, table_c=16, classes=(3, 0, 1, 65, 0, 10))
+    with pytest.raises(ug.DeviceError, match="window too narrow"):
+        device.schedule(v, 0, 10, classes=(8, 0, 1, 0, 0, 10))          # the classic window of ten scalars is a few bits wide
+    with pytest.raises(ug.DeviceError, match="too many bucket sets"):
+        device.schedule(v, 0, 10, table_c=24, classes=(7, 0, 100, 0, 0, 10))
+    # (classic windows bring one set per window and owned residue: the classes are made for the one-set table form)
+    w = device.dvec(4000, b"".join(O.to_le(3 * i + 1) for i in range(4000)))
+    with pytest.raises(ug.DeviceError, match="too many bucket sets|window too narrow"):
+        device.schedule(w, 0, 4000, classes=(2, 0, 2, 0, 0, 4000))
+    # classes switched off again: the plain product
+    pts = _sec(zkey, "zkey", 5)[:640]
+    b = device.bases(pts, 10, table_c=16)
+    assert device.msm(b, device.schedule(v, 0, 10, table_c=16, classes=(0, 0, 0, 0, 0, 0))) == O.g1_msm(pts, b"".join(O.to_le(i + 1) for i in range(10)), 10)
+
+
 def test_msm_window_tables_errors(device, zkey):
     pts = _sec(zkey, "zkey", 5)[:64 * 10]
     sc = b"".join(O.to_le(i + 1) for i in range(10))

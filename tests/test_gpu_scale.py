@@ -278,6 +278,105 @@ def test_sharded_prover_from_slices_and_witness_parts(device):
         p.close()
 
 
+@pytest.mark.parametrize("world,point_ranges,mix", [(4, 1, "C"), (4, 2, "U"), (8, 2, "C"), (5, 1, "U")])
+def test_sharded_prover_with_bucket_class_layouts(device, world, point_ranges, mix):
+    """ug_groth16_shard_layout + ug_groth16_prover_create_sharded_layout: the witness products cut over the
+    ranks by BUCKET CLASS -- the ranks of a group hold the same base-point range with its whole window tables and take the
+    bucket ids of their residues; the lowest buckets, where a circom-like witness piles up its ones, go by scalar range -- in
+    P groups of world / P ranks; chain ranks of five ranks or more take no part of the H product (empty h range). Every rank
+    from its slices only, the proof byte for byte the oracle's. (Not the layout the library chooses by itself: base-point
+    ranges measured faster, profiles/r04_rank_phases_classes.txt.)"""
+    import torch
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    log_domain = 16
+    zkey, wtns, info = synth.build_circuit(device, log_domain, mix=mix, seed=0x5EED0000)
+    n_dom, nv = info["domainSize"], info["nVars"]
+    lays = [ug.ShardedGroth16Prover.shard_layout(nv, 1, n_dom, k, world, point_ranges) for k in range(world)]
+    # the layouts tile everything: h ranges [0, N), per group the residues [0, Q) and the special ranges the group's scalars
+    assert lays[0].h[0] == 0 and lays[-1].h[1] == n_dom and all(a.h[1] == b.h[0] for a, b in zip(lays, lays[1:]))
+    B = world // point_ranges
+    for g in range(point_ranges):
+        grp = lays[g * B:(g + 1) * B]
+        assert all(L.witness == grp[0].witness and L.q_log == grp[0].q_log and L.q_log > 0 for L in grp)
+        assert grp[0].first_residue == 0 and grp[-1].first_residue + grp[-1].residues == 1 << grp[0].q_log
+        assert all(a.first_residue + a.residues == b.first_residue and a.special[1] == b.special[0] for a, b in zip(grp, grp[1:]))
+        assert (grp[0].special[0], grp[-1].special[1]) == grp[0].witness
+    assert lays[0].witness[0] == 0 and lays[-1].witness[1] == nv
+    if world >= 5:
+        assert all(L.h[0] == L.h[1] for L in lays[:3]) and all(L.h[1] > L.h[0] for L in lays[3:])
+    full = torch.empty((3, n_dom, 32), dtype=torch.uint8, device="cuda")
+    total = None
+    # (ranks one after the other: each holds whole tables of its group's range)
+    chains_done = False
+    provers = []
+    for k, L in enumerate(lays):
+        header, coefs, slices = synth.build_circuit_slices(device, log_domain, L.ranges, with_coefs=bool(L.chains))
+        p = ug.ShardedGroth16Prover.from_slices(header, coefs, info["nCoefs"], slices, 0, k, world, public_size=86, layout=L)
+        provers.append(p)
+        p.load_witness_part(wtns, 0)
+        if L.chains:
+            p.load_witness_part(wtns, 1)
+            for c in L.chains:
+                p.hpoly_chain(c, full[c].data_ptr())
+    torch.cuda.synchronize()
+    r_, s_ = fixed_rs()
+    ug.set_test_blinding(r_ + s_)                  # (rank 0 draws r and s when its products are queued: witness_msm_begin)
+    try:
+        for k, (L, p) in enumerate(zip(lays, provers)):
+            p.witness_msm_begin()                                        # the queued form, the H branch beside it
+            first, cnt, _ = p.h_range()
+            assert (first, first + cnt) == L.h
+            bufs = [full[c, first:first + max(cnt, 1)].contiguous() for c in range(3)]
+            torch.cuda.synchronize()
+            p.hpoly_combine(*(b.data_ptr() for b in bufs))
+            hpart = p.run_h_msm()
+            part = p.witness_msm_end()[:320] + hpart[320:384]
+            assert part[:320] == p.run_witness_msm()[:320]               # the blocking call gives the same sums
+            total = part if total is None else ug.ShardedGroth16Prover.add_partials(total, part)
+        got = provers[0].finish(total)
+    finally:
+        ug.set_test_blinding(b"")
+    exp = O.groth16_prove(zkey, wtns, int.from_bytes(r_, "little"), int.from_bytes(s_, "little"))
+    assert got == (exp[0], exp[1])
+    for p in provers:
+        p.close()
+
+
+def test_bucket_class_layout_needs_the_window_tables(device, monkeypatch):
+    """a rank of a bucket-class layout that cannot have its tables (here: switched off) refuses to be created -- with the
+    reason -- instead of proving with classic windows, whose result blocks could not hold one bucket set per window and residue"""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    monkeypatch.setenv("ULTRAGROTH_TABLES", "0")
+    L = ug.ShardedGroth16Prover.shard_layout((1 << 15) - 1, 1, 1 << 15, 1, 4, 1)
+    header, coefs, slices = synth.build_circuit_slices(device, 15, L.ranges, with_coefs=False)
+    with pytest.raises(ug.ProverError, match="needs the fixed-base window tables"):
+        ug.ShardedGroth16Prover.from_slices(header, coefs, 4 << 15, slices, 0, 1, 4, public_size=86, layout=L)
+
+
+@pytest.mark.parametrize("shard", ["1x4", "2x2", "auto"])
+def test_api_on_several_devices_with_bucket_classes(device, monkeypatch, shard):
+    """ULTRAGROTH_DEVICES with ULTRAGROTH_SHARD=PxB: the object the reference's groth16_prover_create returns shards its witness
+    products by bucket class (four ranks on the one device, created one after the other: each holds whole tables); two proofs on
+    one object == the single-device prover's"""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, wtns, info = synth.build_circuit(device, 16, mix="C", seed=0x5EED0000)
+    r_, s_ = fixed_rs()
+    exp = O.groth16_prove(zkey, wtns, int.from_bytes(r_, "little"), int.from_bytes(s_, "little"))
+    monkeypatch.setenv("ULTRAGROTH_DEVICES", "0,0,0,0")
+    monkeypatch.setenv("ULTRAGROTH_SHARD", shard)
+    with ug.Groth16Prover(zkey) as p:
+        for _ in range(2):
+            ug.set_test_blinding(r_ + s_)
+            try:
+                got = p.prove(wtns)
+            finally:
+                ug.set_test_blinding(b"")
+            assert got == (exp[0], exp[1])
+
+
 def test_bench_two_ranks_over_rccl():
     """the real N = 2 launch line of the driver (one process per GPU, backend nccl = RCCL) with --check; needs two GPUs --
     on a one-GPU box the same control flow is rehearsed over gloo (tools/run_multi.sh)"""

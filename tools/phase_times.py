@@ -20,16 +20,20 @@ torch.cuda.set_device(0)
 dev = ug.Device(0)
 domain = 1 << log_domain
 info = dict(domainSize=domain, nVars=domain - 1, nPublic=1, nCoefs=4 * domain)
-wr = bench.witness_slice(info, rank, world)
-ranges = ug.ShardedGroth16Prover.shard_ranges(info["nVars"], 1, domain, rank, world, wr)
-chains = [k for k in range(3) if k % world == rank]
-header, coefs, slices = synth.build_circuit_slices(dev, log_domain, ranges, with_coefs=bool(chains))
-wtns = synth.build_witness(log_domain, "U")
+# argument 6: base-point ranges of the layout (world = base-point form of rounds 1-3; 1 = bucket classes over the whole witness;
+# 0 = the library's choice); argument 7: scalar mix U | C
+point_ranges = int(sys.argv[6]) if len(sys.argv) > 6 else world
+mix = sys.argv[7] if len(sys.argv) > 7 else "U"
+layout = ug.ShardedGroth16Prover.shard_layout(info["nVars"], 1, domain, rank, world, point_ranges)
+wr = layout.witness
+chains = layout.chains
+header, coefs, slices = synth.build_circuit_slices(dev, log_domain, layout.ranges, with_coefs=bool(chains))
+wtns = synth.build_witness(log_domain, mix)
 t0 = time.perf_counter()
-p = ug.ShardedGroth16Prover.from_slices(header, coefs, info["nCoefs"], slices, 0, rank, world, witness_range=wr, public_size=86)
-print("rank %d of %d at 2^%d: witness slice %s (%d points), chains %s, create %.2f s" % (rank, world, log_domain, wr, wr[1] - wr[0], chains, time.perf_counter() - t0))
+p = ug.ShardedGroth16Prover.from_slices(header, coefs, info["nCoefs"], slices, 0, rank, world, public_size=86, layout=layout)
+print("rank %d of %d at 2^%d, mix %s: %s (%d points), create %.2f s" % (rank, world, log_domain, mix, layout, wr[1] - wr[0], time.perf_counter() - t0))
 del coefs, slices
-sl = domain // world
+sl = max(layout.h[1] - layout.h[0], 1)
 full = torch.empty((domain, 32), dtype=torch.uint8, device="cuda")
 # (random slices, top byte small: h = a.b - c is then a vector of full-size scalars, as in a real proof -- with zeros the H
 # product has no entries and takes no time)

@@ -325,8 +325,24 @@ class Registry:
         self.close()
 
 
+class ShardLayout:
+    """out[12] of ug_groth16_shard_layout (include/prover.h): what one rank of a many-device prover owns"""
+
+    def __init__(self, raw):
+        self.raw = list(raw)
+        self.ranges = ((raw[0], raw[1]), (raw[2], raw[3]), (raw[4], raw[5]))      # witness, C, H -- as shard_ranges returns them
+        self.witness, self.c, self.h = self.ranges
+        self.q_log, self.first_residue, self.residues = raw[6], raw[7], raw[8]
+        self.special = (raw[9], raw[10])
+        self.chains = [k for k in range(3) if (raw[11] >> k) & 1]
+
+    def __repr__(self):
+        cls = "classes %d..%d of %d" % (self.first_residue, self.first_residue + self.residues, 1 << self.q_log) if self.q_log else "all buckets"
+        return "ShardLayout(witness %s, h %s, %s, chains %s)" % (self.witness, self.h, cls, self.chains)
+
+
 class ShardedGroth16Prover:
-    """One rank of a base-point-sharded Groth16 prover (one process per GPU): see include/prover.h."""
+    """One rank of a sharded Groth16 prover (one process per GPU): see include/prover.h."""
 
     def __init__(self, zkey, device, rank, world, witness_range=None):
         """witness_range = (first, end): this rank's slice of the witness-indexed sections, chosen by the caller
@@ -345,16 +361,22 @@ class ShardedGroth16Prover:
         self._public_size = groth16_public_size_for_zkey_buf(zkey)
 
     @classmethod
-    def from_slices(cls, header, coefs, n_coefs, slices, device, rank, world, witness_range=None, public_size=None):
+    def from_slices(cls, header, coefs, n_coefs, slices, device, rank, world, witness_range=None, public_size=None, layout=None):
         """ug_groth16_prover_create_sharded_slices: header = zkey section 2, coefs = section 4 records (None: no chain on
-        this rank), slices = (A, B1, B2, C, H) buffers holding this rank's points only (shard_ranges tells which)"""
+        this rank), slices = (A, B1, B2, C, H) buffers holding this rank's points only (shard_ranges tells which).
+        layout (a ShardLayout from shard_layout): ug_groth16_prover_create_sharded_layout -- the rank's part of a many-device
+        layout with bucket classes; the slices are those of layout.ranges"""
         self = cls.__new__(cls)
         self._h = C.c_void_p()
         err = C.create_string_buffer(1024)
         wr = (C.c_ulonglong * 2)(*witness_range) if witness_range is not None else None
         sizes = (C.c_ulonglong * 5)(*[len(x) for x in slices])
-        rc = load().ug_groth16_prover_create_sharded_slices(C.byref(self._h), header, len(header), coefs, n_coefs, *slices, sizes,
-                                                            device, rank, world, wr, err, len(err) - 1)
+        if layout is not None:
+            rc = load().ug_groth16_prover_create_sharded_layout(C.byref(self._h), header, len(header), coefs, n_coefs, *slices, sizes,
+                                                                device, rank, world, (C.c_ulonglong * 12)(*layout.raw), err, len(err) - 1)
+        else:
+            rc = load().ug_groth16_prover_create_sharded_slices(C.byref(self._h), header, len(header), coefs, n_coefs, *slices, sizes,
+                                                                device, rank, world, wr, err, len(err) - 1)
         if rc != PROVER_OK:
             self._h = None
             raise ProverError(rc, err.value.decode(errors="replace"))
@@ -368,6 +390,15 @@ class ShardedGroth16Prover:
         if load().ug_groth16_balanced_witness_range(n_vars, rank, world, out) != PROVER_OK:
             raise ProverError(PROVER_ERROR, "invalid shard rank / count")
         return out[0], out[1]
+
+    @staticmethod
+    def shard_layout(n_vars, n_public, domain, rank, world, point_ranges=0, hbm_bytes=0):
+        """ug_groth16_shard_layout: the rank's part of the many-device layout the library would choose (point_ranges = 0), or of
+        the one with that many base-point ranges (world / point_ranges ranks share a range through bucket classes)"""
+        out = (C.c_ulonglong * 12)()
+        if load().ug_groth16_shard_layout(n_vars, n_public, domain, rank, world, point_ranges, hbm_bytes, out) != PROVER_OK:
+            raise ProverError(PROVER_ERROR, "invalid shard rank / count or layout")
+        return ShardLayout(list(out))
 
     @staticmethod
     def shard_ranges(n_vars, n_public, domain, rank, world, witness_range=None):
@@ -605,10 +636,13 @@ class Device:
         c = np.ascontiguousarray(chunks, dtype=np.uint32)
         _check(self._L.ug_dvec_apply_lookup(dvec.h, w.ctypes.data, p.ctypes.data, len(w), c.ctypes.data, len(c), table, lookup_size))
 
-    def schedule(self, dvec, first, count, table_c=0):
+    def schedule(self, dvec, first, count, table_c=0, classes=None):
+        """classes (ug_schedule_set_classes): (q_log, first_residue, residues, specials, special_first, special_count)"""
         h = C.c_void_p()
         _check(self._L.ug_schedule_create(self._h, C.byref(h)))
         s = _Handle(h, self._L.ug_schedule_destroy, self)
+        if classes is not None:
+            _check(self._L.ug_schedule_set_classes(h, *classes))
         if table_c:
             _check(self._L.ug_schedule_build_tables(h, dvec.h, first, count, table_c))
         else:

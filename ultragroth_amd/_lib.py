@@ -19,7 +19,7 @@ INNER_SYMBOLS = [
     "ug_bases_create_g1", "ug_bases_create_g2", "ug_bases_create_tables_g1", "ug_bases_create_tables_g2", "ug_bases_destroy",
     "ug_msm_table_window", "ug_bases_tables_bytes", "ug_bases_precompute", "ug_ctx_mem_info", "ug_schedule_build_tables",
     "ug_dvec_create", "ug_dvec_upload", "ug_dvec_upload_range", "ug_dvec_upload_idle", "ug_dvec_download", "ug_dvec_gather", "ug_dvec_scatter", "ug_dvec_apply_lookup", "ug_fr_lookup_table", "ug_index_create", "ug_index_destroy", "ug_dvec_gather_index", "ug_dvec_wrap", "ug_dvec_size", "ug_dvec_destroy",
-    "ug_schedule_create", "ug_schedule_build", "ug_schedule_destroy",
+    "ug_schedule_create", "ug_schedule_build", "ug_schedule_destroy", "ug_schedule_set_classes",
     "ug_msm_g1", "ug_msm_g2", "ug_msm_batch", "ug_msm_batch_enqueue", "ug_ctx_collect", "ug_ctx_wait",
     "ug_hpoly_create", "ug_hpoly_run", "ug_hpoly_chain", "ug_hpoly_combine", "ug_hpoly_debug_abc", "ug_hpoly_destroy",
     "ug_fr_ntt", "ug_field_op", "ug_synth_points", "ug_ctx_timings", "ug_ctx_kernel_stats", "ug_ctx_abandon", "ug_test_inject_fault",
@@ -42,6 +42,7 @@ OUTER_SYMBOLS = [
     "ug_test_set_blinding", "ug_prover_last_timings", "ug_prover_kernel_stats", "ug_prover_last_upload_ms",
     "ug_groth16_prover_create_sharded", "ug_groth16_prover_create_sharded_range", "ug_groth16_prover_create_sharded_slices",
     "ug_groth16_shard_ranges", "ug_groth16_balanced_witness_range", "ug_groth16_prover_load_witness_part",
+    "ug_groth16_shard_layout", "ug_groth16_prover_create_sharded_layout",
     "ug_ultra_groth_prover_create_sharded", "ug_ultra_groth_prover_round_commit", "ug_ultra_groth_prover_round_finish",
     "ug_ultra_groth_prover_apply_commitment", "ug_g1_record_add",
     "ug_groth16_prover_load_witness", "ug_groth16_prover_run", "ug_groth16_prover_prove_resident",
@@ -145,6 +146,7 @@ def load():
     L.ug_dvec_destroy.argtypes = [vp]; L.ug_dvec_destroy.restype = None
     L.ug_schedule_create.argtypes = [vp, pp]
     L.ug_schedule_build.argtypes = [vp, vp, u64, u64]
+    L.ug_schedule_set_classes.argtypes = [vp, C.c_int, u32, u32, u32, u64, u64]
     L.ug_schedule_destroy.argtypes = [vp]; L.ug_schedule_destroy.restype = None
     L.ug_msm_g1.argtypes = [vp, vp, vp, i64, vp]
     L.ug_msm_g2.argtypes = [vp, vp, vp, i64, vp]
@@ -202,6 +204,8 @@ def load():
     L.ug_groth16_prover_load_witness.argtypes = [vp, vp, ull, vp, ull]
     L.ug_groth16_prover_load_witness_part.argtypes = [vp, vp, ull, C.c_int, vp, ull]
     L.ug_groth16_shard_ranges.argtypes = [ull, ull, ull, C.c_int, C.c_int, vp, vp]
+    L.ug_groth16_shard_layout.argtypes = [ull, ull, ull, C.c_int, C.c_int, C.c_int, ull, vp]
+    L.ug_groth16_prover_create_sharded_layout.argtypes = [pp, vp, ull, vp, ull, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, ull]
     L.ug_groth16_balanced_witness_range.argtypes = [ull, C.c_int, C.c_int, vp]
     L.ug_groth16_prover_create_sharded_slices.argtypes = [pp, vp, ull, vp, ull, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, ull]
     L.ug_dvec_upload_range.argtypes = [vp, vp, u64, u64, vp]

@@ -265,7 +265,7 @@ bool CoefMatrix::build(const uint8_t* raw44_dev, u64 ncoefs_, u32 domain_, u32 n
         UG_HIP(hipMemsetAsync(flag, 0, 4, stream));
         u32* const bk[2] = {keys_a, keys_b};
         u32* const bv[2] = {idx_a, idx_b};
-        const int at = sorter.sort(nullptr, 0, 0, 0, 0, 0, false, ncoefs, end_bit, bk, bv, flag, stream);      // pair form: (row key, record index)
+        const int at = sorter.sort(nullptr, MsmGeometry(), 0, ncoefs, end_bit, bk, bv, flag, stream);      // pair form: (row key, record index)
         hipLaunchKernelGGL(coef_gather_kernel, dim3(grid_for(ncoefs, 256)), dim3(256), 0, stream, raw44_dev, ncoefs, bv[at], sig, val);
         UG_KERNEL_CHECK();
         hipLaunchKernelGGL(row_ptr_kernel, dim3(grid_for((u64)nrows + 1, 256)), dim3(256), 0, stream, bk[at], ncoefs, nrows, row_ptr);

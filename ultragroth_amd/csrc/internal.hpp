@@ -52,18 +52,61 @@ struct NttPlan {
 };
 
 // ---- msm.hip ------------------------------------------------------------------------------------------
+// Bucket classes (many-device provers, DESIGN.md section 7: the witness products sharded by BUCKET instead of by base point).
+// A schedule with classes keeps only the (scalar, window) digits whose bucket b = |digit| - 1 has its residue b mod Q,
+// Q = 2^q_log, in [r0, r0 + cnt): one bucket set of 2^(c-1) / Q buckets per owned residue, local id b >> q_log. The ranks of
+// a node own disjoint residue ranges of the SAME scalars and the SAME (whole) base tables, so a rank sorts, accumulates and
+// reduces its share of the entries at the full problem's window width -- no extra window, a share of the buckets -- and the
+// weights come back on the host: a digit of magnitude b + 1 = Q (k + 1) - (Q - 1 - r), k = b >> q_log, r = b mod Q, so the sum
+// of a residue's set is Q * S1 - (Q - 1 - r) * S0 with S1 = sum (k + 1) B_k (what the running-sum reduction yields) and
+// S0 = sum B_k (its running sum, emitted beside it).
+// The lowest `specials` bucket ids of every window -- the digits 1 .. specials, which small witness values (bits, bytes,
+// counters) fill with up to millions of entries: one residue's owner would get all of bucket 0 -- are not owned by residue
+// but by SCALAR RANGE: the schedule keeps such a digit iff its scalar lies in [sp_lo, sp_hi) (local indices); they get
+// bucket ids of their own behind the regular sets, and their weighted sum (sum (b + 1) X_b) is a third output.
+struct BucketClasses {
+    int q_log = 0;               // 0: no classes, the schedule owns every bucket
+    u32 r0 = 0, cnt = 1;         // owned residues [r0, r0 + cnt) of Q = 2^q_log
+    u32 specials = 0;            // bucket ids below this are owned by scalar range
+    u32 sp_lo = 0, sp_hi = 0;    // ... the scalars [sp_lo, sp_hi) of the schedule
+    bool on() const { return q_log > 0; }
+};
+constexpr u32 MSM_MAX_SPECIALS = 64;     // (one wave sums a window's special buckets)
+
+// How a scalar's window digits become (bucket key, entry) pairs: the kernel argument of the digit-making kernels (sort.hip)
+struct DigitPlan {
+    u64 n; int c, windows; u32 buckets, sentinel; int tables;      // buckets: per set; sentinel = total_buckets(): the key of a digit that is not kept
+    int q_log; u32 r0, cnt, specials, sp_lo, sp_hi, special_base;  // bucket classes (q_log = 0: none); special_base = first special bucket id
+};
+
 struct MsmGeometry {
     u64 n = 0;          // number of scalars
     int c = 0;          // window bits
     int windows = 0;    // digits per scalar: ceil(255 / c)
-    u32 buckets = 0;    // per bucket set: 2^(c-1)
+    u32 buckets = 0;    // per bucket set: 2^(c-1), with classes 2^(c-1-q_log)
     bool tables = false;  // fixed-base window tables: digit j of scalar i multiplies 2^(c j) P_i, read from table j, so
                           // every digit of every window lands in ONE bucket set (no Horner, 1/windows of the reduction)
+    BucketClasses cls;
     static MsmGeometry choose(u64 n, int force_c = 0);
     static MsmGeometry choose_tables(u64 n, int c);
     static int table_window(u64 n);                                    // cost-model window width for the tables mode
-    int bucket_windows() const { return tables ? 1 : windows; }
-    u64 total_buckets() const { return (u64)bucket_windows() * buckets; }
+    void set_classes(const BucketClasses& k);                          // after choose / choose_tables (divides `buckets`)
+    int window_sets() const { return tables ? 1 : windows; }           // Horner steps on the host
+    int class_sets() const { return cls.on() ? (int)cls.cnt : 1; }
+    int bucket_windows() const { return window_sets() * class_sets(); }      // bucket sets the reduction sees: set (w, j) = w * class_sets + j
+    u64 special_buckets() const { return cls.on() ? (u64)window_sets() * cls.specials : 0; }     // ids behind the regular sets
+    u64 total_buckets() const { return (u64)bucket_windows() * buckets + special_buckets(); }
+    // points of a product's result block: S1 per set; with classes also S0 per set and one weighted sum of the specials per window
+    int result_points() const { return cls.on() ? 2 * bucket_windows() + (cls.specials ? window_sets() : 0) : bucket_windows(); }
+    // entries this schedule is expected to keep (uniform digits): what the segment length is chosen for
+    u64 expected_entries() const { return cls.on() ? ((n * (u64)windows) >> cls.q_log) * cls.cnt : n * (u64)windows; }
+    DigitPlan digit_plan() const {
+        DigitPlan d;
+        d.n = n; d.c = c; d.windows = windows; d.buckets = buckets; d.sentinel = (u32)total_buckets(); d.tables = tables ? 1 : 0;
+        d.q_log = cls.q_log; d.r0 = cls.r0; d.cnt = cls.on() ? cls.cnt : 1; d.specials = cls.on() ? cls.specials : 0;
+        d.sp_lo = cls.sp_lo; d.sp_hi = cls.sp_hi; d.special_base = (u32)((u64)bucket_windows() * buckets);
+        return d;
+    }
 };
 constexpr int TABLE_INDEX_BITS = 27;                                   // entry = index | table << 27 | sign << 31
 constexpr int TABLE_MIN_C = 16, TABLE_MAX_C = 24;                      // <= 16 tables (4 bits), <= 2^23 buckets
@@ -72,6 +115,8 @@ struct HeavyBucket { u32 bucket, first_seg, last_seg, pad; };  // a bucket cut i
 
 // ---- sort.hip: the hand-written LSD radix partition that groups a schedule's pairs by bucket ------------------------
 int radix_plan(int bits, int* shift, int* bins_log);          // passes; low bits first
+// the unsorted pair form: keys / vals [w * n + i] = window w of scalar i (only for scalars of more than 16 windows, i.e. tiny MSMs)
+void digit_pairs(const u32* scalars, const DigitPlan& plan, u32* keys, u32* vals, hipStream_t stream);
 struct RadixSorter {
     u32* lookback = nullptr;      // tiles x 256 status words of the pass in flight
     u32* small = nullptr;         // 4 x 256 bin counts / starts, one tile counter per pass
@@ -79,7 +124,7 @@ struct RadixSorter {
     void reserve(u64 n_pairs, int ipt_min);
     void release();
     // see sort.hip; returns which of the two buffer pairs holds the sorted pairs
-    int sort(const u32* scalars, u64 n, int c, int windows, u32 buckets, u32 sentinel, bool tables, u64 n_pairs, int bits,
+    int sort(const u32* scalars, const MsmGeometry& geo, u32 sentinel, u64 n_pairs, int bits,
              u32* const buf_keys[2], u32* const buf_vals[2], u32* error_flag, hipStream_t stream, u32* n_valid_out = nullptr,
              bool* dropped_out = nullptr);
     ~RadixSorter() { release(); }
@@ -149,10 +194,11 @@ typedef MsmStats KernelStats;
 struct MsmPending {
     bool g2 = false;
     bool empty = true;           // nothing was queued: the sum is the point at infinity
-    int c = 0, bucket_windows = 0;
+    int c = 0, window_sets = 0, class_sets = 1;
+    BucketClasses cls;           // cls.on(): the block holds [S1 per set | S0 per set | specials per window] (MsmGeometry::result_points)
     u32* host = nullptr;
 };
-constexpr size_t MSM_PENDING_WORDS = 64 * 72;       // room for the largest result block (<= 43 windows of G2 words); the LAST word
+constexpr size_t MSM_PENDING_WORDS = 64 * 72;       // room for the largest result block (<= 63 G2 points); the LAST word
                                                     // receives the schedule's failure flag (meta[7])
 MsmPending msm_enqueue_g1(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta, hipStream_t stream,
                           MsmStats* stats, u32* pinned_host);

@@ -6,7 +6,7 @@
 //
 // Pipeline (one "schedule" per scalar vector, shared by every base set multiplied by it):
 //   1. signed digits         scalar -> signed c-bit digits (carry recoding), one (key, val) pair per window, made inside the first
-//                            pass of the sort (sort.hip; msm_digits_kernel only for scalars of more than 16 windows):
+//                            pass of the sort (sort.hip; digit_pairs only for scalars of more than 16 windows):
 //                            key = bucket id (one bucket set for all windows when the base set has window tables, else
 //                            window * 2^(c-1) + |digit| - 1), val = index | table << 27 | sign << 31; zero digits get a
 //                            sentinel key and fall off the end of the sort
@@ -147,52 +147,7 @@ struct G2Cfg {
     }
 };
 
-// ---- 1. digits ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool geq_r(const u32* s) {
-#pragma unroll
-    for (int i = 7; i >= 0; i--) {
-        if (s[i] > FrParams::q32[i]) return true;
-        if (s[i] < FrParams::q32[i]) return false;
-    }
-    return true;
-}
-__global__ void msm_digits_kernel(const u32* scalars, u64 n, int c, int windows, u32 buckets, u32 sentinel, int tables,
-                                  u32* keys, u32* vals) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    u32 s[10];
-    load8(s, scalars + i * 8);
-    s[8] = 0; s[9] = 0;
-    // the group has order r: scalars >= r (never produced by a well-formed witness) are reduced
-    for (int it = 0; it < 6 && geq_r(s); it++) {
-        u64 borrow = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            u64 d = (u64)s[k] - FrParams::q32[k] - borrow;
-            s[k] = (u32)d; borrow = (d >> 32) & 1;
-        }
-    }
-    u32 carry = 0;
-    const u32 half = 1u << (c - 1), full = 1u << c, mask = full - 1;
-    for (int w = 0; w < windows; w++) {
-        int bit = w * c, word = bit >> 5, sh = bit & 31;
-        u64 two = (u64)s[word] | ((u64)s[word + 1] << 32);
-        u32 raw = ((u32)(two >> sh) & mask) + carry;
-        // classic: one bucket set per window; tables: one set, the window selects the table the base is read from
-        const u32 set0 = tables ? 0u : (u32)w * buckets;
-        const u32 tag = tables ? (u32)w << TABLE_INDEX_BITS : 0u;
-        u32 key, val;
-        if (raw > half) {                       // negative digit raw - 2^c, carry into the next window
-            u32 mag = full - raw;               // 0 when the window was all ones and a carry came in
-            carry = 1;
-            key = mag ? set0 + mag - 1 : sentinel;
-            val = (u32)i | tag | 0x80000000u;
-        }
-        else { carry = 0; key = raw ? set0 + raw - 1 : sentinel; val = (u32)i | tag; }
-        keys[(u64)w * n + i] = key;
-        vals[(u64)w * n + i] = val;
-    }
-}
+// ---- 1. digits: sort.hip (recode_scalar, digit_key; the pairs are made inside the first pass of the sort) ----------------------
 
 // ---- 3. bucket bounds -----------------------------------------------------------------------------------
 // meta[0] = number of heavy buckets, meta[1] = number of non-sentinel entries
@@ -617,14 +572,17 @@ __global__ __launch_bounds__(Cfg::BLOCK) void heavy_final_kernel(const HeavyBuck
 template <class Cfg>
 // (w counts the bucket sets of ALL products of a batch, one after the other in `buckets`; the entry counts belong to the
 // schedule, which the products share: bucket set w of any product has the counts of set w mod windows)
+// (out0, optional -- schedules with bucket classes: the plain sum of the chunk's buckets, S0 of internal.hpp's BucketClasses)
 __global__ __launch_bounds__(128) void bucket_chunk_reduce_kernel(const u32* buckets, const u32* count, u32 per_window, int chunk,
-                                                                  u32 nchunks_total, int scalar_bits, u32* out, u32 windows) {
+                                                                  u32 nchunks_total, int scalar_bits, u32* out, u32 windows, u32* out0,
+                                                                  size_t product_buckets) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nchunks_total) return;
     typedef typename Cfg::F F;
     u32 chunks_per_window = per_window / chunk;
     u32 w = t / chunks_per_window, j = t % chunks_per_window;
-    const size_t b0 = (size_t)w * per_window + (size_t)j * chunk;
+    // (product_buckets: the buckets of one product -- its `windows` sets and, with bucket classes, the special buckets behind them)
+    const size_t b0 = (size_t)(w / windows) * product_buckets + (size_t)(w % windows) * per_window + (size_t)j * chunk;
     const size_t c0 = (size_t)(w % windows) * per_window + (size_t)j * chunk;
     const u32* base = buckets + b0 * Cfg::PT_WORDS;
     XYZZ<F> run = xyzz_inf<F>(), acc = xyzz_inf<F>();
@@ -635,6 +593,32 @@ __global__ __launch_bounds__(128) void bucket_chunk_reduce_kernel(const u32* buc
     u32 off = j * (u32)chunk;                  // weight offset of the chunk
     if (off) acc = xyzz_add(acc, xyzz_mul_scalar(run, &off, scalar_bits));
     Cfg::to_words(out + (size_t)t * Cfg::PT_WORDS, acc, 1);
+    if (out0) Cfg::to_words(out0 + (size_t)t * Cfg::PT_WORDS, run, 1);
+}
+// Schedules with bucket classes: the special buckets of window set w (ids special_base + w * S + b, b < S <= 64: the digits
+// 1 .. S, kept by scalar range) -> their weighted sum  sum_b (b + 1) X_b. One wave per (window set, product of the batch).
+template <class Cfg>
+__global__ __launch_bounds__(64) void special_sum_kernel(const u32* bucket_pts, const u32* count, u32 special_base, u32 S, size_t bucket_stride,
+                                                         u32* out, u32 window_sets) {
+    typedef typename Cfg::F F;
+    const u32 w = blockIdx.x, q = blockIdx.y, lane = threadIdx.x;
+    XYZZ<F> x = xyzz_inf<F>();
+    const u32 id = special_base + w * S + lane;
+    if (lane < S && count[id]) x = Cfg::from_words(bucket_pts + (size_t)q * bucket_stride + (size_t)id * Cfg::PT_WORDS, 1);
+    XYZZ<F> acc = xyzz_inf<F>();
+    const u32 k = lane + 1;                                    // <= 64: seven bits
+    for (int i = 6; i >= 0; i--) {
+        acc = xyzz_dbl(acc);
+        if ((k >> i) & 1) acc = xyzz_add(acc, x);
+    }
+    u32 v[Cfg::PT_WORDS];
+    for (int off = 32; off > 0; off >>= 1) {
+        Cfg::to_words(v, acc, 1);
+#pragma unroll
+        for (int i = 0; i < Cfg::PT_WORDS; i++) v[i] = __shfl_xor(v[i], off, 64);
+        acc = xyzz_add(acc, Cfg::from_words(v, 1));
+    }
+    if (lane == 0) Cfg::to_words(out + ((size_t)q * window_sets + w) * Cfg::PT_WORDS, acc, 1);
 }
 template <class Cfg>
 __global__ __launch_bounds__(128) void ec_sum_groups_kernel(const u32* in, u32* out, u32 n_out, int group) {
@@ -842,6 +826,22 @@ MsmGeometry MsmGeometry::choose_tables(u64 n, int c) {
     return g;
 }
 
+void MsmGeometry::set_classes(const BucketClasses& k) {
+    cls = BucketClasses();
+    if (!k.on()) return;
+    if (k.q_log > 8) throw std::invalid_argument("msm: more than 256 bucket classes");
+    const u32 Q = 1u << k.q_log;
+    if (k.cnt < 1 || k.r0 + k.cnt > Q) throw std::invalid_argument("msm: bucket residues outside [0, 2^q_log)");
+    if (k.specials > MSM_MAX_SPECIALS) throw std::invalid_argument("msm: more than 64 special buckets");
+    if (k.sp_lo > k.sp_hi || k.sp_hi > n) throw std::invalid_argument("msm: special-bucket scalar range outside the schedule");
+    // every owned residue needs a bucket set of at least 8 buckets (the reduction's shortest chunk), and the specials must be
+    // bucket ids the window has
+    if (c - 1 < k.q_log + 3 || ((u64)1 << (c - 1)) < k.specials) throw std::invalid_argument("msm: window too narrow for this many bucket classes");
+    cls = k;
+    buckets = 1u << (c - 1 - k.q_log);
+    if ((size_t)result_points() * 72 > MSM_PENDING_WORDS - 1) throw std::invalid_argument("msm: too many bucket sets for one result block");
+}
+
 // ---- schedule -----------------------------------------------------------------------------------------------
 void MsmSchedule::reserve(const MsmGeometry& g) {
     u64 total = g.n * g.windows;
@@ -874,11 +874,11 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
     if (g.n > ((u64)1 << TABLE_INDEX_BITS)) throw std::invalid_argument("msm: more than 2^27 scalars in one schedule");
     geo = g;
     reserve(g);
-    log_seg = segment_log(g.n * g.windows);
+    log_seg = segment_log(g.expected_entries());
     // short segments for the last eighth of a large schedule (SegMap): worth it once the accumulation takes several rounds
     // of workgroups (UG_SEG_TAPER=0 turns it off)
     static const bool taper = !(getenv("UG_SEG_TAPER") && atoi(getenv("UG_SEG_TAPER")) == 0);
-    log_seg_tail = (taper && log_seg == LOG_SEG && ((g.n * g.windows) >> log_seg) >= ((u64)1 << 16)) ? log_seg - 2 : log_seg;
+    log_seg_tail = (taper && log_seg == LOG_SEG && (g.expected_entries() >> log_seg) >= ((u64)1 << 16)) ? log_seg - 2 : log_seg;
     if (g.n == 0) return;
     u64 total = g.n * g.windows;
     u32 nb = (u32)g.total_buckets();
@@ -895,11 +895,7 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
 #endif
     const bool pairs_first = use_cub || g.windows > 16;
     bool dropped = false;                 // the sort left out the zero digits and wrote the entry count to meta[1] itself
-    if (pairs_first) {
-        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, stream,
-                           scalars_dev, g.n, g.c, g.windows, g.buckets, sentinel, g.tables ? 1 : 0, keys_a, vals_a);
-        UG_KERNEL_CHECK();
-    }
+    if (pairs_first) digit_pairs(scalars_dev, g.digit_plan(), keys_a, vals_a, stream);
 #ifdef UG_MEASURE
     if (use_cub) {
         hipcub::DoubleBuffer<u32> dk(keys_a, keys_b), dv(vals_a, vals_b);
@@ -917,8 +913,7 @@ void MsmSchedule::build(const u32* scalars_dev, const MsmGeometry& g, hipStream_
     {
         u32* const bk[2] = {keys_a, keys_b};
         u32* const bv[2] = {vals_a, vals_b};
-        const int at = sorter.sort(pairs_first ? nullptr : scalars_dev, g.n, g.c, g.windows, g.buckets, sentinel, g.tables, total, end_bit, bk, bv,
-                                   meta + 7, stream, meta + 1, &dropped);
+        const int at = sorter.sort(pairs_first ? nullptr : scalars_dev, g, sentinel, total, end_bit, bk, bv, meta + 7, stream, meta + 1, &dropped);
         keys = bk[at];
         vals = bv[at];
     }
@@ -960,7 +955,8 @@ void MsmWorkspace::reserve(const MsmGeometry& g, bool g2, u64 n_segments, u32 n_
     size_t need = (size_t)g.total_buckets() * ptw * 4;
     if (need > bucket_bytes) { dev_alloc(bucket_pts, need); bucket_bytes = need; }
     const int chunk = reduce_chunk(g, sets, g2);           // the chunk the launch uses (msm_enqueue_multi): same arguments, same value
-    size_t cneed = (size_t)g.bucket_windows() * (g.buckets / chunk) * ptw * 4;
+    // (bucket classes: the chunks' plain sums S0 beside their weighted sums, and the specials' sums behind both)
+    size_t cneed = ((size_t)(g.cls.on() ? 2 : 1) * g.bucket_windows() * (g.buckets / chunk) + (size_t)g.window_sets()) * ptw * 4;
     if (cneed > chunk_bytes) { dev_alloc(chunk_pts, cneed); dev_alloc(chunk_pts2, cneed); chunk_bytes = cneed; }
     size_t sneed = (size_t)n_segments * 2 * ptw * 4;
     if (sneed > slot_bytes) { dev_alloc(slot_pts, sneed); slot_bytes = sneed; }
@@ -995,9 +991,10 @@ void msm_enqueue_multi(const MsmSchedule& s, MsmWorkspace& ws, int count, const 
     for (int j = 0; j < count; j++) {
         pend[j] = MsmPending();
         pend[j].g2 = Cfg::PT_WORDS == G2Cfg::PT_WORDS;
-        pend[j].c = g.c; pend[j].bucket_windows = g.bucket_windows(); pend[j].host = pinned_host[j];
+        pend[j].c = g.c; pend[j].window_sets = g.window_sets(); pend[j].class_sets = g.class_sets(); pend[j].cls = g.cls;
+        pend[j].host = pinned_host[j];
         if (g.n == 0 || n_bases[group ? 0 : j] == 0) continue;
-        if ((size_t)pend[j].bucket_windows * Cfg::PT_WORDS > MSM_PENDING_WORDS - 1) throw std::logic_error("msm: result block too large");
+        if ((size_t)g.result_points() * Cfg::PT_WORDS > MSM_PENDING_WORDS - 1) throw std::logic_error("msm: result block too large");
         pend[j].empty = false;
         live[k++] = j;
     }
@@ -1073,33 +1070,50 @@ void msm_enqueue_multi(const MsmSchedule& s, MsmWorkspace& ws, int count, const 
     }
     int chunk = reduce_chunk(g, k, Cfg::PT_WORDS == G2Cfg::PT_WORDS);
     const int windows = g.bucket_windows();            // bucket sets per product: one per window, or one in all with window tables
+                                                       // (times the owned residues of a schedule with bucket classes)
     const int bw = windows * k;                        // ... of the whole batch, product after product
+    const bool classes = g.cls.on();
     u32 cpw = g.buckets / chunk;                       // chunks per bucket set
     u32 nchunks = cpw * bw;
+    // with bucket classes the chunks' plain sums (S0) lie behind their weighted sums and go through the same tree: 2 bw sets
     hipLaunchKernelGGL(bucket_chunk_reduce_kernel<Cfg>, dim3((nchunks + 127) / 128), dim3(128), 0, stream,
-                       ws.bucket_pts, s.bucket_count, g.buckets, chunk, nchunks, g.c, ws.chunk_pts, (u32)windows);
+                       ws.bucket_pts, s.bucket_count, g.buckets, chunk, nchunks, g.c, ws.chunk_pts, (u32)windows,
+                       classes ? ws.chunk_pts + (size_t)nchunks * Cfg::PT_WORDS : (u32*)nullptr, (size_t)g.total_buckets());
     UG_KERNEL_CHECK();
+    const int tree_sets = classes ? 2 * bw : bw;
     u32* cur = ws.chunk_pts; u32* nxt = ws.chunk_pts2;
     while (cpw > 1) {
         // a lane per output (16 serial additions) while that still fills the chip, then a wave per output
-        if ((u64)(cpw / 16) * bw >= 8192) {
+        if ((u64)(cpw / 16) * tree_sets >= 8192) {
             const int group = 16;
-            u32 n_out = (cpw / group) * bw;
+            u32 n_out = (cpw / group) * tree_sets;
             hipLaunchKernelGGL(ec_sum_groups_kernel<Cfg>, dim3((n_out + 127) / 128), dim3(128), 0, stream, cur, nxt, n_out, group);
             cpw /= group;
         } else {
             const int group = cpw >= 256 ? 256 : (int)cpw;
-            u32 n_out = (cpw / group) * bw;
+            u32 n_out = (cpw / group) * tree_sets;
             hipLaunchKernelGGL(ec_sum_wave_kernel<Cfg>, dim3((n_out + 3) / 4), dim3(256), 0, stream, cur, nxt, n_out, group);
             cpw /= group;
         }
         UG_KERNEL_CHECK();
         std::swap(cur, nxt);
     }
+    // result block of a product: [S1 per set | S0 per set | weighted sum of the special buckets per window set]
+    const int wsets = g.window_sets();
+    const bool specials = classes && g.cls.specials;
+    if (specials) {
+        hipLaunchKernelGGL(special_sum_kernel<Cfg>, dim3((unsigned)wsets, (unsigned)k), dim3(64), 0, stream, ws.bucket_pts, s.bucket_count,
+                           (u32)((u64)windows * g.buckets), g.cls.specials, bucket_stride, cur + (size_t)tree_sets * Cfg::PT_WORDS, (u32)wsets);
+        UG_KERNEL_CHECK();
+    }
     for (int q = 0; q < k; q++) {
-        UG_HIP(hipMemcpyAsync(pinned_host[live[q]], cur + (size_t)q * windows * Cfg::PT_WORDS, (size_t)windows * Cfg::PT_WORDS * 4,
-                              hipMemcpyDeviceToHost, stream));
-        UG_HIP(hipMemcpyAsync(pinned_host[live[q]] + MSM_PENDING_WORDS - 1, s.meta + 7, 4, hipMemcpyDeviceToHost, stream));
+        u32* host = pinned_host[live[q]];
+        const size_t set_words = (size_t)windows * Cfg::PT_WORDS;
+        UG_HIP(hipMemcpyAsync(host, cur + (size_t)q * set_words, set_words * 4, hipMemcpyDeviceToHost, stream));
+        if (classes) UG_HIP(hipMemcpyAsync(host + set_words, cur + ((size_t)bw + (size_t)q * windows) * Cfg::PT_WORDS, set_words * 4, hipMemcpyDeviceToHost, stream));
+        if (specials) UG_HIP(hipMemcpyAsync(host + 2 * set_words, cur + ((size_t)tree_sets + (size_t)q * wsets) * Cfg::PT_WORDS,
+                                            (size_t)wsets * Cfg::PT_WORDS * 4, hipMemcpyDeviceToHost, stream));
+        UG_HIP(hipMemcpyAsync(host + MSM_PENDING_WORDS - 1, s.meta + 7, 4, hipMemcpyDeviceToHost, stream));
     }
 }
 template <class Cfg>
@@ -1110,16 +1124,35 @@ MsmPending msm_enqueue(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases,
     return pend;
 }
 
-// Horner over the bucket sets, top first (one set with window tables)
+// Horner over the window sets, top first (one set with window tables). With bucket classes (internal.hpp: BucketClasses) a
+// window's sum is put together from its owned residues' sets: a digit in residue r = r0 + j, local bucket k, has the magnitude
+// Q (k + 1) - m_j with m_j = Q - 1 - r0 - j, so the window's sum is  Q * sum_j S1_j  -  sum_j m_j S0_j  +  the specials' sum;
+// m_j falls by one per set, so the middle term is m_last * (sum of all S0) plus the running sums of S0_0 .. S0_(cnt-2).
 template <class Cfg>
 XYZZ<typename Cfg::F> msm_collect(const MsmPending& p) {
     typedef typename Cfg::F F;
     XYZZ<F> acc = xyzz_inf<F>();
     if (p.empty) return acc;
     if (p.host[MSM_PENDING_WORDS - 1]) throw std::runtime_error("msm: the schedule's sort gave up waiting for a tile (look-back timeout)");
-    for (int w = p.bucket_windows - 1; w >= 0; w--) {
+    const int sets = p.window_sets * p.class_sets;
+    auto point = [&](int idx) { return Cfg::from_words(p.host + (size_t)idx * Cfg::PT_WORDS, 1); };
+    for (int w = p.window_sets - 1; w >= 0; w--) {
         for (int k = 0; k < p.c; k++) acc = xyzz_dbl(acc);
-        acc = xyzz_add(acc, Cfg::from_words(p.host + (size_t)w * Cfg::PT_WORDS, 1));
+        if (!p.cls.on()) { acc = xyzz_add(acc, point(w)); continue; }
+        const int cnt = p.class_sets;
+        XYZZ<F> s1 = xyzz_inf<F>(), s0_all = xyzz_inf<F>(), run = xyzz_inf<F>(), steps = xyzz_inf<F>();
+        for (int j = 0; j < cnt; j++) {
+            s1 = xyzz_add(s1, point(w * cnt + j));
+            const XYZZ<F> s0 = point(sets + w * cnt + j);
+            s0_all = xyzz_add(s0_all, s0);
+            if (j + 1 < cnt) { run = xyzz_add(run, s0); steps = xyzz_add(steps, run); }      // sum_j (cnt - 1 - j) S0_j
+        }
+        for (int k = 0; k < p.cls.q_log; k++) s1 = xyzz_dbl(s1);                              // Q * sum S1
+        const u32 m_last = (1u << p.cls.q_log) - p.cls.r0 - (u32)cnt;                          // m of the last owned residue
+        XYZZ<F> minus = xyzz_add(steps, xyzz_mul_scalar(s0_all, &m_last, 9));
+        XYZZ<F> wsum = xyzz_add(s1, xyzz_neg(minus));
+        if (p.cls.specials) wsum = xyzz_add(wsum, point(2 * sets + w));
+        acc = xyzz_add(acc, wsum);
     }
     return acc;
 }

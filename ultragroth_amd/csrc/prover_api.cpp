@@ -214,6 +214,24 @@ struct Range { uint64_t lo, hi; };
 Range shardRange(uint64_t n, int rank, int count) {
     return Range{n * (uint64_t)rank / (uint64_t)count, n * (uint64_t)(rank + 1) / (uint64_t)count};
 }
+// What one rank of a many-device Groth16 prover owns (made by shardLayouts below). Two ways to cut the
+// witness products (S1-S4, src/groth16.cpp:55-64) over the ranks, and any product of the two:
+//   by base-point range   rank k holds the points and scalars of a contiguous range `w` of the witness-indexed sections
+//   by bucket class       the ranks of a group hold the SAME range `w` (all of it when there is one group) with its whole window
+//                         tables, and each takes the entries of its residues [r0, r0 + cnt) of the bucket ids mod 2^qLog
+//                         (ug_schedule_set_classes; the lowest bucket ids by scalar range `sp` instead)
+// The H product (S10, :154) is always cut by base-point range `h` (h is made in slices); chain ranks may get none of it.
+struct ShardLayout {
+    Range w{0, 0}, h{0, 0};
+    int qLog = 0;
+    uint32_t r0 = 0, cnt = 1;
+    Range sp{0, 0};
+    unsigned chains = 0;          // bit k: this rank runs chain k of the H polynomial (:66-140)
+};
+constexpr uint32_t SHARD_SPECIALS = 16;      // digits 1 .. 16 of every window are owned by scalar range (bits and small constants of a witness)
+// bucket classes per group of B ranks: about sixteen residues per rank (its share of the entries in steps of ~ 6 % of itself, and
+// 2 x 16 + 1 points per result block), 128 at most
+inline int shardQLog(int B) { int q = 4; while (q < 7 && (1 << q) < 16 * B) q++; return q; }
 
 // ---- common device-side state of a prover -------------------------------------------------------------------
 struct DeviceProver {
@@ -518,7 +536,8 @@ public:
     };
     struct Ranges { Range w, c, h; };
     // the slices of rank `rank` of `count` (witnessRange: chosen by the caller, else the even split); C follows the witness slice
-    static Ranges shardRanges(uint64_t M, uint64_t nPublic, uint64_t N, int rank, int count, const Range* witnessRange) {
+    static Ranges shardRanges(uint64_t M, uint64_t nPublic, uint64_t N, int rank, int count, const Range* witnessRange,
+                              const Range* hRange = nullptr) {
         if (count < 1 || rank < 0 || rank >= count) throw std::invalid_argument("invalid shard rank / count");
         if (M < nPublic + 1) throw std::invalid_argument("zkey header: nVars smaller than nPublic + 1");
         Ranges r;
@@ -528,6 +547,10 @@ public:
             r.w = *witnessRange;
         }
         r.h = shardRange(N, rank, count);
+        if (hRange) {
+            if (hRange->lo > hRange->hi || hRange->hi > N) throw std::invalid_argument("h range outside [0, domainSize]");
+            r.h = *hRange;
+        }
         const uint64_t shift = nPublic + 1, nC = M - nPublic - 1;
         r.c.lo = r.w.lo > shift ? r.w.lo - shift : 0;
         r.c.hi = r.w.hi > shift ? r.w.hi - shift : 0;
@@ -540,9 +563,13 @@ public:
     // ranks itself (ug_groth16_prover_create_sharded_range); nullptr = the even split
     // runsChain = false: this rank will never be asked for an H-polynomial chain (hpolyChain / run), so it keeps no coefficient
     // matrix, twiddles or NTT vectors (ranks 3 and up of a many-device prover)
+    // layout (optional): this rank's part of a many-device layout -- overrides the witness range, gives the h range and the
+    // bucket classes of the witness products
     Groth16Prover(const void* zkey, unsigned long long zkeySize, int device, int rank, int count, const Range* witnessRange = nullptr,
-                  bool runsChain = true)
+                  bool runsChain = true, const ShardLayout* layout = nullptr)
         : rank_(rank), count_(count) {
+        if (layout) layout_ = *layout;
+        haveLayout_ = layout != nullptr;
         if (count < 1 || rank < 0 || rank >= count) throw std::invalid_argument("invalid shard rank / count");
         BinFile f(zkey, zkeySize, "zkey", 1);
         hdr_ = loadZkeyHeader(f, false);
@@ -562,8 +589,10 @@ public:
     }
     // from the header section and this rank's slices (ug_groth16_prover_create_sharded_slices)
     Groth16Prover(const void* header, unsigned long long headerSize, const Sources& slices, int device, int rank, int count,
-                  const Range* witnessRange)
+                  const Range* witnessRange, const ShardLayout* layout = nullptr)
         : rank_(rank), count_(count) {
+        if (layout) layout_ = *layout;
+        haveLayout_ = layout != nullptr;
         // a header-only container so that the one header parser serves both forms
         std::vector<uint8_t> mini;
         auto put32 = [&](uint32_t v) { for (int k = 0; k < 4; k++) mini.push_back((uint8_t)(v >> (8 * k))); };
@@ -595,7 +624,8 @@ private:
         const uint8_t *coefs = src.coefs, *pA = src.pA, *pB1 = src.pB1, *pB2 = src.pB2, *pC = src.pC, *pH = src.pH;
         haveHpoly_ = src.haveCoefs;
 
-        const Ranges rg = shardRanges(M, hdr_.nPublic, N, rank, count, witnessRange);
+        const Ranges rg = haveLayout_ ? shardRanges(M, hdr_.nPublic, N, rank, count, &layout_.w, &layout_.h)
+                                      : shardRanges(M, hdr_.nPublic, N, rank, count, witnessRange);
         wr_ = rg.w;                              // witness scalars (and A/B1/B2 points) of this rank
         hr_ = rg.h;                              // h scalars (and H points) of this rank
         const uint64_t cLo = rg.c.lo, cHi = rg.c.hi;
@@ -685,6 +715,14 @@ private:
         ugCheck(ug_dvec_create(d_.ctx2, N, &d_.h));
         ugCheck(ug_schedule_create(d_.ctx, &d_.sw));
         ugCheck(ug_schedule_create(d_.ctx2, &d_.sh));
+        if (haveLayout_ && layout_.qLog) {
+            // Bucket classes: this rank's witness schedule keeps its residues' entries only. They exist for the window-table form
+            // (ONE bucket set per product, so that a class is a slice of it): without the tables every window would bring its own
+            // sets of every owned residue, and the result blocks would not hold them.
+            if (!tableW_) throw std::runtime_error("a bucket-class layout needs the fixed-base window tables (device memory short, or ULTRAGROTH_TABLES=0)");
+            if (layout_.sp.lo > layout_.sp.hi || layout_.sp.hi > M) throw std::invalid_argument("special-bucket range outside [0, nVars]");
+            ugCheck(ug_schedule_set_classes(d_.sw, layout_.qLog, layout_.r0, layout_.cnt, SHARD_SPECIALS, layout_.sp.lo, layout_.sp.hi - layout_.sp.lo));
+        }
         ugCheck(ug_ctx_sync(d_.ctx));                // the table builds queued above end here: create returns a finished prover
         ugCheck(ug_ctx_sync(d_.ctx2));
     }
@@ -916,6 +954,7 @@ public:
     }
     void hpolyCombine(void* da, void* db, void* dc) override {
         uint64_t cnt = hr_.hi - hr_.lo;
+        if (!cnt) return;                            // (a chain rank of a bucket-class layout takes no part in the H product)
         ug_dvec *a = nullptr, *b = nullptr, *c = nullptr;
         ugCheck(ug_dvec_wrap(d_.ctx2, da, cnt, &a));
         ugCheck(ug_dvec_wrap(d_.ctx2, db, cnt, &b));
@@ -1051,6 +1090,8 @@ private:
     uint64_t maxRange_ = MAX_RANGE;    // ULTRAGROTH_MAX_RANGE lowers it (tests: the piecewise path without a 2^27 circuit)
     int tableW_ = 0, tableH_ = 0;      // window widths of the fixed-base tables (0: classic windows), planWindowTables
     int rank_, count_;
+    ShardLayout layout_;               // this rank's part of a many-device layout (haveLayout_), else unused
+    bool haveLayout_ = false;
     ZkeyHeader hdr_;
     std::vector<uint8_t> vk_, publicPart_;
     Range wr_{0, 0}, hr_{0, 0};
@@ -1541,6 +1582,116 @@ std::vector<Range> balancedWitnessRanges(uint64_t nVars, int count) {
     return out;
 }
 
+// ---- the layout of a many-device Groth16 prover: which rank owns what (ShardLayout) -----------------------------------------
+// R ranks in P groups of B = R / P: group p holds one base-point range of the witness-indexed sections, its B ranks the bucket
+// classes of that range's products (B = 1: base-point ranges only, the layout of rounds 1-3). Chains k of the H polynomial run on
+// ranks k mod R. The shares are chosen so that the ranks finish together, from a cost model in units of "all witness products of
+// a proof" measured at 2^24 on one rank of eight (tools/phase_times.py, profiles/r04_rank_phases_*.txt): a chain costs
+// CHAIN_SHARE; a rank's witness products cost CLASS_FIXED + its share of the entries (the part that does not shrink with the
+// share: every rank recodes all scalars of its range, and the kernels behind the accumulation have their latency floor); its H
+// product H_FIXED + H_PART * its share of h. With five ranks or more the chain ranks take no part of the H product at all.
+constexpr double CLASS_FIXED = 0.027, H_FIXED = 0.014, H_PART = 0.175;
+static const double CHAIN_SHARE_CLASSES[3] = {0.058, 0.058, 0.070};
+// device memory a rank needs for the window tables of n witness points and their schedules (planTableWidthsAhead's arithmetic)
+uint64_t classTablesNeed(uint64_t n) {
+    if (n < TABLES_MIN_SCALARS || n > TABLES_MAX_SCALARS) return ~(uint64_t)0;
+    const int c = ug_msm_table_window(n);
+    return ug_bases_tables_bytes(3 * n, 0, c) + ug_bases_tables_bytes(n, 1, c) + n * (3 * 64 + 128) + 24 * n * (uint64_t)((255 + c - 1) / c) + n * 32;
+}
+// P for `R` ranks (0 = decide here): ULTRAGROTH_SHARD=PxB when it fits R, else BASE-POINT RANGES (P = R). Bucket classes are
+// built, tested and kept as an option, not chosen: measured on one rank of eight at 2^24 (profiles/r04_rank_phases_classes.txt),
+// a class rank's witness products take 21.1 ms against 20.2 ms for the base-point rank -- it saves the thirteenth window and
+// half the buckets (2.7 ms of accumulation) and pays them back recoding ALL scalars of its range for its eighth of the entries
+// (schedule 3.3 instead of 0.8 ms); the per-entry rate of the accumulation depends on the entries in flight, not on the window
+// width. ULTRAGROTH_SHARD=auto takes classes from four ranks on when the tables of a group's range fit a device (hbmBytes,
+// 0 = 256 GiB), in as few groups as that allows.
+int pointRangeGroups(uint64_t M, int R, int wanted, uint64_t hbmBytes) {
+    auto valid = [&](int P) { return P >= 1 && P <= R && R % P == 0; };
+    if (wanted && valid(wanted)) return wanted;
+    const char* e = getenv("ULTRAGROTH_SHARD");
+    if (!e || !*e) return R;
+    int P = 0, B = 0;
+    if (sscanf(e, "%dx%d", &P, &B) == 2 && valid(P) && P * B == R) return P;
+    if (strcmp(e, "auto") != 0 || R < 4) return R;
+    if (!hbmBytes) hbmBytes = (uint64_t)256 << 30;
+    for (P = 1; P < R; P *= 2) {
+        if (!valid(P)) continue;
+        const uint64_t need = classTablesNeed(M / (uint64_t)P + 1);
+        if (need != ~(uint64_t)0 && need + ((uint64_t)8 << 30) <= hbmBytes - hbmBytes / 8) return P;
+    }
+    return R;
+}
+std::vector<ShardLayout> shardLayouts(uint64_t M, uint64_t N, int R, int P) {
+    if (R < 1 || P < 1 || R % P) throw std::invalid_argument("invalid shard layout");
+    std::vector<ShardLayout> out(R);
+    for (int c = 0; c < 3; c++) out[c % R].chains |= 1u << c;
+    const int B = R / P;
+    if (B == 1) {                                   // base-point ranges only: chain ranks get fewer points, H split evenly
+        const std::vector<Range> wr = balancedWitnessRanges(M, R);
+        for (int k = 0; k < R; k++) { out[k].w = wr[k]; out[k].h = shardRange(N, k, R); out[k].sp = wr[k]; }
+        return out;
+    }
+    // who takes part in the H product, and every rank's share of the witness entries
+    std::vector<double> chain(R, 0.0), hs(R, 0.0), f(R, 0.0);
+    for (int c = 0; c < 3; c++) chain[c % R] += CHAIN_SHARE_CLASSES[c];
+    int takers = 0;
+    for (int k = 0; k < R; k++) if (R < 5 || !out[k].chains) takers++;
+    double total = 1.0;
+    for (int k = 0; k < R; k++) {
+        hs[k] = (R < 5 || !out[k].chains) ? 1.0 / takers : 0.0;
+        total += chain[k] + CLASS_FIXED + (hs[k] > 0 ? H_FIXED + H_PART * hs[k] : 0.0);
+    }
+    const double T = total / R;
+    double fsum = 0;
+    for (int k = 0; k < R; k++) {
+        f[k] = std::max(T - chain[k] - CLASS_FIXED - (hs[k] > 0 ? H_FIXED + H_PART * hs[k] : 0.0), 0.02);
+        fsum += f[k];
+    }
+    for (double& x : f) x /= fsum;
+    {   // h ranges: contiguous, in rank order
+        double run = 0;
+        uint64_t lo = 0;
+        for (int k = 0; k < R; k++) {
+            run += hs[k];
+            const uint64_t hi = k == R - 1 ? N : std::min<uint64_t>(N, (uint64_t)((double)N * run + 0.5));
+            out[k].h = Range{lo, std::max(lo, hi)};
+            lo = out[k].h.hi;
+        }
+    }
+    const int qLog = shardQLog(B);
+    const uint32_t Q = 1u << qLog;
+    double before = 0;
+    uint64_t wlo = 0;
+    for (int p = 0; p < P; p++) {
+        double F = 0;
+        for (int k = p * B; k < (p + 1) * B; k++) F += f[k];
+        const uint64_t whi = p == P - 1 ? M : std::min<uint64_t>(M, (uint64_t)((double)M * (before + F) + 0.5));
+        before += F;
+        // the group's residues: cnt_k ~ Q f_k / F, at least one each, by largest remainder
+        std::vector<uint32_t> cnt(B, 1);
+        std::vector<std::pair<double, int>> rem;
+        uint32_t given = B;
+        for (int j = 0; j < B; j++) {
+            const double want = (double)(Q - B) * f[p * B + j] / F;          // (beyond the one every rank has)
+            cnt[j] += (uint32_t)want; given += (uint32_t)want;
+            rem.push_back({want - (double)(uint32_t)want, j});
+        }
+        std::sort(rem.begin(), rem.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+        for (size_t q = 0; given < Q; q = (q + 1) % rem.size()) { cnt[rem[q].second]++; given++; }
+        uint32_t r0 = 0;
+        const uint64_t nw = whi - wlo;
+        for (int j = 0; j < B; j++) {
+            ShardLayout& L = out[p * B + j];
+            L.w = Range{wlo, whi};
+            L.qLog = qLog; L.r0 = r0; L.cnt = cnt[j];
+            L.sp = Range{wlo + nw * r0 / Q, wlo + nw * (r0 + cnt[j]) / Q};       // the special buckets: the same shares, by scalar range
+            r0 += cnt[j];
+        }
+        wlo = whi;
+    }
+    return out;
+}
+
 class MultiGroth16Prover : public ProverBase {
 public:
     MultiGroth16Prover(const void* zkey, unsigned long long zkeySize, const std::vector<int>& devices) {
@@ -1549,19 +1700,38 @@ public:
         ZkeyHeader h = loadZkeyHeader(f, false);
         if (!h.rIsBn254) throw std::invalid_argument("zkey curve not supported");
         nPublic_ = h.nPublic; domain_ = h.domainSize;
-        const std::vector<Range> wr = balancedWitnessRanges(h.nVars, R);
-        ranks_.resize(R);
-        // every rank uploads and converts its slices on its own device, all at once
+        // the layout: bucket classes when the tables of a group's range fit the devices (asked from the first one), else -- or when
+        // a rank then fails to build its tables after all -- base-point ranges
         const bool oneShot = g_oneShotProver;          // (thread-local: handed to the creating threads by value)
-        std::vector<std::future<void>> jobs;
-        for (int k = 0; k < R; k++)
-            jobs.push_back(std::async(std::launch::async, [&, k, oneShot] {
+        uint64_t freeB = 0, totalB = 0;
+        { ug_ctx* probe = nullptr; ugCheck(ug_ctx_create(&probe, devices[0])); ug_ctx_mem_info(probe, &freeB, &totalB); ug_ctx_destroy(probe); }
+        const char* te = getenv("ULTRAGROTH_TABLES");
+        const bool tablesOff = (te && te[0] == '0') || (oneShot && !(te && te[0] == '2'));
+        int P = tablesOff ? R : pointRangeGroups(h.nVars, R, 0, freeB);
+        for (;;) {
+            const std::vector<ShardLayout> lay = shardLayouts(h.nVars, h.domainSize, R, P);
+            ranks_.clear();
+            ranks_.resize(R);
+            // every rank uploads and converts its slices on its own device, all at once (ranks that share a device -- rehearsals --
+            // and hold whole tables each: one after the other, or the devices' memory would be asked for R times over)
+            std::vector<std::future<void>> jobs;
+            auto make = [&, oneShot](int k) {
                 g_oneShotProver = oneShot;
-                ranks_[k].reset(new Groth16Prover(zkey, zkeySize, devices[k], k, R, &wr[k], /*runsChain*/ k < 3));
-            }));
-        std::exception_ptr failure;
-        for (auto& j : jobs) { try { j.get(); } catch (...) { if (!failure) failure = std::current_exception(); } }
-        if (failure) { ranks_.clear(); std::rethrow_exception(failure); }
+                ranks_[k].reset(new Groth16Prover(zkey, zkeySize, devices[k], k, R, nullptr, /*runsChain*/ lay[k].chains != 0, &lay[k]));
+            };
+            std::exception_ptr failure;
+            for (int k = 0; k < R; k++) {
+                bool shared = false;
+                for (int q = 0; q < k; q++) shared = shared || devices[q] == devices[k];
+                if (P < R && shared) { for (auto& j : jobs) { try { j.get(); } catch (...) { if (!failure) failure = std::current_exception(); } } jobs.clear(); }
+                jobs.push_back(std::async(std::launch::async, make, k));
+            }
+            for (auto& j : jobs) { try { j.get(); } catch (...) { if (!failure) failure = std::current_exception(); } }
+            if (!failure) { layouts_ = lay; break; }
+            ranks_.clear();
+            if (P == R) std::rethrow_exception(failure);
+            P = R;                                      // once more with base-point ranges
+        }
         // the evaluation vectors of the three chains (on the devices of ranks k mod R) and every rank's slices of them
         for (int c = 0; c < 3; c++) {
             ugCheck(ug_dvec_create(ranks_[c % R]->ctx2(), domain_, &full_[c]));
@@ -1616,7 +1786,7 @@ public:
                         for (int c = 0; c < 3; c++) chainReady[c].get();    // (a chain rank's failure is rethrown here)
                         unsigned long long first = 0, cnt = 0;
                         p.hRange(&first, &cnt, nullptr);
-                        for (int c = 0; c < 3; c++) ugCheck(ug_dvec_copy(slices_[k].v[c], 0, full_[c], first, cnt));
+                        for (int c = 0; c < 3 && cnt; c++) ugCheck(ug_dvec_copy(slices_[k].v[c], 0, full_[c], first, cnt));
                         p.hpolyCombine(ug_dvec_device_ptr(slices_[k].v[0]), ug_dvec_device_ptr(slices_[k].v[1]), ug_dvec_device_ptr(slices_[k].v[2]));
                         uint8_t hpart[UG_GROTH16_PARTIALS_SIZE];
                         p.runHMsm(hpart);
@@ -1657,6 +1827,7 @@ public:
 private:
     struct Slices { ug_dvec* v[3] = {nullptr, nullptr, nullptr}; };
     std::vector<std::unique_ptr<Groth16Prover>> ranks_;
+    std::vector<ShardLayout> layouts_;
     ug_dvec* full_[3] = {nullptr, nullptr, nullptr};
     std::vector<Slices> slices_;
     uint32_t nPublic_ = 0, domain_ = 0;
@@ -2271,6 +2442,42 @@ int ug_groth16_shard_ranges(unsigned long long n_vars, unsigned long long n_publ
         out[0] = r.w.lo; out[1] = r.w.hi; out[2] = r.c.lo; out[3] = r.c.hi; out[4] = r.h.lo; out[5] = r.h.hi;
     } catch (...) { return PROVER_ERROR; }
     return PROVER_OK;
+}
+int ug_groth16_shard_layout(unsigned long long n_vars, unsigned long long n_public, unsigned long long domain_size, int shard_rank,
+                            int shard_count, int point_ranges, unsigned long long hbm_bytes, unsigned long long out[12]) {
+    try {
+        if (shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count || !out || point_ranges < 0) return PROVER_ERROR;
+        const int P = pointRangeGroups(n_vars, shard_count, point_ranges, hbm_bytes);
+        const ShardLayout L = shardLayouts(n_vars, domain_size, shard_count, P)[shard_rank];
+        Groth16Prover::Ranges r = Groth16Prover::shardRanges(n_vars, n_public, domain_size, shard_rank, shard_count, &L.w, &L.h);
+        out[0] = r.w.lo; out[1] = r.w.hi; out[2] = r.c.lo; out[3] = r.c.hi; out[4] = r.h.lo; out[5] = r.h.hi;
+        out[6] = (unsigned long long)L.qLog; out[7] = L.r0; out[8] = L.cnt; out[9] = L.sp.lo; out[10] = L.sp.hi; out[11] = L.chains;
+    } catch (...) { return PROVER_ERROR; }
+    return PROVER_OK;
+}
+int ug_groth16_prover_create_sharded_layout(void** prover_object, const void* zkey_header, unsigned long long zkey_header_size,
+                                            const void* coefs, unsigned long long n_coefs, const void* points_a, const void* points_b1,
+                                            const void* points_b2, const void* points_c, const void* points_h,
+                                            const unsigned long long slice_bytes[5], int device, int shard_rank, int shard_count,
+                                            const unsigned long long layout[12], char* error_msg, unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL) throw std::invalid_argument("Null prover object");
+    if (zkey_header == NULL) throw std::invalid_argument("Null zkey buffer");
+    if (slice_bytes == NULL) throw std::invalid_argument("Null slice sizes");
+    if (layout == NULL) throw std::invalid_argument("Null layout");
+    Groth16Prover::Sources src;
+    src.sliceBytes = slice_bytes;
+    src.coefs = static_cast<const uint8_t*>(coefs); src.nCoefs = coefs ? n_coefs : 0; src.haveCoefs = coefs != NULL;
+    src.pA = static_cast<const uint8_t*>(points_a); src.pB1 = static_cast<const uint8_t*>(points_b1);
+    src.pB2 = static_cast<const uint8_t*>(points_b2); src.pC = static_cast<const uint8_t*>(points_c);
+    src.pH = static_cast<const uint8_t*>(points_h);
+    ShardLayout L;
+    L.w = Range{layout[0], layout[1]}; L.h = Range{layout[4], layout[5]};
+    if (layout[6] > 8 || layout[7] > 255 || layout[8] > 256) throw std::invalid_argument("invalid bucket classes in the layout");
+    L.qLog = (int)layout[6]; L.r0 = (uint32_t)layout[7]; L.cnt = (uint32_t)layout[8]; L.sp = Range{layout[9], layout[10]};
+    L.chains = (unsigned)layout[11];
+    *prover_object = static_cast<ProverBase*>(new Groth16Prover(zkey_header, zkey_header_size, src, device, shard_rank, shard_count, nullptr, &L));
+    API_CATCH
 }
 int ug_groth16_balanced_witness_range(unsigned long long n_vars, int shard_rank, int shard_count, unsigned long long out[2]) {
     try {

@@ -34,13 +34,14 @@ constexpr int SORT_MAX_IPT = 16;              // most pairs a lane holds per til
 constexpr int SORT_FUSED_MAX_WINDOWS = 16;    // the fused first pass takes whole scalars per lane: windows * scalars_per_lane <= SORT_MAX_IPT
 constexpr int SORT_MAX_BINS = 256;
 constexpr u32 LB_VALUE_MASK = (1u << 30) - 1, LB_AGGREGATE = 1u << 30, LB_PREFIX = 2u << 30;
+constexpr u32 SORT_MAX_GRID = 4096;           // workgroups of a pass (each takes tiles until none is left): a few per CU slot
 constexpr u32 SPIN_LIMIT = 1u << 20;          // a look-back that has not seen its predecessor by then gives up and flags the schedule
 
 struct SortPassArgs {
     // source: either pair arrays ...
     const u32* keys_in; const u32* vals_in;
-    // ... or the scalars themselves (first pass): n scalars of 32 bytes, recoded as msm_digits does
-    const u32* scalars; u64 n; int c, windows; u32 buckets, sentinel; int tables;
+    // ... or the scalars themselves (first pass): plan.n scalars of 32 bytes, recoded by recode_scalar
+    const u32* scalars; DigitPlan plan;
     u32* keys_out; u32* vals_out;
     u64 n_pairs;                      // pairs the source holds (the rest of the last tile is padding made on the fly)
     u32 n_moved;                      // pairs every pass moves (real ones + the first pass's padding): nothing is written beyond
@@ -51,7 +52,8 @@ struct SortPassArgs {
     const u32* n_valid;               // drop mode (see RadixSorter::sort): the pairs that exist after the first pass -- on the device
     int drop;                         // drop mode, first pass: pairs with key >= sentinel (zero digits, padding) are not written at all
     u32* lookback;                    // tiles x 2^bins_log status words, zeroed
-    u32* tile_counter;                // zeroed: hands out tile numbers in start order
+    u32* tile_counter;                // zeroed: hands out tile numbers in the order they are taken
+    u32 n_tiles;                      // fused first pass: its tile count (the other passes end at the pair count)
     u32* error_flag;
 };
 
@@ -63,12 +65,23 @@ __device__ __forceinline__ bool scalar_geq_r(const u32* s) {
     }
     return true;
 }
-// the signed-digit recoding of one scalar (same rule as the pair form it replaces: digit in (-2^(c-1), 2^(c-1)], a carry into the
-// next window; a zero digit gets the sentinel key); f(window, key, val) is called for every window in order
+// The bucket key of a digit of magnitude mag >= 1 in window w of scalar i, or the sentinel when this schedule does not keep it.
+// Without classes: set w (one set in all with window tables), bucket mag - 1. With classes (internal.hpp: BucketClasses): the
+// lowest bucket ids are kept by scalar range and get ids behind the regular sets, the others by the residue of the bucket id.
+__device__ __forceinline__ u32 digit_key(const DigitPlan& d, int w, u32 mag, u64 i) {
+    const u32 b = mag - 1;
+    const u32 wset = d.tables ? 0u : (u32)w;
+    if (d.q_log == 0) return wset * d.buckets + b;
+    if (b < d.specials) return (i >= d.sp_lo && i < d.sp_hi) ? d.special_base + wset * d.specials + b : d.sentinel;
+    const u32 j = (b & ((1u << d.q_log) - 1)) - d.r0;          // (unsigned: residues below r0 wrap to large values)
+    return j < d.cnt ? (wset * d.cnt + j) * d.buckets + (b >> d.q_log) : d.sentinel;
+}
+// the signed-digit recoding of one scalar: digit in (-2^(c-1), 2^(c-1)], a carry into the next window; a zero digit (and a digit
+// another rank owns) gets the sentinel key; f(window, key, val) is called for every window in order
 template <class Fn>
-__device__ __forceinline__ void recode_scalar(const u32* scalars, u64 i, u64 n, int c, int windows, u32 buckets, u32 sentinel, int tables, Fn&& f) {
-    if (i >= n) {                                     // padding of the last tile
-        for (int w = 0; w < windows; w++) f(w, 0xffffffffu, 0u);
+__device__ __forceinline__ void recode_scalar(const u32* scalars, u64 i, const DigitPlan& d, Fn&& f) {
+    if (i >= d.n) {                                   // padding of the last tile
+        for (int w = 0; w < d.windows; w++) f(w, 0xffffffffu, 0u);
         return;
     }
     u32 s[10];
@@ -79,32 +92,39 @@ __device__ __forceinline__ void recode_scalar(const u32* scalars, u64 i, u64 n, 
         u64 borrow = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            u64 d = (u64)s[k] - FrParams::q32[k] - borrow;
-            s[k] = (u32)d; borrow = (d >> 32) & 1;
+            u64 dd = (u64)s[k] - FrParams::q32[k] - borrow;
+            s[k] = (u32)dd; borrow = (dd >> 32) & 1;
         }
     }
     u32 carry = 0;
+    const int c = d.c;
     const u32 half = 1u << (c - 1), full = 1u << c, mask = full - 1;
-    for (int w = 0; w < windows; w++) {
+    for (int w = 0; w < d.windows; w++) {
         const int bit = w * c, word = bit >> 5, sh = bit & 31;
         const u64 two = (u64)s[word] | ((u64)s[word + 1] << 32);
         const u32 raw = ((u32)(two >> sh) & mask) + carry;
-        const u32 set0 = tables ? 0u : (u32)w * buckets;
-        const u32 tag = tables ? (u32)w << TABLE_INDEX_BITS : 0u;
+        const u32 tag = d.tables ? (u32)w << TABLE_INDEX_BITS : 0u;
         u32 key, val;
-        if (raw > half) {
-            const u32 mag = full - raw;
+        if (raw > half) {                             // negative digit raw - 2^c, carry into the next window
+            const u32 mag = full - raw;               // 0 when the window was all ones and a carry came in
             carry = 1;
-            key = mag ? set0 + mag - 1 : sentinel;
+            key = mag ? digit_key(d, w, mag, i) : d.sentinel;
             val = (u32)i | tag | 0x80000000u;
-        } else { carry = 0; key = raw ? set0 + raw - 1 : sentinel; val = (u32)i | tag; }
+        } else { carry = 0; key = raw ? digit_key(d, w, raw, i) : d.sentinel; val = (u32)i | tag; }
         f(w, key, val);
     }
 }
 
+__global__ void digit_pairs_kernel(const u32* scalars, DigitPlan d, u32* keys, u32* vals) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.n) return;
+    recode_scalar(scalars, i, d, [&](int w, u32 key, u32 val) { keys[(u64)w * d.n + i] = key; vals[(u64)w * d.n + i] = val; });
+}
+
 struct SortHistArgs {
     const u32* keys_in;                // pair form (scalars == nullptr) ...
-    const u32* scalars; u64 n; int c, windows; u32 buckets, sentinel; int tables;       // ... or scalar form
+    const u32* scalars; DigitPlan plan;                                                 // ... or scalar form
+    u32 sentinel;
     u64 n_pairs, n_padded;             // padded: whole tiles (the padding pairs are counted: they take part in every pass)
     int passes; int shift[4]; int bins_log[4];
     u32* hist;                         // passes x 256 counters, zeroed
@@ -127,9 +147,9 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(SortHistArgs a
     };
     const u64 stride = (u64)gridDim.x * SORT_THREADS;
     if (a.scalars) {
-        const u64 lanes = a.n_padded / (u64)a.windows;            // one scalar (all its windows) per lane turn
+        const u64 lanes = a.n_padded / (u64)a.plan.windows;       // one scalar (all its windows) per lane turn
         for (u64 i = (u64)blockIdx.x * SORT_THREADS + threadIdx.x; i < lanes; i += stride)
-            recode_scalar(a.scalars, i, a.n, a.c, a.windows, a.buckets, a.sentinel, a.tables, [&](int, u32 key, u32) { count(key); });
+            recode_scalar(a.scalars, i, a.plan, [&](int, u32 key, u32) { count(key); });
     } else {
         for (u64 i = (u64)blockIdx.x * SORT_THREADS + threadIdx.x; i < a.n_padded; i += stride) count(i < a.n_pairs ? a.keys_in[i] : 0xffffffffu);
     }
@@ -162,16 +182,22 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const u32 bins = 1u << a.bins_log, dmask = bins - 1;
 
-    if (tid == 0) misc[0] = atomicAdd(a.tile_counter, 1u);           // tiles are numbered in the order they start
+    // drop mode, passes after the first: the pair count is the device's (what the first pass kept)
+    const u64 n_pairs = (!FROM_SCALARS && a.n_valid) ? (u64)*a.n_valid : a.n_pairs;
+    const u32 n_moved = (!FROM_SCALARS && a.n_valid) ? *a.n_valid : a.n_moved;
+    // A workgroup takes tiles until none is left (the grid is at most SORT_MAX_GRID workgroups: the host knows only an upper bound
+    // of the tile count when the first pass dropped pairs -- a circom-like witness, a schedule with bucket classes -- and a grid
+    // of that bound cost one same-address atomic, ~11 ns each, one after the other, per tile that then had nothing to do: 0.46
+    // of a 0.63 ms pass over an eighth of the pairs). Tiles are numbered in the order they are TAKEN, so a tile only ever waits
+    // for tiles that running workgroups hold.
+    for (;;) {
+    __syncthreads();                                                  // (the previous turn's LDS is done with)
+    if (tid == 0) misc[0] = atomicAdd(a.tile_counter, 1u);
     for (int i = tid; i < SORT_WAVES * SORT_MAX_BINS; i += SORT_THREADS) wcnt[i] = 0;
     __syncthreads();
     const u32 tile = misc[0];
     const u64 e0 = (u64)tile * T;
-    // drop mode, passes after the first: the pair count is the device's (what the first pass kept); tiles beyond it have nothing
-    // to do (tiles are numbered in start order, so these are simply the last numbers handed out: nobody waits for them)
-    const u64 n_pairs = (!FROM_SCALARS && a.n_valid) ? (u64)*a.n_valid : a.n_pairs;
-    const u32 n_moved = (!FROM_SCALARS && a.n_valid) ? *a.n_valid : a.n_moved;
-    if (!FROM_SCALARS && e0 >= n_pairs) return;
+    if (FROM_SCALARS ? tile >= a.n_tiles : e0 >= n_pairs) return;
 
     // ---- load (or make) the tile's pairs: lane holds pairs j = 0 .. ipt-1; wave-striped, so that (wave, j, lane) is memory order
     u32 key[SORT_MAX_IPT], val[SORT_MAX_IPT];
@@ -182,8 +208,8 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
         for (int j = 0; j < SORT_MAX_IPT; j++) { key[j] = 0xffffffffu; val[j] = 0; }
         for (int sc = 0; sc < a.spl; sc++) {
             const u64 i = ((u64)tile * SORT_THREADS + tid) * (u64)a.spl + (u64)sc;
-            const int j0 = sc * a.windows;
-            recode_scalar(a.scalars, i, a.n, a.c, a.windows, a.buckets, a.sentinel, a.tables, [&](int w, u32 k, u32 v) {
+            const int j0 = sc * a.plan.windows;
+            recode_scalar(a.scalars, i, a.plan, [&](int w, u32 k, u32 v) {
 #pragma unroll
                 for (int j = 0; j < SORT_MAX_IPT; j++) if (j == j0 + w) { key[j] = k; val[j] = v; }
             });
@@ -206,7 +232,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
     for (int j = 0; j < SORT_MAX_IPT; j++) {
         if (j < ipt) {
             const u32 d = (key[j] >> a.shift) & dmask;
-            const bool keep = !(FROM_SCALARS && a.drop) || key[j] < a.sentinel;      // (drop mode: zero digits and padding take no part)
+            const bool keep = !(FROM_SCALARS && a.drop) || key[j] < a.plan.sentinel;      // (drop mode: zero digits and padding take no part)
             u64 peers = __ballot(keep);
             for (int b = 0; b < a.bins_log; b++) {
                 const u64 vote = __ballot((d >> b) & 1u);
@@ -276,7 +302,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
     // ---- reorder through LDS: the tile's pairs in bin order ...
 #pragma unroll
     for (int j = 0; j < SORT_MAX_IPT; j++) {
-        if (j < ipt && (!(FROM_SCALARS && a.drop) || key[j] < a.sentinel)) {
+        if (j < ipt && (!(FROM_SCALARS && a.drop) || key[j] < a.plan.sentinel)) {
             const u32 d = (key[j] >> a.shift) & dmask;
             const u32 lp = texcl[d] + wcnt[wave * SORT_MAX_BINS + d] + rank[j];
             stage_k[lp] = key[j]; stage_v[lp] = val[j];
@@ -294,6 +320,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
             a.vals_out[pos] = stage_v[lp];
         }
     }
+    }      // the next tile
 }
 
 template <class T> void sort_alloc(T*& p, size_t bytes) { if (p) hipFree(p); p = nullptr; UG_HIP(hipMalloc(&p, bytes ? bytes : 4)); }
@@ -311,6 +338,12 @@ int radix_plan(int bits, int* shift, int* bins_log) {
         shift[p] = at; bins_log[p] = w; at += w;
     }
     return passes;
+}
+
+void digit_pairs(const u32* scalars, const DigitPlan& plan, u32* keys, u32* vals, hipStream_t stream) {
+    if (!plan.n) return;
+    hipLaunchKernelGGL(digit_pairs_kernel, dim3((unsigned)((plan.n + 255) / 256)), dim3(256), 0, stream, scalars, plan, keys, vals);
+    UG_KERNEL_CHECK();
 }
 
 void RadixSorter::reserve(u64 n_pairs, int ipt_min) {
@@ -336,8 +369,10 @@ void RadixSorter::release() {
 // and the number of pairs that remain is stored at *n_valid_out (before any pass runs). A circom-like witness is mostly zeros
 // and small values: more than half of its (scalar, window) pairs are zero digits that the other form carries through every pass
 // only to cut them off at the end. *dropped_out tells whether the mode was taken (it needs the scalar form).
-int RadixSorter::sort(const u32* scalars, u64 n, int c, int windows, u32 buckets, u32 sentinel, bool tables, u64 n_pairs, int bits,
+int RadixSorter::sort(const u32* scalars, const MsmGeometry& geo, u32 sentinel, u64 n_pairs, int bits,
                       u32* const buf_keys[2], u32* const buf_vals[2], u32* error_flag, hipStream_t stream, u32* n_valid_out, bool* dropped_out) {
+    const int windows = geo.windows;
+    const DigitPlan plan = geo.digit_plan();
     int shift[4], bins_log[4];
     const int passes = radix_plan(bits, shift, bins_log);
     if (passes > 4) throw std::logic_error("radix sort: key too wide");
@@ -363,7 +398,7 @@ int RadixSorter::sort(const u32* scalars, u64 n, int c, int windows, u32 buckets
     {
         SortHistArgs h;
         h.keys_in = fused ? nullptr : buf_keys[0];
-        h.scalars = fused ? scalars : nullptr; h.n = n; h.c = c; h.windows = windows; h.buckets = buckets; h.sentinel = sentinel; h.tables = tables ? 1 : 0;
+        h.scalars = fused ? scalars : nullptr; h.plan = plan; h.sentinel = sentinel;
         h.n_pairs = n_pairs; h.n_padded = fused ? n_padded : ((n_pairs + (u64)SORT_THREADS * ipt_pairs - 1) / ((u64)SORT_THREADS * ipt_pairs)) * ((u64)SORT_THREADS * ipt_pairs);
         h.passes = passes;
         for (int p = 0; p < 4; p++) { h.shift[p] = p < passes ? shift[p] : 0; h.bins_log[p] = p < passes ? bins_log[p] : 1; }
@@ -384,7 +419,7 @@ int RadixSorter::sort(const u32* scalars, u64 n, int c, int windows, u32 buckets
         const bool first_fused = fused && p == 0;
         SortPassArgs a;
         a.keys_in = buf_keys[cur]; a.vals_in = buf_vals[cur];
-        a.scalars = first_fused ? scalars : nullptr; a.n = n; a.c = c; a.windows = windows; a.buckets = buckets; a.sentinel = sentinel; a.tables = tables ? 1 : 0;
+        a.scalars = first_fused ? scalars : nullptr; a.plan = plan;
         const int dst = first_fused ? 0 : 1 - cur;
         a.keys_out = buf_keys[dst]; a.vals_out = buf_vals[dst];
         a.n_pairs = p == 0 ? n_pairs : moved;                // later passes read the padding of the first one as pairs
@@ -397,19 +432,21 @@ int RadixSorter::sort(const u32* scalars, u64 n, int c, int windows, u32 buckets
         a.lookback = lookback; a.tile_counter = counters + p; a.error_flag = error_flag;
         const u64 T = (u64)SORT_THREADS * (u64)a.ipt;
         const u64 tiles = (moved + T - 1) / T;
+        a.n_tiles = (u32)tiles;
         if (tiles > tiles_cap) throw std::logic_error("radix sort: look-back table too small");
         UG_HIP(hipMemsetAsync(lookback, 0, (size_t)tiles * ((size_t)1 << bins_log[p]) * 4, stream));
         const size_t lds = (2 * T + SORT_WAVES * SORT_MAX_BINS + 2 * SORT_MAX_BINS + 8) * 4;
+        const unsigned grid = (unsigned)std::min<u64>(tiles, SORT_MAX_GRID);
         static const int lbw = measure_env("UG_SORT_LBW") ? atoi(measure_env("UG_SORT_LBW")) : 4;      // A/B switch: look-back window
         if (lbw >= 16) {
-            if (first_fused) hipLaunchKernelGGL((radix_pass_kernel<true, 16>), dim3((unsigned)tiles), dim3(SORT_THREADS), lds, stream, a);
-            else hipLaunchKernelGGL((radix_pass_kernel<false, 16>), dim3((unsigned)tiles), dim3(SORT_THREADS), lds, stream, a);
+            if (first_fused) hipLaunchKernelGGL((radix_pass_kernel<true, 16>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
+            else hipLaunchKernelGGL((radix_pass_kernel<false, 16>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
         } else if (lbw >= 8) {
-            if (first_fused) hipLaunchKernelGGL((radix_pass_kernel<true, 8>), dim3((unsigned)tiles), dim3(SORT_THREADS), lds, stream, a);
-            else hipLaunchKernelGGL((radix_pass_kernel<false, 8>), dim3((unsigned)tiles), dim3(SORT_THREADS), lds, stream, a);
+            if (first_fused) hipLaunchKernelGGL((radix_pass_kernel<true, 8>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
+            else hipLaunchKernelGGL((radix_pass_kernel<false, 8>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
         } else {
-            if (first_fused) hipLaunchKernelGGL((radix_pass_kernel<true, 4>), dim3((unsigned)tiles), dim3(SORT_THREADS), lds, stream, a);
-            else hipLaunchKernelGGL((radix_pass_kernel<false, 4>), dim3((unsigned)tiles), dim3(SORT_THREADS), lds, stream, a);
+            if (first_fused) hipLaunchKernelGGL((radix_pass_kernel<true, 4>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
+            else hipLaunchKernelGGL((radix_pass_kernel<false, 4>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
         }
         UG_KERNEL_CHECK();
         cur = dst;

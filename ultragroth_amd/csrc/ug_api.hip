@@ -157,6 +157,16 @@ struct ug_index {
 };
 struct ug_schedule {
     ug_ctx* ctx; MsmSchedule sched; u64 first = 0;
+    BucketClasses cls;                    // ug_schedule_set_classes: applied by every later build
+    u64 sp_first = 0, sp_end = 0;         // ... its special-bucket scalar range, in the scalar vector's (global) indices
+    // the classes as the build of scalars [first, first + count) sees them (the scalar range clipped and made local)
+    BucketClasses classes_for(u64 first_, u64 count) const {
+        BucketClasses k = cls;
+        if (!k.on()) return k;
+        const u64 lo = sp_first > first_ ? sp_first - first_ : 0, hi = sp_end > first_ ? sp_end - first_ : 0;
+        k.sp_lo = (u32)(lo < count ? lo : count); k.sp_hi = (u32)(hi < count ? hi : count);
+        return k;
+    }
 };
 struct ug_hpoly {
     ug_ctx* ctx; CoefMatrix mat; NttPlan ntt; u32 domain = 0, nvars = 0;
@@ -698,7 +708,9 @@ int ug_schedule_build(ug_schedule* s, const ug_dvec* scalars, uint64_t first, ui
     fault_point(UG_FAULT_SCHEDULE_BUILD);
     ScopedTimer tm(c, &c->msm_ms);
     s->first = first;
-    s->sched.build(scalars->data + first * 8, MsmGeometry::choose(count), c->stream);
+    MsmGeometry g = MsmGeometry::choose(count);
+    g.set_classes(s->classes_for(first, count));
+    s->sched.build(scalars->data + first * 8, g, c->stream);
     tm.stop();
     UG_CATCH
 }
@@ -710,10 +722,27 @@ int ug_schedule_build_tables(ug_schedule* s, const ug_dvec* scalars, uint64_t fi
     ctx->use();
     fault_point(UG_FAULT_SCHEDULE_BUILD);
     MsmGeometry g = MsmGeometry::choose_tables(count, c);
+    g.set_classes(s->classes_for(first, count));
     ScopedTimer tm(ctx, &ctx->msm_ms);
     s->first = first;
     s->sched.build(scalars->data + first * 8, g, ctx->stream);
     tm.stop();
+    UG_CATCH
+}
+// Bucket classes for every later build of this schedule (include/ultragroth_hip.h; csrc/internal.hpp: BucketClasses)
+int ug_schedule_set_classes(ug_schedule* s, int q_log, uint32_t first_residue, uint32_t residues, uint32_t specials,
+                            uint64_t special_first, uint64_t special_count) {
+    UG_TRY
+    if (!s) throw std::invalid_argument("null argument");
+    if (q_log < 0 || q_log > 8) throw std::invalid_argument("bucket classes: q_log outside [0, 8]");
+    BucketClasses k;
+    if (q_log) {
+        if (residues < 1 || (uint64_t)first_residue + residues > ((uint64_t)1 << q_log)) throw std::invalid_argument("bucket classes: residues outside [0, 2^q_log)");
+        if (specials > MSM_MAX_SPECIALS) throw std::invalid_argument("bucket classes: more than 64 special buckets");
+        k.q_log = q_log; k.r0 = first_residue; k.cnt = residues; k.specials = specials;
+    }
+    s->cls = k;
+    s->sp_first = special_first; s->sp_end = special_first + special_count;
     UG_CATCH
 }
 void ug_schedule_destroy(ug_schedule* s) {
