@@ -439,15 +439,22 @@ def main():
         # coefficient records only on the ranks that run an H-polynomial chain: no rank holds the whole zkey
         domain = 1 << log_domain
         info = dict(domainSize=domain, nVars=domain - 1, nPublic=1, nCoefs=4 * domain)
-        wr = witness_slice(info, rank, world)
-        ranges = ug.ShardedGroth16Prover.shard_ranges(info["nVars"], 1, domain, rank, world, wr)
-        runs_chain = domain % world != 0 or any(k % world == rank for k in range(3))
-        header, coefs, slices = synth.build_circuit_slices(dev, log_domain, ranges, with_coefs=runs_chain, g1_only=args.g1_only)
+        # the layout is the library's (ug_groth16_shard_layout: what ULTRAGROTH_DEVICES uses inside it): base-point ranges with
+        # fewer points for the chain ranks, or -- ULTRAGROTH_SHARD=PxB -- bucket classes; a domain that does not split over the
+        # ranks keeps the even base-point form (every rank then forms the whole H polynomial itself)
+        even = domain % world != 0
+        layouts = [ug.ShardedGroth16Prover.shard_layout(info["nVars"], 1, domain, r, world, world if even else 0) for r in range(world)]
+        layout = layouts[rank]
+        if even:
+            rg = ug.ShardedGroth16Prover.shard_ranges(info["nVars"], 1, domain, rank, world, None)
+            layout = ug.ShardLayout([rg[0][0], rg[0][1], rg[1][0], rg[1][1], rg[2][0], rg[2][1], 0, 0, 1, rg[0][0], rg[0][1], 7])
+        runs_chain = even or bool(layout.chains)
+        header, coefs, slices = synth.build_circuit_slices(dev, log_domain, layout.ranges, with_coefs=runs_chain, g1_only=args.g1_only)
         wtns = synth.build_witness(log_domain, args.mix)
         zkey_bytes = len(header) + (len(coefs) if coefs is not None else 0) + sum(len(x) for x in slices)
         t0 = time.perf_counter()
         prover = ug.ShardedGroth16Prover.from_slices(header, coefs, info["nCoefs"], slices, local_rank, rank, world,
-                                                     witness_range=wr, public_size=82 + 4)
+                                                     public_size=82 + 4, layout=layout)
         create_s = time.perf_counter() - t0
         del coefs, slices
 
@@ -462,23 +469,27 @@ def main():
     split_h = dist is not None and info["domainSize"] % world == 0
     if split_h:
         n_dom = info["domainSize"]
-        sl = n_dom // world
+        # every rank's slice of h (the layouts' h ranges: even in the base-point form; in a bucket-class layout of five ranks or
+        # more the chain ranks take none). A scatter sends equal pieces: the longest range's length, from each rank's first
+        # element on (the vectors carry that much padding behind their end)
+        h_first = [L.h[0] for L in layouts]
+        sl = max(max(L.h[1] - L.h[0] for L in layouts), 1)
         ev_dev = "cuda"
-        fulls = {k: torch.empty((n_dom, 32), dtype=torch.uint8, device=ev_dev) for k in range(3) if k % world == rank}
+        fulls = {k: torch.empty((n_dom + sl, 32), dtype=torch.uint8, device=ev_dev) for k in layout.chains}
         bufs = torch.empty((3, sl, 32), dtype=torch.uint8, device=ev_dev)
 
     def scatter_slices(out, src_full, src):
         """returns a work handle (nccl: the three scatters, from three different roots, are in flight together) or None"""
         if backend == "nccl":
-            return dist.scatter(out, [src_full[r * sl:(r + 1) * sl] for r in range(world)] if rank == src else None, src=src,
+            return dist.scatter(out, [src_full[h_first[r]:h_first[r] + sl] for r in range(world)] if rank == src else None, src=src,
                                 async_op=True)
         o = torch.empty(out.shape, dtype=torch.uint8)               # gloo rehearsal: through host memory
-        lst = [src_full[r * sl:(r + 1) * sl].cpu() for r in range(world)] if rank == src else None
+        lst = [src_full[h_first[r]:h_first[r] + sl].cpu() for r in range(world)] if rank == src else None
         dist.scatter(o, lst, src=src)
         out.copy_(o)
         return None
 
-    my_chains = [k for k in range(3) if k % world == rank] if split_h else []
+    my_chains = list(layout.chains) if split_h else []
 
     # the 384-byte partial blocks of all ranks: ONE collective into one buffer and one copy back to the host (an EC addition is
     # not an RCCL reduction operator, so the blocks are gathered and added on the host: 5 points per rank)
@@ -672,8 +683,7 @@ def main():
     if rank == 0:
         (acc_ms, launches, entries), (g2_ms, g2_launches, g2_entries), (ntt_ms, ntt_launches, ntt_points) = kstats[:3]
         grp_ms, grp_launches, grp_entries = kstats[3]                          # A | B1 | C in one launch (three products per entry)
-        ws = witness_slice(info, 0, world)
-        n_local = (ws[1] - ws[0]) if ws else info["nVars"] // world
+        n_local = (layouts[0].witness[1] - layouts[0].witness[0]) if not single else info["nVars"]
         # Algorithmic bytes per launch (restated in DESIGN.md): G1 accumulation 96 B per point of
         # the slice (64 B affine base + 32 B scalar, each read once), G2 160 B per point, one NTT pass 64 B per point
         g1_bytes, g2_bytes, ntt_bytes = 96.0 * n_local, 160.0 * n_local, 64.0 * info["domainSize"]
@@ -738,7 +748,9 @@ def main():
                                       1 if args.g1_only else 2),
                        "log_domain": log_domain, "mix": args.mix, "overlap": bool(os.environ.get("ULTRAGROTH_OVERLAP", "0") not in ("", "0")),
                        "fused_g1_group": os.environ.get("ULTRAGROTH_FUSED", "1") != "0",
-                       "parallelism": "one GPU" if single else "base-range shard x%d%s" % (world, ", H-poly chains split over ranks" if split_h else "")},
+                       "parallelism": "one GPU" if single else "%s x%d%s" % (
+                           "base-range shard" if not layout.q_log else "bucket-class shard (%d point ranges)" % len({L.witness for L in layouts}),
+                           world, ", H-poly chains split over ranks" if split_h else "")},
             "msm_ms_per_proof": msm_ms / args.steps, "fft_ms_per_proof": fft_ms / args.steps,
             "split_region": ("device time of the MSM (S1-S4, S10) and FFT (S5-S9) parts of the K timed steps themselves" if single else
                              "stream time of rank 0's MSM and FFT parts over the K timed steps; its chains run on a second stream BESIDE "
