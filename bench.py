@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--overlap", action="store_true", help="ULTRAGROTH_OVERLAP=1: H branch on a second stream beside the witness MSMs "
                                                            "(faster, but per-kernel times and the MSM | FFT split stretch)")
     ap.add_argument("--ultra", action="store_true", help="BASELINE.json configs[4]: UltraGroth two-round prove (single GPU)")
+    ap.add_argument("--pmc-summary", default=None, help="summary of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload "
+                    "(tools/pmc_summary.py, made in the same gpurun call by tools/run_r4_prof.sh): `roofline.traffic` is then what those "
+                    "passes counted; without it the newest committed profiles/r*_pmc_summary.json is read and labelled as such")
     return ap.parse_args()
 
 
@@ -173,7 +176,12 @@ def bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_r
     runs its slices of the final MSMs; the three NTT chains go to ranks 0..2 with their evaluation vectors scattered
     slice-wise, as for Groth16; the 384-byte partial blocks are all-gathered and rank 0 finishes."""
     LOOKUP_LOG = 16                              # SURVEY.md section 8(d) cfg 5: lookup_size 2^16, chunks M/8
-    zkey, uwtns, info = synth.build_ultra_circuit(dev, args.log_domain, mix="C", lookup_log=LOOKUP_LOG)
+    zkey = None
+    if dist is None:
+        zkey, uwtns, info = synth.build_ultra_circuit(dev, args.log_domain, mix="C", lookup_log=LOOKUP_LOG)
+    else:                                        # N > 1: no rank makes (or holds) the whole zkey -- only its slices, below
+        info = synth.ultra_info(args.log_domain)
+        uwtns = synth.build_ultra_witness(args.log_domain, "C", lookup_log=LOOKUP_LOG)
     workload = ("ultragroth-bn254 2^%d constraints, two rounds, lookup 2^%d, circom-like witness (BASELINE.json configs[4] "
                 "shape; step = ultra_groth_prover_prove, one call after the other, .uwtns in host memory: the lookup completion "
                 "rewrites the witness every proof, so there is no resident-witness form of this step)" % (args.log_domain, LOOKUP_LOG))
@@ -181,7 +189,8 @@ def bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_r
 
     def expected():
         import oracle as O
-        return O.ultra_groth_prove(zkey, uwtns, *(int.from_bytes(b, "little") for b in FIXED))
+        zk = zkey if zkey is not None else synth.build_ultra_circuit(dev, args.log_domain, mix="C", lookup_log=LOOKUP_LOG)[0]
+        return O.ultra_groth_prove(zk, uwtns, *(int.from_bytes(b, "little") for b in FIXED))
 
     def line(elapsed, msm_ms, fft_ms, create_s, parallelism, **extra):
         print(json.dumps({
@@ -249,14 +258,20 @@ def bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_r
             sys.exit(3)
         return
 
-    t0 = time.perf_counter()
-    prover = ug.ShardedUltraGrothProver(zkey, local_rank, rank, world)
-    create_s = time.perf_counter() - t0
-    cuda = backend == "nccl"
     n_dom = info["domainSize"]
     split_h = n_dom % world == 0
-    sl = n_dom // world if split_h else 0
     my_chains = [k for k in range(3) if k % world == rank] if split_h else list(range(3))
+    # every rank from the header section and ITS slices of the point sections and index lists (ug_ultra_groth_prover_create_sharded_slices;
+    # the same generator entered at the slice), the coefficient records only on the ranks that run a chain
+    rg = ug.ShardedUltraGrothProver.shard_ranges(info["nVars"], n_dom, info["nC1"], info["nC2"], rank, world)
+    header, coefs, slices = synth.build_ultra_circuit_slices(dev, args.log_domain, rg, with_coefs=bool(my_chains))
+    t0 = time.perf_counter()
+    prover = ug.ShardedUltraGrothProver.from_slices(header, coefs, info["nCoefs"], slices, local_rank, rank, world,
+                                                    public_size=82 * (info["nPublic"] - 1) + 4)
+    create_s = time.perf_counter() - t0
+    del coefs, slices
+    cuda = backend == "nccl"
+    sl = n_dom // world if split_h else 0
     fulls = {k: torch.empty((n_dom, 32), dtype=torch.uint8, device="cuda") for k in my_chains}
     bufs = torch.empty((3, max(sl, 1), 32), dtype=torch.uint8, device="cuda")
 
@@ -720,16 +735,21 @@ def main():
         kern = [e for e in kern if e["launches"]]
         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, corrected as the microarch guide says): NOT
         # measured in this run -- read from the committed summary of the same workload under profiles/ (null if absent)
-        for name in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
+        import glob
+        sources = [(args.pmc_summary, "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload made beside this run "
+                                      "(tools/run_r4_prof.sh), corrected as the microarch guide says" % args.pmc_summary)] if args.pmc_summary else []
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+            sources.append((path, "profiles/%s (separate rocprofv3 --pmc passes on this workload; not measured in this run)" % os.path.basename(path)))
+        for path, label in sources:
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", name))).get(str(log_domain), {})
+                pmc = json.load(open(path)).get(str(log_domain), {})
             except Exception:
                 continue
             for e in kern:
                 k = pmc.get(e["kernel"])
                 if k and e["traffic"] is None and single and args.mix == "U" and not args.g1_only:
                     e["traffic"] = k["fetch"] + k["write"]
-                    e["traffic_source"] = "profiles/%s (separate rocprofv3 --pmc passes on this workload; not measured in this run)" % name
+                    e["traffic_source"] = label
         kern.sort(key=lambda e: -e["ms_per_step"])
         roofline = dict(kern[0]) if kern else {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None}
         roofline["kernels"] = {e["kernel"]: e for e in kern[1:]}

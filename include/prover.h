@@ -281,6 +281,23 @@ int ug_groth16_prover_finish(void *prover_object, const void *partials_sum,
 int ug_ultra_groth_prover_create_sharded(void **prover_object, const void *zkey_buffer, unsigned long long zkey_size,
                                          int device, int shard_rank, int shard_count,
                                          char *error_msg, unsigned long long error_msg_maxsize);
+/* The same from this rank's SLICES only (no rank holds the whole zkey): zkey_header = the bytes of zkey section 2 (protocol 1337),
+ * coefs = section 4 without its 4-byte count (NULL: this rank runs no H-polynomial chain and keeps no coefficient matrix),
+ * points_* = the rank's slices of sections 5 (A), 6 (B1), 7 (B2), 8 (round points C1), 9 (final points C2), 12 (H) and
+ * round_indexes / final_round_indexes its slices of the index lists 10 / 11 (u32 each), all starting at the first element of the
+ * ranges ug_ultra_groth_shard_ranges reports: out[8] = {witness first, end | round set first, end | final set first, end | H first, end}.
+ * slice_bytes = the byte counts of the eight buffers in that order (A, B1, B2, C1, C2, H, round_indexes, final_round_indexes): a slice
+ * shorter than the rank's range is refused instead of read past its end. (Sharding of src/ultra_groth.cpp:401-462.) */
+int ug_ultra_groth_shard_ranges(unsigned long long n_vars, unsigned long long domain_size, unsigned long long n_round_indexes,
+                                unsigned long long n_final_indexes, int shard_rank, int shard_count, unsigned long long out[8]);
+int ug_ultra_groth_prover_create_sharded_slices(void **prover_object, const void *zkey_header, unsigned long long zkey_header_size,
+                                                const void *coefs, unsigned long long n_coefs,
+                                                const void *points_a, const void *points_b1, const void *points_b2,
+                                                const void *points_round_c, const void *points_final_c, const void *points_h,
+                                                const void *round_indexes, const void *final_round_indexes,
+                                                const unsigned long long slice_bytes[8],
+                                                int device, int shard_rank, int shard_count,
+                                                char *error_msg, unsigned long long error_msg_maxsize);
 int ug_ultra_groth_prover_round_commit(void *prover_object, void *commit_part_out,
                                        char *error_msg, unsigned long long error_msg_maxsize);
 int ug_ultra_groth_prover_round_finish(void *prover_object, const void *commit_sum, void *commitment_out,

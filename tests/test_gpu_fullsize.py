@@ -132,6 +132,30 @@ def test_piecewise_ranges_at_full_size(full_zkey, full_prover, monkeypatch):
         assert _prove(p, wtns) == _expected(zkey, wtns, FULL_LOG, "C")
 
 
+def test_reference_api_on_eight_ranks_at_configs2_size(full_zkey, monkeypatch):
+    """The path the reference's own CLI / API takes on a node (src/main_prover.cpp:55, groth16_prover_create / _prove with
+    ULTRAGROTH_DEVICES): eight ranks -- here on the one device -- behind groth16_prover_prove at the full 2^24 size: one sharded
+    rank object per listed device, the witness in parts, chains on ranks 0-2 first, peer copies of the evaluation slices
+    (ug_dvec_copy: the same-device branch here), partial blocks added on the host; byte for byte the expected proof, twice
+    (circom-like, then uniform scalars) on one object. The step time goes to gpurun_out/fullsize_progress.log (eight ranks share
+    one GPU: a correctness rehearsal, not a speed)."""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, info = full_zkey
+    monkeypatch.setenv("ULTRAGROTH_DEVICES", "0,0,0,0,0,0,0,0")
+    _progress("2^%d x8 behind the reference API: creating" % FULL_LOG)
+    t0 = time.perf_counter()
+    with ug.Groth16Prover(zkey) as p:
+        _progress("2^%d x8 behind the reference API: created in %.1f s" % (FULL_LOG, time.perf_counter() - t0))
+        for mix in ("C", "U"):
+            wtns = synth.build_witness(FULL_LOG, mix)
+            exp = _expected(zkey, wtns, FULL_LOG, mix)
+            t0 = time.perf_counter()
+            got = _prove(p, wtns)
+            _progress("2^%d x8 behind the reference API, mix %s: groth16_prover_prove took %.1f ms" % (FULL_LOG, mix, 1e3 * (time.perf_counter() - t0)))
+            assert got == exp, mix
+
+
 @pytest.fixture(scope="module")
 def huge(device):
     """BASELINE.json configs[3]'s circuit (2^HUGE_LOG constraints) with its expected proof, made once for the single-GPU
@@ -254,18 +278,87 @@ def test_eight_sliced_ranks_at_configs3_size(device, huge, monkeypatch):
     _progress("2^%d x8: done" % HUGE_LOG)
 
 
-def test_ultragroth_at_configs4_size(device):
+ULTRA_LOG = int(os.environ.get("UG_ULTRA_LOG", "22"))
+ULTRA_BLINDING = (bytes(range(1, 32)), bytes(range(40, 71)), bytes(range(80, 111)))          # r_k, r, s
+
+
+@pytest.fixture(scope="module")
+def ultra(device):
+    """BASELINE.json configs[4]'s circuit (UltraGroth, 2^22 constraints, lookup table 2^16) with the oracle's proof, made once for
+    the single-GPU and the 8-rank tests below"""
+    from ultragroth_amd import synth
+    _progress("ultragroth 2^%d: building the circuit" % ULTRA_LOG)
+    zkey, uwtns, info = synth.build_ultra_circuit(device, ULTRA_LOG, mix="C", lookup_log=16)
+    _progress("ultragroth 2^%d: oracle" % ULTRA_LOG)
+    exp = O.ultra_groth_prove(zkey, uwtns, *(int.from_bytes(b, "little") for b in ULTRA_BLINDING))
+    return zkey, uwtns, info, exp
+
+
+def test_eight_sliced_ultragroth_ranks_at_configs4_size(device, ultra):
+    """BASELINE.json configs[4] as its text has it -- UltraGroth on a 2^22 circuit over EIGHT ranks -- rehearsed on one device at
+    full size (src/ultra_groth.cpp:401-462 sharded; src/prover.cpp:226-300 is the single-process caller): every rank is created
+    from the header section and ITS slices only (ug_ultra_groth_prover_create_sharded_slices: the witness-indexed sets, the round
+    and final sets with their slices of the two index lists, H; ranks 3-7 without a coefficient matrix), every rank commits to its
+    part of the round set, rank 0 closes the round, every rank derives the challenge and completes its witness (lookup 2^16), the
+    final round runs queued -- chain ranks their chain first, then the witness products with the H branch beside them -- the
+    384-byte blocks are added and rank 0 finishes: byte for byte the oracle's proof of the single-GPU test below."""
+    import torch
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, uwtns, info, exp = ultra
+    world, n_dom, nv = 8, info["domainSize"], info["nVars"]
+    assert synth.build_ultra_witness(ULTRA_LOG, "C", lookup_log=16) == uwtns       # what bench.py's ranks make for themselves
+    ranks = []
+    try:
+        for k in range(world):
+            rg = ug.ShardedUltraGrothProver.shard_ranges(nv, n_dom, info["nC1"], info["nC2"], k, world)
+            _progress("ultragroth 2^%d x8: creating rank %d (witness %d..%d)" % (ULTRA_LOG, k, rg[0][0], rg[0][1]))
+            header, coefs, slices = synth.build_ultra_circuit_slices(device, ULTRA_LOG, rg, with_coefs=(k < 3))
+            ranks.append(ug.ShardedUltraGrothProver.from_slices(header, coefs, 4 * n_dom, slices, 0, k, world,
+                                                                public_size=82 * (info["nPublic"] - 1) + 4))
+            del coefs, slices
+        full = torch.empty((3, n_dom, 32), dtype=torch.uint8, device="cuda")
+        ug.set_test_blinding(b"".join(ULTRA_BLINDING))
+        try:
+            total = bytes(64)
+            for p in ranks:
+                p.load_witness(uwtns)
+                total = ug.ShardedUltraGrothProver.add_records(total, p.round_commit())
+            commitment = ranks[0].round_finish(total)
+            for p in ranks:
+                p.apply_commitment(commitment)
+            _progress("ultragroth 2^%d x8: final round" % ULTRA_LOG)
+            for k in range(3):                                 # eight ranks: a chain rank runs its chain first, alone
+                ranks[k].hpoly_chain(k, full[k].data_ptr())
+            for p in ranks:
+                p.witness_msm_begin()
+            acc = None
+            for p in ranks:
+                first, cnt, _ = p.h_range()
+                bufs = [full[k, first:first + cnt] for k in range(3)]
+                torch.cuda.current_stream().synchronize()
+                p.hpoly_combine(*(b.data_ptr() for b in bufs))
+                hpart = p.run_h_msm()
+                part = p.witness_msm_end()[:320] + hpart[320:384]
+                acc = part if acc is None else ug.ShardedGroth16Prover.add_partials(acc, part)
+            got = ranks[0].finish(acc)
+        finally:
+            ug.set_test_blinding(b"")
+    finally:
+        for p in ranks:
+            p.close()
+    assert got == exp
+    _progress("ultragroth 2^%d x8: done" % ULTRA_LOG)
+
+
+def test_ultragroth_at_configs4_size(device, ultra):
     """BASELINE.json configs[4]'s circuit on one GPU inside the suite: UltraGroth, 2^22 constraints, lookup table 2^16
     (SURVEY.md section 8d cfg 5), a CREATED prover (window tables), two proofs on the one object; == the oracle (parity of the
     UltraGroth whole proof is unpinned upstream: no fixture exists there; the oracle's pieces are pinned)"""
     import ultragroth_amd as ug
-    from ultragroth_amd import synth
-    log_domain = int(os.environ.get("UG_ULTRA_LOG", "22"))
-    _progress("ultragroth 2^%d: building the circuit" % log_domain)
-    zkey, uwtns, info = synth.build_ultra_circuit(device, log_domain, mix="C", lookup_log=16)
-    rk, r, s = bytes(range(1, 32)), bytes(range(40, 71)), bytes(range(80, 111))
-    _progress("ultragroth 2^%d: oracle" % log_domain)
-    exp = O.ultra_groth_prove(zkey, uwtns, int.from_bytes(rk, "little"), int.from_bytes(r, "little"), int.from_bytes(s, "little"))
+    zkey, uwtns, info, exp = ultra
+    log_domain = ULTRA_LOG
+    rk, r, s = ULTRA_BLINDING
     _progress("ultragroth 2^%d: proving" % log_domain)
     with ug.UltraGrothProver(zkey) as p:
         for _ in range(2):

@@ -395,20 +395,20 @@ def test_bench_two_ranks_over_rccl():
         assert line["n_gpus"] == 2 and ("bit-exact" in (line.get("check") or line["config"]["workload"]))
 
 
-def test_bench_driver_line_with_five_ranks_over_gloo():
+def test_bench_driver_line_with_four_ranks_over_gloo():
     """The driver's own launch line for a many-GPU run -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
-    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W`, no other flag -- with N = 5 ranks sharing
-    the one device over gloo (RCCL refuses two ranks on one device, and this pool allows six GPU processes: five ranks beside
-    the test runner; N = 8 itself is the driver's to launch), at 2^16 so that it takes seconds. More than three ranks means
-    ranks without a chain, chain-first order, slices of different length. The whole JSON contract of the line is asserted;
-    `cpu_baseline` is null at N > 1 (the run contract measures it at N = 1 only) and says so; every rank has left its process
-    group before rank 0 prints."""
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W`, no other flag -- with N = 4 ranks sharing
+    the one device over gloo (RCCL refuses two ranks on one device, and this pool allows six processes on a GPU: the test
+    runner, the launcher and four ranks; N = 8 itself is the driver's to launch), at 2^16 so that it takes seconds. Four ranks
+    means a rank without a chain and slices of different length; the chain-first order of a large node is forced. The whole
+    JSON contract of the line is asserted; `cpu_baseline` is null at N > 1 (the run contract measures it at N = 1 only) and
+    says so; every rank has left its process group before rank 0 prints."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, UG_BENCH_BACKEND="gloo", UG_BENCH_ONE_DEVICE="1", OMP_NUM_THREADS="4")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "5", "--master-addr", "127.0.0.1",
-                        "--master-port", "29633", os.path.join(root, "bench.py"), "--gpus", "5", "--steps", "2", "--warmup", "1",
+    env = dict(os.environ, UG_BENCH_BACKEND="gloo", UG_BENCH_ONE_DEVICE="1", OMP_NUM_THREADS="4", UG_BENCH_CHAIN_ORDER="first")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", "29633", os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
                         "--log-domain", "16"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
@@ -417,16 +417,16 @@ def test_bench_driver_line_with_five_ranks_over_gloo():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline", "comm"):
         assert key in d, key
-    assert d["metric"] == "proofs/s" and d["n_gpus"] == 5 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert d["metric"] == "proofs/s" and d["n_gpus"] == 4 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
     assert abs(d["value"] * d["ms_per_step"] - 1e3) < 1e-3
-    assert d["comm"] == {"backend": "gloo", "world_size": 5, "rccl_version": None, "devices_visible": d["comm"]["devices_visible"]}
+    assert d["comm"] == {"backend": "gloo", "world_size": 4, "rccl_version": None, "devices_visible": d["comm"]["devices_visible"]}
     assert d["cpu_baseline"] is None and "N = 1" in d["cpu_baseline_note"]
-    assert "x5" in d["config"]["parallelism"] and "workload" in d["config"]
+    assert "base-range shard x4, H-poly chains split over ranks" in d["config"]["parallelism"] and "workload" in d["config"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["launches"] > 0 and 0 < rf["frac"] < 1
-    # the same launch with --check: the five ranks' proof is the single-device proof, byte for byte
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "5", "--master-addr", "127.0.0.1",
-                        "--master-port", "29634", os.path.join(root, "bench.py"), "--gpus", "5", "--steps", "1", "--warmup", "1",
+    # the same launch with --check: the four ranks' proof is the single-device proof, byte for byte
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", "29634", os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1",
                         "--log-domain", "16", "--check"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     assert json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])["check"] == "bit-exact"
@@ -1046,6 +1046,79 @@ def test_sharded_ultragroth_queued_final_round(device, world, chain_first):
     finally:
         for p in ranks:
             p.close()
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_sharded_ultragroth_from_slices(device, world):
+    """ug_ultra_groth_prover_create_sharded_slices: every rank from the header section and ITS slices of the six point sections and
+    the two index lists only (byte counts checked), ranks beyond the three chain ranks without a coefficient matrix -- the
+    generator's slices are the zkey's sections cut at ug_ultra_groth_shard_ranges -- and the proof of the sliced ranks == the proof of
+    ranks made from the whole zkey == the oracle"""
+    import torch
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    log_domain = 13
+    zkey, uwtns, info = synth.build_ultra_circuit(device, log_domain)
+    assert synth.build_ultra_witness(log_domain) == uwtns
+    si = synth.ultra_info(log_domain)
+    assert all(si[k] == info[k] for k in ("nVars", "domainSize", "nC1", "nC2", "nPublic"))
+    rk, r, s = bytes(range(1, 32)), bytes(range(40, 71)), bytes(range(80, 111))
+    exp = O.ultra_groth_prove(zkey, uwtns, int.from_bytes(rk, "little"), int.from_bytes(r, "little"), int.from_bytes(s, "little"))
+    n_dom, nv = info["domainSize"], info["nVars"]
+    sec = lambda k: _sec_of(zkey, k)
+    ranks = []
+    for k in range(world):
+        rg = ug.ShardedUltraGrothProver.shard_ranges(nv, n_dom, info["nC1"], info["nC2"], k, world)
+        header, coefs, slices = synth.build_ultra_circuit_slices(device, log_domain, rg, with_coefs=(k < 3))
+        (w0, w1), (r0, r1), (f0, f1), (h0, h1) = rg
+        assert header == sec(2)
+        for got_sl, (sid, rec, lo, hi) in zip(slices, ((5, 64, w0, w1), (6, 64, w0, w1), (7, 128, w0, w1), (8, 64, r0, r1), (9, 64, f0, f1),
+                                                       (12, 64, h0, h1), (10, 4, r0, r1), (11, 4, f0, f1))):
+            assert bytes(got_sl) == sec(sid)[lo * rec:hi * rec], sid
+        ranks.append(ug.ShardedUltraGrothProver.from_slices(header, coefs, info.get("nCoefs", 4 * n_dom), slices, 0, k, world, public_size=86))
+        if k == 1:
+            short = list(slices)
+            short[6] = bytes(short[6])[:-4]
+            with pytest.raises(ug.ProverError, match="round_indexes slice is shorter"):
+                ug.ShardedUltraGrothProver.from_slices(header, coefs, 4 * n_dom, short, 0, k, world, public_size=86)
+    full = torch.empty((3, n_dom, 32), dtype=torch.uint8, device="cuda")
+    try:
+        ug.set_test_blinding(rk + r + s)
+        try:
+            total = bytes(64)
+            for p in ranks:
+                p.load_witness(uwtns)
+                total = ug.ShardedUltraGrothProver.add_records(total, p.round_commit())
+            commitment = ranks[0].round_finish(total)
+            for p in ranks:
+                p.apply_commitment(commitment)
+            for k in range(3):
+                ranks[k % world].hpoly_chain(k, full[k].data_ptr())
+            if world > 3:
+                with pytest.raises(ug.ProverError, match="created without the coefficient matrix"):
+                    ranks[3].hpoly_chain(0, full[0].data_ptr())
+            acc = None
+            for q, p in enumerate(ranks):
+                p.witness_msm_begin()
+                first, cnt, _ = p.h_range()
+                bufs = [full[k, first:first + cnt].contiguous() for k in range(3)]
+                torch.cuda.current_stream().synchronize()
+                p.hpoly_combine(*(b.data_ptr() for b in bufs))
+                hpart = p.run_h_msm()
+                part = p.witness_msm_end()[:320] + hpart[320:384]
+                acc = part if acc is None else ug.ShardedGroth16Prover.add_partials(acc, part)
+            got = ranks[0].finish(acc)
+        finally:
+            ug.set_test_blinding(b"")
+        assert got == exp
+    finally:
+        for p in ranks:
+            p.close()
+
+
+def _sec_of(buf, sid):
+    off, sz = O.section(buf, "zkey", sid)
+    return bytes(buf[off:off + sz])
 
 
 def test_created_prover_at_2_20_bit_exact(device):

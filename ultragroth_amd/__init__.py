@@ -519,6 +519,31 @@ class ShardedUltraGrothProver(ShardedGroth16Prover):
             raise ProverError(rc, err.value.decode(errors="replace"))
         self._public_size = ultra_groth_public_size_for_zkey_buf(zkey)
 
+    @classmethod
+    def from_slices(cls, header, coefs, n_coefs, slices, device, rank, world, public_size):
+        """ug_ultra_groth_prover_create_sharded_slices: header = zkey section 2, coefs = section 4 records (None: no chain on this
+        rank), slices = (A, B1, B2, C1, C2, H, round_indexes, final_round_indexes) buffers holding this rank's part only
+        (shard_ranges tells which)"""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(1024)
+        sizes = (C.c_ulonglong * 8)(*[len(x) for x in slices])
+        rc = load().ug_ultra_groth_prover_create_sharded_slices(C.byref(self._h), header, len(header), coefs, n_coefs, *slices, sizes,
+                                                                device, rank, world, err, len(err) - 1)
+        if rc != PROVER_OK:
+            self._h = None
+            raise ProverError(rc, err.value.decode(errors="replace"))
+        self._public_size = public_size
+        return self
+
+    @staticmethod
+    def shard_ranges(n_vars, domain, n_round, n_final, rank, world):
+        """((witness first, end), (round set first, end), (final set first, end), (H first, end)) of a rank"""
+        out = (C.c_ulonglong * 8)()
+        if load().ug_ultra_groth_shard_ranges(n_vars, domain, n_round, n_final, rank, world, out) != PROVER_OK:
+            raise ProverError(PROVER_ERROR, "invalid shard rank / count")
+        return (out[0], out[1]), (out[2], out[3]), (out[4], out[5]), (out[6], out[7])
+
     def _call(self, name, *args):
         err = C.create_string_buffer(1024)
         rc = getattr(load(), name)(self._h, *args, err, len(err) - 1)

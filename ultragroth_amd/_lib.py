@@ -43,7 +43,8 @@ OUTER_SYMBOLS = [
     "ug_groth16_prover_create_sharded", "ug_groth16_prover_create_sharded_range", "ug_groth16_prover_create_sharded_slices",
     "ug_groth16_shard_ranges", "ug_groth16_balanced_witness_range", "ug_groth16_prover_load_witness_part",
     "ug_groth16_shard_layout", "ug_groth16_prover_create_sharded_layout",
-    "ug_ultra_groth_prover_create_sharded", "ug_ultra_groth_prover_round_commit", "ug_ultra_groth_prover_round_finish",
+    "ug_ultra_groth_prover_create_sharded", "ug_ultra_groth_shard_ranges", "ug_ultra_groth_prover_create_sharded_slices",
+    "ug_ultra_groth_prover_round_commit", "ug_ultra_groth_prover_round_finish",
     "ug_ultra_groth_prover_apply_commitment", "ug_g1_record_add",
     "ug_groth16_prover_load_witness", "ug_groth16_prover_run", "ug_groth16_prover_prove_resident",
     "ug_groth16_partials_add", "ug_groth16_prover_finish",
@@ -205,6 +206,8 @@ def load():
     L.ug_groth16_prover_load_witness_part.argtypes = [vp, vp, ull, C.c_int, vp, ull]
     L.ug_groth16_shard_ranges.argtypes = [ull, ull, ull, C.c_int, C.c_int, vp, vp]
     L.ug_groth16_shard_layout.argtypes = [ull, ull, ull, C.c_int, C.c_int, C.c_int, ull, vp]
+    L.ug_ultra_groth_shard_ranges.argtypes = [ull, ull, ull, ull, C.c_int, C.c_int, vp]
+    L.ug_ultra_groth_prover_create_sharded_slices.argtypes = [pp, vp, ull, vp, ull] + [vp] * 9 + [C.c_int, C.c_int, C.c_int, vp, ull]
     L.ug_groth16_prover_create_sharded_layout.argtypes = [pp, vp, ull, vp, ull, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, ull]
     L.ug_groth16_balanced_witness_range.argtypes = [ull, C.c_int, C.c_int, vp]
     L.ug_groth16_prover_create_sharded_slices.argtypes = [pp, vp, ull, vp, ull, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, ull]

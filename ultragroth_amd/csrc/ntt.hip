@@ -56,6 +56,9 @@ struct PassArgs {
     int j;                // log2(tiles per workgroup)
     int gather_bitrev;    // first pass only: read element idx from in[bitrev(idx)]
     int scatter_bitrev;   // last pass only: write element idx to out[bitrev(idx)]
+#ifdef UG_MEASURE
+    int fuse_steps;       // UG_NTT_FUSE_STEPS=1 (WRONG results, timing only): two radix-4 steps per LDS round trip -- see the kernel
+#endif
 };
 
 // Raw limb-wise sum / difference WITHOUT the carry pass (limbs may exceed 29 bits): the radix-4 step below feeds them
@@ -142,6 +145,51 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassBatch batch) 
         __syncthreads();
         d = 1;
     }
+#ifdef UG_MEASURE
+    // Measurement only (round 4, VERDICT item 6: what would a radix-8 / radix-16 step buy?): two radix-4 steps on ONE set of
+    // registers per LDS round trip -- the second step takes the first one's outputs as if they were its own four elements (they
+    // are not: the results are WRONG) -- i.e. the instruction stream of four stages with half the LDS loads, stores, address
+    // arithmetic and barriers and the same products, carry passes and twiddle loads: an upper bound of what ANY higher radix
+    // can save (a real radix-16 step would also need 16 elements per lane in registers).
+    if (a.fuse_steps) {
+        for (; d + 3 < k; d += 4) {
+            for (u32 bf = tid; bf < (u32)(E >> 2); bf += nth) {
+                u32 t, p;
+                if (s0 == 0) { t = bf >> (k - 2); p = bf & ((1u << (k - 2)) - 1); } else { t = bf & tmask; p = bf >> j; }
+                u32 x0[NL], x1[NL], x2[NL], x3[NL];
+                u32 q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+                for (int half = 0; half < 2; half++) {
+                    const int dd = d + 2 * half;
+                    const u32 D = 1u << dd;
+                    const u32 elow = p & (D - 1);
+                    const u32 e0 = ((p >> dd) << (dd + 2)) | elow;
+                    q0 = lpos(e0, t); q1 = lpos(e0 + D, t); q2 = lpos(e0 + 2 * D, t); q3 = lpos(e0 + 3 * D, t);
+                    Fr wa = ld_twiddle(a.tw, twidx(dd, elow, t));
+                    Fr wb0 = ld_twiddle(a.tw, twidx(dd + 1, elow, t));
+                    Fr wb1 = ld_twiddle(a.tw, twidx(dd + 1, elow + D, t));
+                    if (half == 0) { ld(x0, q0); ld(x1, q1); ld(x2, q2); ld(x3, q3); }
+                    Fr t1 = mul(as_fr(x1), wa);
+                    Fr t3 = mul(as_fr(x3), wa);
+                    u32 a0[NL], a1[NL], a2[NL], a3[NL];
+                    raw_add(a0, x0, t1); raw_sub2q(a1, x0, t1);
+                    raw_add(a2, x2, t3); raw_sub2q(a3, x2, t3);
+                    Fr u2 = mul(as_fr(a2), wb0);
+                    Fr u3 = mul(as_fr(a3), wb1);
+                    u32 y[NL];
+                    Fr r0, r1, r2, r3;
+                    raw_add(y, a0, u2); r0 = norm_weak<FrParams>(y);
+                    raw_sub2q(y, a0, u2); r2 = norm_weak<FrParams>(y);
+                    raw_add(y, a1, u3); r1 = norm_weak<FrParams>(y);
+                    raw_sub2q(y, a1, u3); r3 = norm_weak<FrParams>(y);
+#pragma unroll
+                    for (int l = 0; l < NL; l++) { x0[l] = r0.l[l]; x1[l] = r1.l[l]; x2[l] = r2.l[l]; x3[l] = r3.l[l]; }
+                }
+                st(q0, as_fr(x0)); st(q1, as_fr(x1)); st(q2, as_fr(x2)); st(q3, as_fr(x3));
+            }
+            __syncthreads();
+        }
+    }
+#endif
     for (; d < k; d += 2) {
         const u32 D = 1u << d;
         for (u32 bf = tid; bf < (u32)(E >> 2); bf += nth) {
@@ -373,6 +421,10 @@ void NttPlan::launch(const NttPass* const* lists, int count, int p, hipStream_t 
         PassArgs& a = b.a[c];
         a.in = n.in; a.out = n.out; a.tw = n.tw; a.post = n.post; a.post_const = n.post_const; a.in2 = n.in2; a.fin_a = n.fin_a; a.fin_b = n.fin_b;
         a.logn = n.logn; a.s0 = n.s0; a.k = n.k; a.j = n.j; a.gather_bitrev = n.gather_bitrev; a.scatter_bitrev = n.scatter_bitrev;
+#ifdef UG_MEASURE
+        static const int fuse_steps = getenv("UG_NTT_FUSE_STEPS") ? atoi(getenv("UG_NTT_FUSE_STEPS")) : 0;
+        a.fuse_steps = fuse_steps;
+#endif
     }
     for (int c = count; c < 3; c++) b.a[c] = b.a[0];
     const PassArgs& a = b.a[0];

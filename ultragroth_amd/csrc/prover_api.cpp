@@ -1112,12 +1112,65 @@ private:
 // =================================================================================================================
 class UltraGrothProver : public ProverBase {
 public:
+    // What a prover is made from: whole sections of a zkey buffer, or (sliced) only this rank's slice of each point section
+    // and of the two index lists, so that a rank of a many-GPU prover never holds the whole zkey in host memory
+    struct Sources {
+        bool sliced = false;
+        const uint8_t* coefs = nullptr; uint64_t nCoefs = 0; bool haveCoefs = true;     // !haveCoefs: this rank runs no NTT chain
+        const uint8_t *pA = nullptr, *pB1 = nullptr, *pB2 = nullptr, *pRoundC = nullptr, *pFinalC = nullptr, *pH = nullptr;
+        const uint8_t *idx1 = nullptr, *idx2 = nullptr;
+        const unsigned long long* sliceBytes = nullptr;       // sliced: byte counts of pA, pB1, pB2, pRoundC, pFinalC, pH, idx1, idx2
+    };
+    struct Ranges { Range w, h, c1, c2; };
+    static Ranges shardRanges(uint64_t M, uint64_t N, uint64_t nC1, uint64_t nC2, int rank, int count) {
+        if (count < 1 || rank < 0 || rank >= count) throw std::invalid_argument("invalid shard rank / count");
+        return Ranges{shardRange(M, rank, count), shardRange(N, rank, count), shardRange(nC1, rank, count), shardRange(nC2, rank, count)};
+    }
     // rank `rank` of `count`: the witness-indexed sets (A, B1, B2), the round set (C1 with round_indexes), the final set
     // (C2 with final_round_indexes) and H are each cut into `count` contiguous slices; every rank keeps the whole witness
-    UltraGrothProver(const void* zkey, unsigned long long zkeySize, int device, int rank = 0, int count = 1) {
+    UltraGrothProver(const void* zkey, unsigned long long zkeySize, int device, int rank = 0, int count = 1, bool runsChain = true) {
         if (count < 1 || rank < 0 || rank >= count) throw std::invalid_argument("invalid shard rank / count");
         BinFile f(zkey, zkeySize, "zkey", 1);
         hdr_ = loadZkeyHeader(f, true);
+        if (!hdr_.rIsBn254) throw std::invalid_argument("zkey curve not supported");
+        const uint64_t M = hdr_.nVars, N = hdr_.domainSize;
+        Sources src;
+        src.coefs = checkedSection(f, 4, 4 + hdr_.nCoefs * 44) + 4;
+        src.nCoefs = hdr_.nCoefs;
+        src.haveCoefs = runsChain;
+        // section map of protocol 1337 (src/prover.cpp:242-259)
+        src.pA = checkedSection(f, 5, M * 64);
+        src.pB1 = checkedSection(f, 6, M * 64);
+        src.pB2 = checkedSection(f, 7, M * 128);
+        src.pRoundC = checkedSection(f, 8, (uint64_t)hdr_.numIndexesC1 * 64);
+        src.pFinalC = checkedSection(f, 9, (uint64_t)hdr_.numIndexesC2 * 64);
+        src.idx1 = checkedSection(f, 10, (uint64_t)hdr_.numIndexesC1 * 4);
+        src.idx2 = checkedSection(f, 11, (uint64_t)hdr_.numIndexesC2 * 4);
+        src.pH = checkedSection(f, 12, N * 64);
+        init(src, device, rank, count);
+    }
+    // from the header section and this rank's slices (ug_ultra_groth_prover_create_sharded_slices)
+    UltraGrothProver(const void* header, unsigned long long headerSize, const Sources& slices, int device, int rank, int count) {
+        if (count < 1 || rank < 0 || rank >= count) throw std::invalid_argument("invalid shard rank / count");
+        std::vector<uint8_t> mini;             // a header-only container, so that the one header parser serves both forms
+        auto put32 = [&](uint32_t v) { for (int k = 0; k < 4; k++) mini.push_back((uint8_t)(v >> (8 * k))); };
+        auto put64 = [&](uint64_t v) { for (int k = 0; k < 8; k++) mini.push_back((uint8_t)(v >> (8 * k))); };
+        mini.insert(mini.end(), {'z', 'k', 'e', 'y'});
+        put32(1); put32(3);
+        put32(1); put64(4); put32(1337);
+        put32(2); put64(headerSize);
+        mini.insert(mini.end(), static_cast<const uint8_t*>(header), static_cast<const uint8_t*>(header) + headerSize);
+        put32(4); put64(0);
+        BinFile f(mini.data(), mini.size(), "zkey", 1);
+        hdr_ = loadZkeyHeader(f, true);
+        hdr_.nCoefs = slices.nCoefs;
+        Sources src = slices;
+        src.sliced = true;
+        init(src, device, rank, count);        // (copies the verification-key points out of `mini` before it goes away)
+    }
+
+private:
+    void init(const Sources& src, int device, int rank, int count) {
         if (!hdr_.rIsBn254) throw std::invalid_argument("zkey curve not supported");
         vk_.assign(hdr_.alpha1, hdr_.alpha1 + 64 + 64 + 128 + 128 + 64 + 128 + 64 + 128);
         uint8_t* v = vk_.data();
@@ -1125,22 +1178,32 @@ public:
         hdr_.roundDelta1 = v + 384; hdr_.roundDelta2 = v + 448; hdr_.delta1 = v + 576; hdr_.delta2 = v + 640;
 
         const uint64_t M = hdr_.nVars, N = hdr_.domainSize;
-        const uint8_t* coefs = checkedSection(f, 4, 4 + hdr_.nCoefs * 44) + 4;
-        // section map of protocol 1337 (src/prover.cpp:242-259)
-        const uint8_t* pA = checkedSection(f, 5, M * 64);
-        const uint8_t* pB1 = checkedSection(f, 6, M * 64);
-        const uint8_t* pB2 = checkedSection(f, 7, M * 128);
-        const uint8_t* pRoundC = checkedSection(f, 8, (uint64_t)hdr_.numIndexesC1 * 64);
-        const uint8_t* pFinalC = checkedSection(f, 9, (uint64_t)hdr_.numIndexesC2 * 64);
-        const uint8_t* idx1 = checkedSection(f, 10, (uint64_t)hdr_.numIndexesC1 * 4);
-        const uint8_t* idx2 = checkedSection(f, 11, (uint64_t)hdr_.numIndexesC2 * 4);
-        const uint8_t* pH = checkedSection(f, 12, N * 64);
-        wr_ = shardRange(M, rank, count);
-        hr_ = shardRange(N, rank, count);
-        const Range c1 = shardRange(hdr_.numIndexesC1, rank, count), c2 = shardRange(hdr_.numIndexesC2, rank, count);
+        const Ranges rg = shardRanges(M, N, hdr_.numIndexesC1, hdr_.numIndexesC2, rank, count);
+        wr_ = rg.w; hr_ = rg.h;
+        const Range c1 = rg.c1, c2 = rg.c2;
+        const uint8_t *coefs = src.coefs, *pA = src.pA, *pB1 = src.pB1, *pB2 = src.pB2, *pRoundC = src.pRoundC, *pFinalC = src.pFinalC,
+                      *pH = src.pH, *idx1 = src.idx1, *idx2 = src.idx2;
+        haveHpoly_ = src.haveCoefs;
+        if (!src.sliced) {                       // whole sections: step to this rank's slices
+            pA += wr_.lo * 64; pB1 += wr_.lo * 64; pB2 += wr_.lo * 128; pRoundC += c1.lo * 64; pFinalC += c2.lo * 64; pH += hr_.lo * 64;
+            idx1 += c1.lo * 4; idx2 += c2.lo * 4;
+        } else {                                 // slices: each must hold this rank's range (a short buffer would be read past its end)
+            const uint64_t need[8] = {(wr_.hi - wr_.lo) * 64, (wr_.hi - wr_.lo) * 64, (wr_.hi - wr_.lo) * 128, (c1.hi - c1.lo) * 64,
+                                      (c2.hi - c2.lo) * 64, (hr_.hi - hr_.lo) * 64, (c1.hi - c1.lo) * 4, (c2.hi - c2.lo) * 4};
+            const uint8_t* ptr[8] = {pA, pB1, pB2, pRoundC, pFinalC, pH, idx1, idx2};
+            static const char* const what[8] = {"points_a", "points_b1", "points_b2", "points_round_c", "points_final_c", "points_h",
+                                                "round_indexes", "final_round_indexes"};
+            for (int k = 0; k < 8; k++) {
+                if (need[k] && !ptr[k]) throw std::invalid_argument(std::string("Null ") + what[k] + " slice");
+                if (src.sliceBytes && src.sliceBytes[k] < need[k])
+                    throw std::invalid_argument(std::string(what[k]) + " slice is shorter than this rank's range: " + std::to_string(src.sliceBytes[k]) +
+                                                " bytes, needed " + std::to_string(need[k]));
+            }
+            if (src.haveCoefs && !src.coefs && src.nCoefs) throw std::invalid_argument("Null coefficient records");
+        }
         roundIdx_.resize(c1.hi - c1.lo); finalIdx_.resize(c2.hi - c2.lo);
-        memcpy(roundIdx_.data(), idx1 + c1.lo * 4, roundIdx_.size() * 4);
-        memcpy(finalIdx_.data(), idx2 + c2.lo * 4, finalIdx_.size() * 4);
+        if (!roundIdx_.empty()) memcpy(roundIdx_.data(), idx1, roundIdx_.size() * 4);
+        if (!finalIdx_.empty()) memcpy(finalIdx_.data(), idx2, finalIdx_.size() * 4);
         for (uint32_t i : roundIdx_) if (i >= M) throw std::range_error("round index outside the witness");
         for (uint32_t i : finalIdx_) if (i >= M) throw std::range_error("final round index outside the witness");
 
@@ -1150,20 +1213,20 @@ public:
         // beside them on one GPU as well; by default the second stream is ordered behind the first on the device
         ugCheck(ug_ctx_create(&d_.ctx2, device));
         if (fusedGroups()) {                            // A and B1 share the witness scalars: one interleaved group
-            const void* hosts[2] = {pA + wr_.lo * 64, pB1 + wr_.lo * 64};
+            const void* hosts[2] = {pA, pB1};
             const uint64_t counts[2] = {wr_.hi - wr_.lo, wr_.hi - wr_.lo}, firsts[2] = {wr_.lo, wr_.lo};
             ugCheck(ug_bases_create_group_g1(d_.ctx, 2, hosts, counts, firsts, wr_.lo, wr_.hi - wr_.lo, 0, &d_.G));
         } else {
-            ugCheck(ug_bases_create_g1(d_.ctx, pA + wr_.lo * 64, wr_.hi - wr_.lo, wr_.lo, &d_.A));
-            ugCheck(ug_bases_create_g1(d_.ctx, pB1 + wr_.lo * 64, wr_.hi - wr_.lo, wr_.lo, &d_.B1));
+            ugCheck(ug_bases_create_g1(d_.ctx, pA, wr_.hi - wr_.lo, wr_.lo, &d_.A));
+            ugCheck(ug_bases_create_g1(d_.ctx, pB1, wr_.hi - wr_.lo, wr_.lo, &d_.B1));
         }
-        ugCheck(ug_bases_create_g2(d_.ctx, pB2 + wr_.lo * 128, wr_.hi - wr_.lo, wr_.lo, &d_.B2));
+        ugCheck(ug_bases_create_g2(d_.ctx, pB2, wr_.hi - wr_.lo, wr_.lo, &d_.B2));
         // the round / final sets are multiplied with GATHERED scalars (position k of the slice's index list), so their
         // slices count from 0
-        ugCheck(ug_bases_create_g1(d_.ctx, pFinalC + c2.lo * 64, c2.hi - c2.lo, 0, &d_.C));
-        ugCheck(ug_bases_create_g1(d_.ctx, pRoundC + c1.lo * 64, c1.hi - c1.lo, 0, &d_.roundC));
-        ugCheck(ug_bases_create_g1(d_.ctx2, pH + hr_.lo * 64, hr_.hi - hr_.lo, hr_.lo, &d_.H));
-        ugCheck(ug_hpoly_create(d_.ctx2, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
+        ugCheck(ug_bases_create_g1(d_.ctx, pFinalC, c2.hi - c2.lo, 0, &d_.C));
+        ugCheck(ug_bases_create_g1(d_.ctx, pRoundC, c1.hi - c1.lo, 0, &d_.roundC));
+        ugCheck(ug_bases_create_g1(d_.ctx2, pH, hr_.hi - hr_.lo, hr_.lo, &d_.H));
+        if (haveHpoly_) ugCheck(ug_hpoly_create(d_.ctx2, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
         ugCheck(ug_dvec_create(d_.ctx, M, &d_.w));
         wCur_ = d_.w;
         witness_.attach(d_.ctx, M, &d_.w, &d_.w2);
@@ -1179,6 +1242,7 @@ public:
         tableBytes = planWindowTables(d_.ctx, groups);
     }
 
+public:
     std::vector<TableGroup> tableGroups() override {
         std::vector<TableGroup> groups(4);
         const uint64_t nw = wr_.hi - wr_.lo;
@@ -1337,6 +1401,7 @@ public:
     }
     void hpolyChain(int which, void* deviceOut) override {
         if (!committed_) throw std::invalid_argument("the round commitment has not been applied");
+        if (!haveHpoly_) throw std::invalid_argument("this rank was created without the coefficient matrix");
         ug_dvec* v = nullptr;
         ugCheck(ug_dvec_wrap(d_.ctx2, deviceOut, hdr_.domainSize, &v));
         int rc = ug_hpoly_chain(d_.hp, wCur_, which, v);
@@ -1417,6 +1482,7 @@ public:
         bracket.begin();
         // ULTRAGROTH_TRACE=1: host wall-clock per phase on stderr (where the non-MSM, non-FFT time of a proof goes)
         trace_ = getenv("ULTRAGROTH_TRACE") && atoi(getenv("ULTRAGROTH_TRACE")) != 0;
+        if (!haveHpoly_) throw std::invalid_argument("this rank was created without the coefficient matrix");
         adopt(*lease);
         QueueGuard inFlight(d_.ctx, d_.ctx2);            // (declared before `terms`: the host threads join first, then the device is drained)
         uint8_t part[64], commit[64];
@@ -1512,7 +1578,7 @@ private:
     Range wr_{0, 0}, hr_{0, 0};
     uint8_t commitRec_[64] = {0};
     u32 rkw_[8] = {0};
-    bool witnessLoaded_ = false, committed_ = false, haveRoundScalar_ = false, trace_ = false;
+    bool witnessLoaded_ = false, committed_ = false, haveRoundScalar_ = false, trace_ = false, haveHpoly_ = true;
     std::chrono::steady_clock::time_point tPhase_;
     int tableW_ = 0, tableC1_ = 0, tableC2_ = 0, tableH_ = 0;      // fixed-base table widths per schedule group (0: classic)
     DeviceProver d_;
@@ -1853,7 +1919,7 @@ public:
         for (int k = 0; k < R; k++)
             jobs.push_back(std::async(std::launch::async, [&, k, oneShot] {
                 g_oneShotProver = oneShot;
-                ranks_[k].reset(new UltraGrothProver(zkey, zkeySize, devices[k], k, R));
+                ranks_[k].reset(new UltraGrothProver(zkey, zkeySize, devices[k], k, R, /*runsChain*/ k < 3));
             }));
         std::exception_ptr failure;
         for (auto& j : jobs) { try { j.get(); } catch (...) { if (!failure) failure = std::current_exception(); } }
@@ -2594,6 +2660,35 @@ int ug_ultra_groth_prover_create_sharded(void** prover_object, const void* zkey_
     if (prover_object == NULL) throw std::invalid_argument("Null prover object");
     if (zkey_buffer == NULL) throw std::invalid_argument("Null zkey buffer");
     *prover_object = static_cast<ProverBase*>(new UltraGrothProver(zkey_buffer, zkey_size, device, shard_rank, shard_count));
+    API_CATCH
+}
+int ug_ultra_groth_shard_ranges(unsigned long long n_vars, unsigned long long domain_size, unsigned long long n_round_indexes,
+                                unsigned long long n_final_indexes, int shard_rank, int shard_count, unsigned long long out[8]) {
+    try {
+        if (!out) return PROVER_ERROR;
+        const UltraGrothProver::Ranges r = UltraGrothProver::shardRanges(n_vars, domain_size, n_round_indexes, n_final_indexes, shard_rank, shard_count);
+        out[0] = r.w.lo; out[1] = r.w.hi; out[2] = r.c1.lo; out[3] = r.c1.hi; out[4] = r.c2.lo; out[5] = r.c2.hi; out[6] = r.h.lo; out[7] = r.h.hi;
+    } catch (...) { return PROVER_ERROR; }
+    return PROVER_OK;
+}
+int ug_ultra_groth_prover_create_sharded_slices(void** prover_object, const void* zkey_header, unsigned long long zkey_header_size,
+                                                const void* coefs, unsigned long long n_coefs, const void* points_a, const void* points_b1,
+                                                const void* points_b2, const void* points_round_c, const void* points_final_c,
+                                                const void* points_h, const void* round_indexes, const void* final_round_indexes,
+                                                const unsigned long long slice_bytes[8], int device, int shard_rank, int shard_count,
+                                                char* error_msg, unsigned long long error_msg_maxsize) {
+    API_TRY
+    if (prover_object == NULL) throw std::invalid_argument("Null prover object");
+    if (zkey_header == NULL) throw std::invalid_argument("Null zkey buffer");
+    if (slice_bytes == NULL) throw std::invalid_argument("Null slice sizes");
+    UltraGrothProver::Sources src;
+    src.sliceBytes = slice_bytes;
+    src.coefs = static_cast<const uint8_t*>(coefs); src.nCoefs = coefs ? n_coefs : 0; src.haveCoefs = coefs != NULL;
+    src.pA = static_cast<const uint8_t*>(points_a); src.pB1 = static_cast<const uint8_t*>(points_b1);
+    src.pB2 = static_cast<const uint8_t*>(points_b2); src.pRoundC = static_cast<const uint8_t*>(points_round_c);
+    src.pFinalC = static_cast<const uint8_t*>(points_final_c); src.pH = static_cast<const uint8_t*>(points_h);
+    src.idx1 = static_cast<const uint8_t*>(round_indexes); src.idx2 = static_cast<const uint8_t*>(final_round_indexes);
+    *prover_object = static_cast<ProverBase*>(new UltraGrothProver(zkey_header, zkey_header_size, src, device, shard_rank, shard_count));
     API_CATCH
 }
 int ug_ultra_groth_prover_round_commit(void* prover_object, void* commit_part_out, char* error_msg, unsigned long long error_msg_maxsize) {

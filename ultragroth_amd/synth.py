@@ -210,40 +210,61 @@ def build_witness(log_domain, mix="U", seed=0x5EED0000):
     return wtns + struct.pack("<IQ", 2, w.nbytes) + w.tobytes()
 
 
-def build_ultra_circuit(dev, log_domain, mix="C", seed=0x5EED0005, lookup_log=8):
-    """UltraGroth (protocol 1337) zkey + .uwtns of the same shapes: SURVEY.md section 8(d) config 5.
-
-    nPublic = 2 with rand_indx = 2; the private signals are split into a round set C1 (a quarter of them) and a
-    final set C2 (the rest); lookup table of 2^lookup_log rows, nVars/8 chunks. Section map as the reference reads
-    it (src/prover.cpp:242-259, src/zkey_utils.cpp:123-163; uwtns sections 3..6 src/prover.cpp:287-292)."""
-    domain = 1 << log_domain
-    nvars = domain - 1
-    n_public, rand_indx = 2, 2
+def _ultra_index_lists(log_domain, seed):
+    """the generator's split of the private signals into the round set (a quarter) and the final set, and the generator
+    state behind it (the .uwtns draws from the same stream)"""
+    nvars = (1 << log_domain) - 1
+    n_public = 2
     rng = np.random.Generator(np.random.PCG64(seed))
     priv = rng.permutation(np.arange(n_public + 1, nvars, dtype=np.uint32))
     n1 = len(priv) // 4
-    idx1 = np.sort(priv[:n1]).astype("<u4")
-    idx2 = np.sort(priv[n1:]).astype("<u4")
+    return np.sort(priv[:n1]).astype("<u4"), np.sort(priv[n1:]).astype("<u4"), rng
+
+
+def _ultra_header(dev, log_domain, n1, n2, n_public=2, rand_indx=2):
+    domain = 1 << log_domain
     r_le = R_MOD.to_bytes(32, "little")
     q_le = Q_MOD.to_bytes(32, "little")
     vk_g1 = bytes(synth_points(dev, 4, SEEDS["VK"]))                    # alpha1, beta1, round_delta1, final_delta1
     vk_g2 = bytes(synth_points(dev, 4, SEEDS["VK"], g2=True))           # beta2, gamma2, round_delta2, final_delta2
     header = struct.pack("<I", 32) + q_le + struct.pack("<I", 32) + r_le
-    header += struct.pack("<IIIIII", nvars, n_public, domain, len(idx1), len(idx2), rand_indx)
+    header += struct.pack("<IIIIII", domain - 1, n_public, domain, n1, n2, rand_indx)
     header += vk_g1[0:64] + vk_g1[64:128] + vk_g2[0:128] + vk_g2[128:256]
     header += vk_g1[128:192] + vk_g2[256:384] + vk_g1[192:256] + vk_g2[384:512]
-    coefs = coefficients(domain, nvars, seed + 1)
-    secs = [
-        (1, struct.pack("<I", 1337)), (2, header), (3, bytes(64 * (n_public + 1))),
-        (4, struct.pack("<I", len(coefs)) + coefs.tobytes()),
-        (5, bytes(synth_points(dev, nvars, SEEDS["A"]))), (6, bytes(synth_points(dev, nvars, SEEDS["B1"]))),
-        (7, bytes(synth_points(dev, nvars, SEEDS["B2"], g2=True))),
-        (8, bytes(synth_points(dev, len(idx1), SEEDS["C"]))),                 # round points C1
-        (9, bytes(synth_points(dev, len(idx2), SEEDS["C"] + (1 << 28)))),     # final points C2
-        (10, idx1.tobytes()), (11, idx2.tobytes()),
-        (12, bytes(synth_points(dev, domain, SEEDS["H"]))), (13, b""),
-    ]
-    zkey = b"zkey" + struct.pack("<II", 1, len(secs)) + b"".join(_section(i, p) for i, p in secs)
+    return header
+
+
+def ultra_info(log_domain, seed=0x5EED0005):
+    """sizes of build_ultra_circuit(log_domain, seed) without building it"""
+    idx1, idx2, _ = _ultra_index_lists(log_domain, seed)
+    domain = 1 << log_domain
+    return dict(domainSize=domain, nVars=domain - 1, nPublic=2, randIndx=2, nC1=len(idx1), nC2=len(idx2), nCoefs=4 * domain)
+
+
+def build_ultra_circuit_slices(dev, log_domain, ranges, with_coefs=True, seed=0x5EED0005):
+    """What ONE rank of a sharded UltraGroth prover needs of build_ultra_circuit(log_domain, seed=seed), without the rest:
+    (header section, coefficient records or None, (A, B1, B2, C1, C2, H, round_indexes, final_round_indexes) slices) for
+    ranges = ((w0, w1), (r0, r1), (f0, f1), (h0, h1)) as ShardedUltraGrothProver.shard_ranges reports them."""
+    import ctypes as C
+    domain = 1 << log_domain
+    idx1, idx2, _ = _ultra_index_lists(log_domain, seed)
+    (w0, w1), (r0, r1), (f0, f1), (h0, h1) = ranges
+    coefs = None
+    if with_coefs:
+        coefs = (C.c_char * (4 * domain * 44))()
+        coefficients(domain, domain - 1, seed + 1, out=coefs)
+    slices = (synth_points(dev, w1 - w0, SEEDS["A"] + w0), synth_points(dev, w1 - w0, SEEDS["B1"] + w0),
+              synth_points(dev, w1 - w0, SEEDS["B2"] + w0, g2=True), synth_points(dev, r1 - r0, SEEDS["C"] + r0),
+              synth_points(dev, f1 - f0, SEEDS["C"] + (1 << 28) + f0), synth_points(dev, h1 - h0, SEEDS["H"] + h0),
+              idx1[r0:r1].tobytes(), idx2[f0:f1].tobytes())
+    return _ultra_header(dev, log_domain, len(idx1), len(idx2)), coefs, slices
+
+
+def _ultra_witness(log_domain, mix, seed, lookup_log, idx2, rng, n_public=2, rand_indx=2):
+    """the .uwtns of build_ultra_circuit: signals, chunks, frequencies and the two lookup index lists (src/prover.cpp:287-292);
+    rng = the generator state _ultra_index_lists left"""
+    nvars = (1 << log_domain) - 1
+    r_le = R_MOD.to_bytes(32, "little")
     w = scalars(nvars, mix, seed + 2)
     w[0] = (1, 0, 0, 0)
     lookup = 1 << lookup_log
@@ -257,7 +278,39 @@ def build_ultra_circuit(dev, log_domain, mix="C", seed=0x5EED0005, lookup_log=8)
     p_idx = np.concatenate([np.array([0], dtype=np.uint32), 1 + rng.permutation(n_push - 1)[:len(targets)].astype(np.uint32)]).astype("<u4")
     uw = [(1, struct.pack("<I", 32) + r_le + struct.pack("<I", nvars)), (2, w.tobytes()), (3, chunks.tobytes()),
           (4, freq.tobytes()), (5, w_idx.tobytes()), (6, p_idx.tobytes())]
-    wtns = b"wtns" + struct.pack("<II", 2, len(uw)) + b"".join(_section(i, p) for i, p in uw)
+    return b"wtns" + struct.pack("<II", 2, len(uw)) + b"".join(_section(i, p) for i, p in uw), lookup, n_chunks
+
+
+def build_ultra_witness(log_domain, mix="C", seed=0x5EED0005, lookup_log=8):
+    """the .uwtns of build_ultra_circuit(log_domain, mix, seed, lookup_log) alone"""
+    _, idx2, rng = _ultra_index_lists(log_domain, seed)
+    return _ultra_witness(log_domain, mix, seed, lookup_log, idx2, rng)[0]
+
+
+def build_ultra_circuit(dev, log_domain, mix="C", seed=0x5EED0005, lookup_log=8):
+    """UltraGroth (protocol 1337) zkey + .uwtns of the same shapes: SURVEY.md section 8(d) config 5.
+
+    nPublic = 2 with rand_indx = 2; the private signals are split into a round set C1 (a quarter of them) and a
+    final set C2 (the rest); lookup table of 2^lookup_log rows, nVars/8 chunks. Section map as the reference reads
+    it (src/prover.cpp:242-259, src/zkey_utils.cpp:123-163; uwtns sections 3..6 src/prover.cpp:287-292)."""
+    domain = 1 << log_domain
+    nvars = domain - 1
+    n_public, rand_indx = 2, 2
+    idx1, idx2, rng = _ultra_index_lists(log_domain, seed)
+    header = _ultra_header(dev, log_domain, len(idx1), len(idx2), n_public, rand_indx)
+    coefs = coefficients(domain, nvars, seed + 1)
+    secs = [
+        (1, struct.pack("<I", 1337)), (2, header), (3, bytes(64 * (n_public + 1))),
+        (4, struct.pack("<I", len(coefs)) + coefs.tobytes()),
+        (5, bytes(synth_points(dev, nvars, SEEDS["A"]))), (6, bytes(synth_points(dev, nvars, SEEDS["B1"]))),
+        (7, bytes(synth_points(dev, nvars, SEEDS["B2"], g2=True))),
+        (8, bytes(synth_points(dev, len(idx1), SEEDS["C"]))),                 # round points C1
+        (9, bytes(synth_points(dev, len(idx2), SEEDS["C"] + (1 << 28)))),     # final points C2
+        (10, idx1.tobytes()), (11, idx2.tobytes()),
+        (12, bytes(synth_points(dev, domain, SEEDS["H"]))), (13, b""),
+    ]
+    zkey = b"zkey" + struct.pack("<II", 1, len(secs)) + b"".join(_section(i, p) for i, p in secs)
+    wtns, lookup, n_chunks = _ultra_witness(log_domain, mix, seed, lookup_log, idx2, rng, n_public, rand_indx)
     info = dict(domainSize=domain, nVars=nvars, nPublic=n_public, randIndx=rand_indx, nC1=len(idx1), nC2=len(idx2),
                 lookup=lookup, chunks=n_chunks)
     return zkey, wtns, info
