@@ -1,4 +1,6 @@
 # round 3: the radix partition without the zero digits (drop mode of RadixSorter::sort, UG_SORT_DROP=0 for the old form): the parity
+# (round 4: the A/B switches this recipe sets exist only in the -DUG_MEASURE build -- make -C ultragroth_amd/csrc MEASURE=1 measure)
+export ULTRAGROTH_LIB=${GRAFT_REPO_ROOT:-$PWD}/ultragroth_amd/csrc/libultragroth_hip_measure.so
 # suites, then both forms at 2^24 on the circom-like and the uniform mix with --check, radix kernels under rocprofv3:
 # bash tools/run_r3_drop.sh
 set -o pipefail

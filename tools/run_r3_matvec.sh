@@ -1,4 +1,6 @@
 # round 3: coefficient mat-vec with the bit reversal in 16 x 16 LDS tiles (UG_MATVEC_TILED=1, default) against one scattered
+# (round 4: the A/B switches this recipe sets exist only in the -DUG_MEASURE build -- make -C ultragroth_amd/csrc MEASURE=1 measure)
+export ULTRAGROTH_LIB=${GRAFT_REPO_ROOT:-$PWD}/ultragroth_amd/csrc/libultragroth_hip_measure.so
 # 32-byte store per lane (=0): parity of the H polynomial first, then both forms under rocprofv3 at 2^24: bash tools/run_r3_matvec.sh
 set -o pipefail
 cd $GRAFT_REPO_ROOT

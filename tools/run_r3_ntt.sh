@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 4: the A/B switches this recipe sets exist only in the -DUG_MEASURE build -- make -C ultragroth_amd/csrc MEASURE=1 measure)
+export ULTRAGROTH_LIB=${GRAFT_REPO_ROOT:-$PWD}/ultragroth_amd/csrc/libultragroth_hip_measure.so
 # round 3: NTT with unpacked twiddles and the three chains batched per pass; mat-vec with four entries in flight
 set -o pipefail
 mkdir -p gpurun_out

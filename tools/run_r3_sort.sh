@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 4: the A/B switches this recipe sets exist only in the -DUG_MEASURE build -- make -C ultragroth_amd/csrc MEASURE=1 measure)
+export ULTRAGROTH_LIB=${GRAFT_REPO_ROOT:-$PWD}/ultragroth_amd/csrc/libultragroth_hip_measure.so
 # round 3: the hand-written radix partition against the library sort (UG_SORT=cub), whole-library A/B at 2^24; then the gather ablation
 set -o pipefail
 mkdir -p gpurun_out

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 4: the A/B switches this recipe sets exist only in the -DUG_MEASURE build -- make -C ultragroth_amd/csrc MEASURE=1 measure)
+export ULTRAGROTH_LIB=${GRAFT_REPO_ROOT:-$PWD}/ultragroth_amd/csrc/libultragroth_hip_measure.so
 # round 3: tile shapes of the radix partition (pairs per lane in the pair-form passes, scalars per lane in the fused first pass)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp
