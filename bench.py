@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--overlap", action="store_true", help="ULTRAGROTH_OVERLAP=1: H branch on a second stream beside the witness MSMs "
                                                            "(faster, but per-kernel times and the MSM | FFT split stretch)")
     ap.add_argument("--ultra", action="store_true", help="BASELINE.json configs[4]: UltraGroth two-round prove (single GPU)")
+    ap.add_argument("--replicas", action="store_true", help="N > 1: after the sharded steps, also time the OTHER way to use a node -- every "
+                    "rank a whole prover of its own, proving its own proofs, no exchange at all -- and report it as the extra key "
+                    "`replicated_proofs_per_s` (throughput of independent proofs; `value` stays the one proof sharded over the ranks, which "
+                    "is what BASELINE.json's configs[3] and the north star ask for). Every rank then builds the whole circuit.")
     ap.add_argument("--pmc-summary", default=None, help="summary of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload "
                     "(tools/pmc_summary.py, made in the same gpurun call by tools/run_r4_prof.sh): `roofline.traffic` is then what those "
                     "passes counted; without it the newest committed profiles/r*_pmc_summary.json is read and labelled as such")
@@ -680,6 +684,35 @@ def main():
                 chk = ("groth16_prover_prove differs from the phase calls", "")
         ug.set_test_blinding(b"")
 
+    # --replicas: the node used the other way round -- N independent provers, each proving whole proofs on its own GPU (what a
+    # batch of unrelated proofs wants: no exchange, linear by construction). An extra figure; a failure here costs the figure,
+    # not the line.
+    replicated = None
+    if dist is not None and args.replicas:
+        try:
+            ms_sharded = 1e3 * elapsed / args.steps
+            prover.close()
+            os.environ["ULTRAGROTH_DEVICE"] = str(local_rank)       # (the reference's create call takes its device from here)
+            full_zkey, full_wtns, _ = synth.build_circuit(dev, log_domain, mix=args.mix, g1_only=args.g1_only)
+            own = ug.Groth16Prover(full_zkey)
+            del full_zkey
+            own.load_witness(full_wtns)
+            own.prove_resident()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                own.prove_resident()
+            barrier()
+            dt = time.perf_counter() - t1
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            own.close()
+            replicated = {"proofs_per_s": world * args.steps / float(tt.item()), "ms_per_proof_per_rank": 1e3 * float(tt.item()) / args.steps,
+                          "note": "every rank a whole prover of its own proving its own proofs (no exchange); against %.2f ms per proof "
+                                  "for ONE proof sharded over the %d ranks" % (ms_sharded, world)}
+        except Exception as e:                          # noqa: BLE001 -- reported, not fatal
+            replicated = {"proofs_per_s": None, "error": str(e)[:300]}
+
     # The process group ends HERE, before rank 0 assembles the line: what follows on rank 0 (the --check comparison, which
     # synthesises the whole circuit once more; at N = 1 the CPU baseline) is host work of tens of seconds, and the other ranks
     # must not sit in a collective -- spinning on their GPUs -- while it runs: they are done and exit.
@@ -776,6 +809,7 @@ def main():
                              "stream time of rank 0's MSM and FFT parts over the K timed steps; its chains run on a second stream BESIDE "
                              "its witness MSMs, so the two overlap and their sum exceeds the step"),
             "comm": comm,
+            "replicated": replicated,
             # outside the timed region (N = 1): the reference's call with the .wtns in host memory
             "prove_call_ms_per_step": prove_call_ms,
             "witness_upload_ms_per_proof": upload_ms,

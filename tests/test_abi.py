@@ -225,6 +225,59 @@ def test_balanced_witness_ranges_tile_the_witness():
         ug.ShardedGroth16Prover.balanced_witness_range(100, 3, 3)
 
 
+def test_shard_layouts_tile_everything(monkeypatch):
+    """ug_groth16_shard_layout (host arithmetic only): for every rank count and every split into P base-point ranges x B bucket-class
+    ranks the layouts tile the witness (per group), the residues [0, Q) and the special-bucket scalars of every group, and h; the
+    default is the base-point form (P = world, no classes: it measured faster); ULTRAGROTH_SHARD=PxB asks for
+    classes; chain ranks get smaller shares, and from five ranks on no part of h; no rank gets more than 31 residues (a result
+    block holds 63 points); the ultra ranges tile their four sets"""
+    import ultragroth_amd as ug
+    S = ug.ShardedGroth16Prover
+    monkeypatch.delenv("ULTRAGROTH_SHARD", raising=False)
+    for log_n in (14, 20, 24, 26):
+        n_vars, dom = (1 << log_n) - 1, 1 << log_n
+        for world in (1, 2, 3, 4, 5, 6, 8, 16):
+            base = [S.shard_layout(n_vars, 1, dom, k, world) for k in range(world)]
+            assert all(L.q_log == 0 for L in base)                               # the library's own choice: base-point ranges
+            assert [L.witness for L in base] == [S.balanced_witness_range(n_vars, k, world) for k in range(world)]
+            for P in [p for p in (1, 2, 4, 8) if world % p == 0 and p < world]:
+                lay = [S.shard_layout(n_vars, 1, dom, k, world, P) for k in range(world)]
+                B = world // P
+                assert lay[0].h[0] == 0 and lay[-1].h[1] == dom and all(a.h[1] == b.h[0] for a, b in zip(lay, lay[1:]))
+                assert lay[0].witness[0] == 0 and lay[-1].witness[1] == n_vars
+                for g in range(P):
+                    grp = lay[g * B:(g + 1) * B]
+                    Q = 1 << grp[0].q_log
+                    assert grp[0].q_log > 0 and all(L.witness == grp[0].witness and L.q_log == grp[0].q_log for L in grp)
+                    assert grp[0].first_residue == 0 and grp[-1].first_residue + grp[-1].residues == Q
+                    assert all(a.first_residue + a.residues == b.first_residue and a.special[1] == b.special[0] for a, b in zip(grp, grp[1:]))
+                    assert (grp[0].special[0], grp[-1].special[1]) == grp[0].witness
+                    assert all(1 <= L.residues <= 31 for L in grp)
+                    if g + 1 < P:
+                        assert grp[0].witness[1] == lay[(g + 1) * B].witness[0]
+                for k, L in enumerate(lay):
+                    assert L.chains == [c for c in range(3) if c % world == k]
+                    assert L.c[0] == max(L.witness[0] - 2, 0) and L.c[1] == max(L.witness[1] - 2, 0)
+                if world >= 5:
+                    assert all(L.h[0] == L.h[1] for L in lay[:3]) and all(L.h[1] > L.h[0] for L in lay[3:])
+                    if P == 1 and world == 8:                                     # eight ranks: a chain outweighs a fifth of the H product, so the chain ranks get fewer residues
+                        assert max(L.residues for L in lay[:3]) <= min(L.residues for L in lay[3:])
+    monkeypatch.setenv("ULTRAGROTH_SHARD", "2x4")
+    assert [S.shard_layout((1 << 24) - 1, 1, 1 << 24, k, 8).q_log for k in range(8)] == [6] * 8
+    assert S.shard_layout((1 << 24) - 1, 1, 1 << 24, 0, 4).q_log == 0                       # 2 x 4 does not fit four ranks: base-point form
+    monkeypatch.setenv("ULTRAGROTH_SHARD", "auto")
+    assert S.shard_layout((1 << 24) - 1, 1, 1 << 24, 0, 8).witness == (0, (1 << 24) - 1)      # one group: the tables of 2^24 points fit
+    assert S.shard_layout((1 << 26) - 1, 1, 1 << 26, 7, 8).witness[0] > 0                      # 2^26: two groups
+    assert S.shard_layout((1 << 24) - 1, 1, 1 << 24, 0, 2).q_log == 0                          # fewer than four ranks: base-point form
+    with pytest.raises(ug.ProverError):
+        S.shard_layout(100, 1, 128, 4, 4)
+    U = ug.ShardedUltraGrothProver
+    for world in (1, 3, 8):
+        rs = [U.shard_ranges(1000, 1024, 249, 748, k, world) for k in range(world)]
+        for part, end in zip(range(4), (1000, 249, 748, 1024)):
+            assert rs[0][part][0] == 0 and rs[-1][part][1] == end and all(a[part][1] == b[part][0] for a, b in zip(rs, rs[1:]))
+
+
 @pytest.mark.parametrize("order", ["library_first", "torch_first"])
 def test_one_hip_runtime_whatever_the_import_order(order):
     """torch bundles a HIP runtime of its own: the loader must leave ONE copy in the process whichever is imported first

@@ -15,3 +15,5 @@ timeout -k 10 600 python bench.py --log-domain 22 --steps 3 --warmup 1 --no-cpu-
 timeout -k 10 600 python bench.py --log-domain 22 --ultra --steps 3 --warmup 1 > gpurun_out/cfg4.json 2> gpurun_out/cfg4.err && show gpurun_out/cfg4.json || tail -3 gpurun_out/cfg4.err
 ( time timeout -k 10 900 python bench.py --log-domain 26 --steps 2 --warmup 1 --no-cpu-baseline ) > gpurun_out/cfg3.json 2> gpurun_out/cfg3.err && show gpurun_out/cfg3.json || tail -5 gpurun_out/cfg3.err
 tail -4 gpurun_out/cfg3.err
+# (round 4) the reference's largest legal domain, 2^27: the piecewise path (ranges above 2^26 scalars) at its own size
+( time timeout -k 10 900 python bench.py --log-domain 27 --steps 2 --warmup 1 --no-cpu-baseline --host-threads 1 ) > gpurun_out/cfg27.json 2> gpurun_out/cfg27.err && show gpurun_out/cfg27.json || tail -5 gpurun_out/cfg27.err

@@ -7,6 +7,9 @@ for N in 2 4; do
 timeout -k 10 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus $N --steps 2 --warmup 1 --log-domain 18 --no-cpu-baseline --check > gpurun_out/multi$N.json 2> gpurun_out/multi$N.err; echo "N=$N rc=$?"; grep -v "socket.cpp\|Gloo\|amdgpu.ids" gpurun_out/multi$N.err | tail -5 | cut -c1-300; python -c "
 import json; d=json.loads(open('gpurun_out/multi$N.json').read().strip().splitlines()[-1]); print(d['n_gpus'], d['ms_per_step'], d['config']['parallelism'], d.get('check'))"
 done
+# --replicas: the extra throughput figure (every rank a whole prover of its own)
+timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29614 bench.py --gpus 2 --steps 2 --warmup 1 --log-domain 18 --no-cpu-baseline --check --replicas > gpurun_out/multirep.json 2> gpurun_out/multirep.err; echo "replicas rc=$?"; python -c "
+import json; d=json.loads(open('gpurun_out/multirep.json').read().strip().splitlines()[-1]); print(d['n_gpus'], d['ms_per_step'], d.get('check'), d['replicated'])"
 # the bucket-class layouts (ULTRAGROTH_SHARD=PxB), four and five ranks
 for SH in 1x4 2x2 1x5; do
 N=${SH#*x}; P=${SH%x*}; N=$((N * P))
