@@ -28,7 +28,10 @@ namespace ug {
 
 namespace {
 
-constexpr int SORT_THREADS = 256;
+#ifndef UG_SORT_THREADS
+#define UG_SORT_THREADS 256           // (512 measured in round 4: profiles/r04_variants_ab.txt item 5)
+#endif
+constexpr int SORT_THREADS = UG_SORT_THREADS;
 constexpr int SORT_WAVES = SORT_THREADS / 64;
 constexpr int SORT_MAX_IPT = 16;              // most pairs a lane holds per tile (32 was measured: the longer unrolled bodies cost every shape 10 %)
 constexpr int SORT_FUSED_MAX_WINDOWS = 16;    // the fused first pass takes whole scalars per lane: windows * scalars_per_lane <= SORT_MAX_IPT
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
     u32* wcnt = lds + 2 * T;                              // SORT_WAVES x 256 per-wave counters, later per-wave starts
     u32* texcl = wcnt + SORT_WAVES * SORT_MAX_BINS;       // 256: start of each bin inside the tile
     u32* gbase = texcl + SORT_MAX_BINS;                   // 256: global position of the tile's first pair of a bin, minus its tile position
-    u32* misc = gbase + SORT_MAX_BINS;                    // [0] tile number, [1..4] wave totals of the scan
+    u32* misc = gbase + SORT_MAX_BINS;                    // [0] tile number, [1 .. SORT_WAVES] wave totals of the scan
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const u32 bins = 1u << a.bins_log, dmask = bins - 1;
 
@@ -310,7 +313,12 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
     }
     __syncthreads();
     // ... and out: neighbouring lanes hold neighbouring pairs of a bin, i.e. neighbouring addresses
-    const u32 staged = (FROM_SCALARS && a.drop) ? misc[1] + misc[2] + misc[3] + misc[4] : T;      // drop mode: the pairs the tile kept
+    u32 staged = T;
+    if (FROM_SCALARS && a.drop) {                          // drop mode: the pairs the tile kept
+        staged = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; w++) staged += misc[1 + w];
+    }
     for (u32 lp = tid; lp < staged; lp += SORT_THREADS) {
         const u32 k = stage_k[lp];
         const u32 d = (k >> a.shift) & dmask;
@@ -435,8 +443,17 @@ int RadixSorter::sort(const u32* scalars, const MsmGeometry& geo, u32 sentinel, 
         a.n_tiles = (u32)tiles;
         if (tiles > tiles_cap) throw std::logic_error("radix sort: look-back table too small");
         UG_HIP(hipMemsetAsync(lookback, 0, (size_t)tiles * ((size_t)1 << bins_log[p]) * 4, stream));
-        const size_t lds = (2 * T + SORT_WAVES * SORT_MAX_BINS + 2 * SORT_MAX_BINS + 8) * 4;
+        const size_t lds = (2 * T + SORT_WAVES * SORT_MAX_BINS + 2 * SORT_MAX_BINS + 16) * 4;
         const unsigned grid = (unsigned)std::min<u64>(tiles, SORT_MAX_GRID);
+        if (lds > 64 * 1024) {                                 // (tiles of more than 64 KiB: only the UG_SORT_THREADS = 512 build)
+            static const bool once = [] {
+                const int cap = 160 * 1024;
+                UG_HIP(hipFuncSetAttribute((const void*)radix_pass_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                UG_HIP(hipFuncSetAttribute((const void*)radix_pass_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                return true;
+            }();
+            (void)once;
+        }
         static const int lbw = measure_env("UG_SORT_LBW") ? atoi(measure_env("UG_SORT_LBW")) : 4;      // A/B switch: look-back window
         if (lbw >= 16) {
             if (first_fused) hipLaunchKernelGGL((radix_pass_kernel<true, 16>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
