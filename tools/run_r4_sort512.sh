@@ -7,8 +7,8 @@ V=$GRAFT_REPO_ROOT/ultragroth_amd/csrc/build/variants/libug_sort512.so
 ULTRAGROTH_LIB=$V python bench.py --log-domain 20 --steps 1 --warmup 1 --no-cpu-baseline --check > gpurun_out/s512_check.json 2> gpurun_out/s512_check.err; echo "variant --check 2^20 U rc=$?"
 ULTRAGROTH_LIB=$V python bench.py --log-domain 20 --mix C --steps 1 --warmup 1 --no-cpu-baseline --check > gpurun_out/s512_checkc.json 2> gpurun_out/s512_checkc.err; echo "variant --check 2^20 C rc=$?"
 cd /tmp && export TMPDIR=/tmp
-for WHICH in base s512 base s512; do
-  L=""; [ $WHICH = s512 ] && L=$V
+for WHICH in ${VARIANTS:-base sort512 base sort512}; do
+  L=""; [ $WHICH != base ] && L=$GRAFT_REPO_ROOT/ultragroth_amd/csrc/build/variants/libug_$WHICH.so
   rm -rf $GRAFT_REPO_ROOT/gpurun_out/ab_$WHICH
   ULTRAGROTH_LIB=$L timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/ab_$WHICH -- python3 $GRAFT_REPO_ROOT/bench.py --log-domain 24 --steps 4 --warmup 1 --no-cpu-baseline --host-threads 1 > $GRAFT_REPO_ROOT/gpurun_out/ab_$WHICH.json 2> $GRAFT_REPO_ROOT/gpurun_out/ab_$WHICH.err
   python3 - $WHICH <<'PY'

@@ -9,7 +9,7 @@
 //   radix_hist_kernel     one read of the SCALARS (not of a materialised pair array): recodes them into signed window digits
 //                         and counts, for every pass of the sort, how many pairs fall into each digit bin
 //   radix_scan_kernel     exclusive scan of those counts: where each bin of each pass starts
-//   radix_pass_kernel     one pass = one stable partition by up to 8 key bits. A tile of 256 lanes x <= 16 pairs is ranked
+//   radix_pass_kernel     one pass = one stable partition by up to 8 key bits. A tile of 512 lanes x <= 16 pairs is ranked
 //                         inside the workgroup (wave-level match on the digit bits, per-wave counters in LDS), reordered
 //                         through LDS so that pairs of one bin leave in runs, and scattered; the offset of a tile within a
 //                         bin comes from a decoupled look-back over the tiles before it (one 32-bit status word per tile and
@@ -29,7 +29,8 @@ namespace ug {
 namespace {
 
 #ifndef UG_SORT_THREADS
-#define UG_SORT_THREADS 256           // (512 measured in round 4: profiles/r04_variants_ab.txt item 5)
+#define UG_SORT_THREADS 512           // round 4 (profiles/r04_variants_ab.txt item 5): tiles of 8 192 pairs leave 256-byte runs per bin; 256 lanes:
+                                      // 1.17 ms per pass over 201 M pairs, 512: 1.01, 1 024: 1.05
 #endif
 constexpr int SORT_THREADS = UG_SORT_THREADS;
 constexpr int SORT_WAVES = SORT_THREADS / 64;
@@ -81,10 +82,14 @@ __device__ __forceinline__ u32 digit_key(const DigitPlan& d, int w, u32 mag, u64
 }
 // the signed-digit recoding of one scalar: digit in (-2^(c-1), 2^(c-1)], a carry into the next window; a zero digit (and a digit
 // another rank owns) gets the sentinel key; f(window, key, val) is called for every window in order
-template <class Fn>
+// CW: the window width as a compile-time constant (0: taken from the plan). The widths the provers use at size (22: window
+// tables of 2^24 points; 20: classic windows and many-GPU ranks) get an unrolled window loop with static limb indices -- the
+// runtime form indexes the scalar's limbs dynamically, a chain of selects per window.
+template <int CW, class Fn>
 __device__ __forceinline__ void recode_scalar(const u32* scalars, u64 i, const DigitPlan& d, Fn&& f) {
+    const int windows = CW ? (255 + CW - 1) / CW : d.windows;
     if (i >= d.n) {                                   // padding of the last tile
-        for (int w = 0; w < d.windows; w++) f(w, 0xffffffffu, 0u);
+        for (int w = 0; w < windows; w++) f(w, 0xffffffffu, 0u);
         return;
     }
     u32 s[10];
@@ -100,28 +105,31 @@ __device__ __forceinline__ void recode_scalar(const u32* scalars, u64 i, const D
         }
     }
     u32 carry = 0;
-    const int c = d.c;
+    const int c = CW ? CW : d.c;
     const u32 half = 1u << (c - 1), full = 1u << c, mask = full - 1;
-    for (int w = 0; w < d.windows; w++) {
-        const int bit = w * c, word = bit >> 5, sh = bit & 31;
+#pragma unroll
+    for (int w = 0; w < (CW ? (255 + CW - 1) / CW : 1); w++) {       // (compile-time trip count when CW != 0 ...)
+      for (int wr = w; wr < (CW ? w + 1 : windows); wr++) {           // (... else the runtime loop, entered once)
+        const int bit = wr * c, word = bit >> 5, sh = bit & 31;
         const u64 two = (u64)s[word] | ((u64)s[word + 1] << 32);
         const u32 raw = ((u32)(two >> sh) & mask) + carry;
-        const u32 tag = d.tables ? (u32)w << TABLE_INDEX_BITS : 0u;
+        const u32 tag = d.tables ? (u32)wr << TABLE_INDEX_BITS : 0u;
         u32 key, val;
         if (raw > half) {                             // negative digit raw - 2^c, carry into the next window
             const u32 mag = full - raw;               // 0 when the window was all ones and a carry came in
             carry = 1;
-            key = mag ? digit_key(d, w, mag, i) : d.sentinel;
+            key = mag ? digit_key(d, wr, mag, i) : d.sentinel;
             val = (u32)i | tag | 0x80000000u;
-        } else { carry = 0; key = raw ? digit_key(d, w, raw, i) : d.sentinel; val = (u32)i | tag; }
-        f(w, key, val);
+        } else { carry = 0; key = raw ? digit_key(d, wr, raw, i) : d.sentinel; val = (u32)i | tag; }
+        f(wr, key, val);
+      }
     }
 }
 
 __global__ void digit_pairs_kernel(const u32* scalars, DigitPlan d, u32* keys, u32* vals) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.n) return;
-    recode_scalar(scalars, i, d, [&](int w, u32 key, u32 val) { keys[(u64)w * d.n + i] = key; vals[(u64)w * d.n + i] = val; });
+    recode_scalar<0>(scalars, i, d, [&](int w, u32 key, u32 val) { keys[(u64)w * d.n + i] = key; vals[(u64)w * d.n + i] = val; });
 }
 
 struct SortHistArgs {
@@ -135,6 +143,7 @@ struct SortHistArgs {
 };
 
 // counts per pass and bin; a grid-stride loop, counters in LDS, one global atomic per (workgroup, pass, bin)
+template <int CW>
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(SortHistArgs a) {
     __shared__ u32 h[4 * SORT_MAX_BINS];
     for (int i = threadIdx.x; i < 4 * SORT_MAX_BINS; i += SORT_THREADS) h[i] = 0;
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(SortHistArgs a
     if (a.scalars) {
         const u64 lanes = a.n_padded / (u64)a.plan.windows;       // one scalar (all its windows) per lane turn
         for (u64 i = (u64)blockIdx.x * SORT_THREADS + threadIdx.x; i < lanes; i += stride)
-            recode_scalar(a.scalars, i, a.plan, [&](int, u32 key, u32) { count(key); });
+            recode_scalar<CW>(a.scalars, i, a.plan, [&](int, u32 key, u32) { count(key); });
     } else {
         for (u64 i = (u64)blockIdx.x * SORT_THREADS + threadIdx.x; i < a.n_padded; i += stride) count(i < a.n_pairs ? a.keys_in[i] : 0xffffffffu);
     }
@@ -171,7 +180,8 @@ __global__ void radix_scan_kernel(u32* hist, int passes, u32* n_valid_out) {
     if (p == 0 && n_valid_out) *n_valid_out = run;      // drop mode: every counted pair is a pair that stays
 }
 
-template <bool FROM_SCALARS, int LBW>
+constexpr int LBW = 4;     // look-back window: the status words of four predecessors are read per turn (8 and 16 measured in round 3: no gain)
+template <bool FROM_SCALARS, int CW>
 __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a) {
     extern __shared__ u32 lds[];
     const int ipt = a.ipt;
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
         for (int sc = 0; sc < a.spl; sc++) {
             const u64 i = ((u64)tile * SORT_THREADS + tid) * (u64)a.spl + (u64)sc;
             const int j0 = sc * a.plan.windows;
-            recode_scalar(a.scalars, i, a.plan, [&](int w, u32 k, u32 v) {
+            recode_scalar<CW>(a.scalars, i, a.plan, [&](int w, u32 k, u32 v) {
 #pragma unroll
                 for (int j = 0; j < SORT_MAX_IPT; j++) if (j == j0 + w) { key[j] = k; val[j] = v; }
             });
@@ -381,17 +391,23 @@ int RadixSorter::sort(const u32* scalars, const MsmGeometry& geo, u32 sentinel, 
                       u32* const buf_keys[2], u32* const buf_vals[2], u32* error_flag, hipStream_t stream, u32* n_valid_out, bool* dropped_out) {
     const int windows = geo.windows;
     const DigitPlan plan = geo.digit_plan();
-    int shift[4], bins_log[4];
-    const int passes = radix_plan(bits, shift, bins_log);
-    if (passes > 4) throw std::logic_error("radix sort: key too wide");
     // measurement switches (-DUG_MEASURE builds): pairs per lane of the pair-form passes, scalars per lane of the fused first pass
-    static const int env_ipt = measure_env("UG_SORT_IPT") ? atoi(measure_env("UG_SORT_IPT")) : 16;
+#ifndef UG_SORT_IPT_DEFAULT
+#define UG_SORT_IPT_DEFAULT 16
+#endif
+    static const int env_ipt = measure_env("UG_SORT_IPT") ? atoi(measure_env("UG_SORT_IPT")) : UG_SORT_IPT_DEFAULT;
     static const int env_spl = measure_env("UG_SORT_SPL") ? atoi(measure_env("UG_SORT_SPL")) : 1;
     const int ipt_pairs = env_ipt < 4 ? 4 : env_ipt > SORT_MAX_IPT ? SORT_MAX_IPT : env_ipt;
     const bool fused = scalars != nullptr && windows <= SORT_FUSED_MAX_WINDOWS;
     static const bool drop_ok = !(measure_env("UG_SORT_DROP") && atoi(measure_env("UG_SORT_DROP")) == 0);      // A/B switch
     const bool drop = fused && n_valid_out != nullptr && drop_ok;
     if (dropped_out) *dropped_out = drop;
+    // drop mode sorts no sentinel: the keys are below it, and one bit less may do (2^21 buckets: 7 | 7 | 7 instead of 7 | 7 | 8 --
+    // the last pass with 128 bins instead of 256, i.e. runs twice as long per bin and tile)
+    if (drop) { bits = 1; while (((u64)1 << bits) < sentinel) bits++; }
+    int shift[4], bins_log[4];
+    const int passes = radix_plan(bits, shift, bins_log);
+    if (passes > 4) throw std::logic_error("radix sort: key too wide");
     int spl = 1;
     if (fused) { spl = env_spl < 1 ? 1 : env_spl; while (spl > 1 && spl * windows > SORT_MAX_IPT) spl--; }
     const int ipt_first = fused ? windows * spl : ipt_pairs;
@@ -415,7 +431,10 @@ int RadixSorter::sort(const u32* scalars, const MsmGeometry& geo, u32 sentinel, 
         const u64 lanes = fused ? h.n_padded / (u64)windows : h.n_padded;
         unsigned blocks = (unsigned)std::min<u64>((lanes + SORT_THREADS - 1) / SORT_THREADS, 2048);
         if (!blocks) blocks = 1;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(blocks), dim3(SORT_THREADS), 0, stream, h);
+        const int cw = fused ? (plan.c == 22 || plan.c == 20 ? plan.c : 0) : 0;
+        if (cw == 22) hipLaunchKernelGGL(radix_hist_kernel<22>, dim3(blocks), dim3(SORT_THREADS), 0, stream, h);
+        else if (cw == 20) hipLaunchKernelGGL(radix_hist_kernel<20>, dim3(blocks), dim3(SORT_THREADS), 0, stream, h);
+        else hipLaunchKernelGGL(radix_hist_kernel<0>, dim3(blocks), dim3(SORT_THREADS), 0, stream, h);
         UG_KERNEL_CHECK();
         hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(64), 0, stream, hist, passes, drop ? n_valid_out : (u32*)nullptr);
         UG_KERNEL_CHECK();
@@ -445,26 +464,23 @@ int RadixSorter::sort(const u32* scalars, const MsmGeometry& geo, u32 sentinel, 
         UG_HIP(hipMemsetAsync(lookback, 0, (size_t)tiles * ((size_t)1 << bins_log[p]) * 4, stream));
         const size_t lds = (2 * T + SORT_WAVES * SORT_MAX_BINS + 2 * SORT_MAX_BINS + 16) * 4;
         const unsigned grid = (unsigned)std::min<u64>(tiles, SORT_MAX_GRID);
-        if (lds > 64 * 1024) {                                 // (tiles of more than 64 KiB: only the UG_SORT_THREADS = 512 build)
+        // the fused first pass with the window width as a compile-time constant where the provers' sizes use it
+        const int cw = first_fused ? (plan.c == 22 || plan.c == 20 ? plan.c : 0) : 0;
+        if (lds > 64 * 1024) {                                 // (tiles of more than 64 KiB of LDS)
             static const bool once = [] {
                 const int cap = 160 * 1024;
-                UG_HIP(hipFuncSetAttribute((const void*)radix_pass_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-                UG_HIP(hipFuncSetAttribute((const void*)radix_pass_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                UG_HIP(hipFuncSetAttribute((const void*)radix_pass_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                UG_HIP(hipFuncSetAttribute((const void*)radix_pass_kernel<true, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                UG_HIP(hipFuncSetAttribute((const void*)radix_pass_kernel<true, 22>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                UG_HIP(hipFuncSetAttribute((const void*)radix_pass_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
                 return true;
             }();
             (void)once;
         }
-        static const int lbw = measure_env("UG_SORT_LBW") ? atoi(measure_env("UG_SORT_LBW")) : 4;      // A/B switch: look-back window
-        if (lbw >= 16) {
-            if (first_fused) hipLaunchKernelGGL((radix_pass_kernel<true, 16>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
-            else hipLaunchKernelGGL((radix_pass_kernel<false, 16>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
-        } else if (lbw >= 8) {
-            if (first_fused) hipLaunchKernelGGL((radix_pass_kernel<true, 8>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
-            else hipLaunchKernelGGL((radix_pass_kernel<false, 8>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
-        } else {
-            if (first_fused) hipLaunchKernelGGL((radix_pass_kernel<true, 4>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
-            else hipLaunchKernelGGL((radix_pass_kernel<false, 4>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
-        }
+        if (!first_fused) hipLaunchKernelGGL((radix_pass_kernel<false, 0>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
+        else if (cw == 22) hipLaunchKernelGGL((radix_pass_kernel<true, 22>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
+        else if (cw == 20) hipLaunchKernelGGL((radix_pass_kernel<true, 20>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
+        else hipLaunchKernelGGL((radix_pass_kernel<true, 0>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
         UG_KERNEL_CHECK();
         cur = dst;
     }
