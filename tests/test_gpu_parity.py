@@ -226,6 +226,37 @@ def test_msm_bucket_classes_add_up(device, zkey, table_c, q_log, parts, specials
     assert acc == exp
 
 
+def test_msm_bucket_classes_with_classic_windows(device):
+    """bucket classes on a CLASSIC schedule (no window tables: one bucket set per window and owned residue, the special buckets
+    per window, Horner over the windows on the host) -- possible when the windows are few enough for the result block: 2^16
+    scalars take ~20 windows; two ranks with one residue each, and four with the residues of Q = 4, G1 and G2"""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zk, wt, info = synth.build_circuit(device, 16, mix="C")
+    n = info["nVars"]
+    A, B2, wb = bytes(_sec(zk, "zkey", 5)), bytes(_sec(zk, "zkey", 7)), bytes(_sec(wt, "wtns", 2))
+    g1, g2 = device.bases(A, n), device.bases(B2, n, g2=True)
+    v = device.dvec(n, wb)
+    plain = device.schedule(v, 0, n)
+    exp1, exp2 = device.msm(g1, plain), device.msm(g2, plain, g2=True)
+    assert exp1 == O.g1_msm(A, wb, n)
+    ran = 0
+    for q_log, specials in ((1, 0), (2, 0), (1, 16), (2, 3)):
+        Q = 1 << q_log
+        s1, s2 = bytes(64), bytes(128)
+        try:
+            for r in range(Q):
+                sch = device.schedule(v, 0, n, classes=(q_log, r, 1, specials, n * r // Q, n * (r + 1) // Q - n * r // Q))
+                s1 = O.g1_add(s1, device.msm(g1, sch))
+                s2 = O.g2_add(s2, device.msm(g2, sch, g2=True))
+        except ug.DeviceError as e:                     # (the cost-model window brings more sets than a result block holds: refused)
+            assert "too many bucket sets" in str(e) or "window too narrow" in str(e)
+            continue
+        assert s1 == exp1 and s2 == exp2, (q_log, specials)
+        ran += 1
+    assert ran >= 1
+
+
 def test_msm_bucket_classes_errors(device, zkey):
     import ultragroth_amd as ug
     v = device.dvec(10, b"".join(O.to_le(i + 1) for i in range(10)))

@@ -198,7 +198,7 @@ struct MsmPending {
     BucketClasses cls;           // cls.on(): the block holds [S1 per set | S0 per set | specials per window] (MsmGeometry::result_points)
     u32* host = nullptr;
 };
-constexpr size_t MSM_PENDING_WORDS = 64 * 72;       // room for the largest result block (<= 63 G2 points); the LAST word
+constexpr size_t MSM_PENDING_WORDS = 128 * 72;      // room for the largest result block (<= 127 G2 points); the LAST word
                                                     // receives the schedule's failure flag (meta[7])
 MsmPending msm_enqueue_g1(const MsmSchedule& s, MsmWorkspace& ws, const u32* bases, u64 n_bases, int64_t delta, hipStream_t stream,
                           MsmStats* stats, u32* pinned_host);
