@@ -45,7 +45,7 @@
  *   test hooks         ULTRAGROTH_TEST_HOOKS=1 enables ug_test_set_blinding / ULTRAGROTH_TEST_BLINDING and ug_test_inject_fault;
  *                      without it those calls fail and the variables are ignored
  *   measurement        NOT in this library: UG_SORT=cub (library sort, links hipcub), UG_GROUP_FOLD_LOG (gathers folded into
- *                      cache: WRONG sums), UG_SORT_IPT / _SPL / _LBW / _DROP, UG_NTT_BATCH, UG_MATVEC_TILED exist only in the
+ *                      cache: WRONG sums), UG_NTT_FUSE_STEPS (WRONG results), UG_SORT_IPT / _SPL / _DROP, UG_NTT_BATCH, UG_MATVEC_TILED exist only in the
  *                      -DUG_MEASURE build (`make -C ultragroth_amd/csrc MEASURE=1 measure` -> libultragroth_hip_measure.so,
  *                      loaded with ULTRAGROTH_LIB=<path> by the Python mirror); tests/test_abi.py checks that the product
  *                      library holds none of these names and no hipcub symbol.
