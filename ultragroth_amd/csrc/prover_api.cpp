@@ -1766,8 +1766,9 @@ public:
         ZkeyHeader h = loadZkeyHeader(f, false);
         if (!h.rIsBn254) throw std::invalid_argument("zkey curve not supported");
         nPublic_ = h.nPublic; domain_ = h.domainSize;
-        // the layout: bucket classes when the tables of a group's range fit the devices (asked from the first one), else -- or when
-        // a rank then fails to build its tables after all -- base-point ranges
+        // the layout (shardLayouts): base-point ranges, unless ULTRAGROTH_SHARD asks for bucket classes (PxB, or auto: when the
+        // tables of a group's range fit the devices, asked from the first one); if a class rank then cannot build its tables after
+        // all, everything is created once more with base-point ranges
         const bool oneShot = g_oneShotProver;          // (thread-local: handed to the creating threads by value)
         uint64_t freeB = 0, totalB = 0;
         { ug_ctx* probe = nullptr; ugCheck(ug_ctx_create(&probe, devices[0])); ug_ctx_mem_info(probe, &freeB, &totalB); ug_ctx_destroy(probe); }

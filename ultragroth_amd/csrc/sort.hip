@@ -107,22 +107,25 @@ __device__ __forceinline__ void recode_scalar(const u32* scalars, u64 i, const D
     u32 carry = 0;
     const int c = CW ? CW : d.c;
     const u32 half = 1u << (c - 1), full = 1u << c, mask = full - 1;
-#pragma unroll
-    for (int w = 0; w < (CW ? (255 + CW - 1) / CW : 1); w++) {       // (compile-time trip count when CW != 0 ...)
-      for (int wr = w; wr < (CW ? w + 1 : windows); wr++) {           // (... else the runtime loop, entered once)
-        const int bit = wr * c, word = bit >> 5, sh = bit & 31;
+    auto window = [&](int w) {
+        const int bit = w * c, word = bit >> 5, sh = bit & 31;
         const u64 two = (u64)s[word] | ((u64)s[word + 1] << 32);
         const u32 raw = ((u32)(two >> sh) & mask) + carry;
-        const u32 tag = d.tables ? (u32)wr << TABLE_INDEX_BITS : 0u;
+        const u32 tag = d.tables ? (u32)w << TABLE_INDEX_BITS : 0u;
         u32 key, val;
         if (raw > half) {                             // negative digit raw - 2^c, carry into the next window
             const u32 mag = full - raw;               // 0 when the window was all ones and a carry came in
             carry = 1;
-            key = mag ? digit_key(d, wr, mag, i) : d.sentinel;
+            key = mag ? digit_key(d, w, mag, i) : d.sentinel;
             val = (u32)i | tag | 0x80000000u;
-        } else { carry = 0; key = raw ? digit_key(d, wr, raw, i) : d.sentinel; val = (u32)i | tag; }
-        f(wr, key, val);
-      }
+        } else { carry = 0; key = raw ? digit_key(d, w, raw, i) : d.sentinel; val = (u32)i | tag; }
+        f(w, key, val);
+    };
+    if constexpr (CW != 0) {
+#pragma unroll
+        for (int w = 0; w < (255 + CW - 1) / CW; w++) window(w);
+    } else {
+        for (int w = 0; w < windows; w++) window(w);
     }
 }
 
