@@ -172,6 +172,13 @@ def witness_slice(info, rank, world):
     return ug.ShardedGroth16Prover.balanced_witness_range(info["nVars"], rank, world)
 
 
+def padded_h_slices(h_ranges):
+    """How the evaluation vectors travel when the ranks' h ranges differ in length (a bucket-class layout gives its chain ranks
+    none): a scatter sends equal pieces, so every rank gets the LONGEST range's length from its own first element on, and the
+    vectors carry that much padding behind their end. Returns (first element per rank, piece length)."""
+    return [h[0] for h in h_ranges], max(max(h[1] - h[0] for h in h_ranges), 1)
+
+
 def bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_rank):
     """UltraGroth (BASELINE.json configs[4]). N = 1: the whole ultra_groth_prover_prove call (witness upload, round
     commitment MSM, Keccak challenge, lookup completion, final-round MSMs + H polynomial, blinding, JSON).
@@ -491,8 +498,7 @@ def main():
         # every rank's slice of h (the layouts' h ranges: even in the base-point form; in a bucket-class layout of five ranks or
         # more the chain ranks take none). A scatter sends equal pieces: the longest range's length, from each rank's first
         # element on (the vectors carry that much padding behind their end)
-        h_first = [L.h[0] for L in layouts]
-        sl = max(max(L.h[1] - L.h[0] for L in layouts), 1)
+        h_first, sl = padded_h_slices([L.h for L in layouts])
         ev_dev = "cuda"
         fulls = {k: torch.empty((n_dom + sl, 32), dtype=torch.uint8, device=ev_dev) for k in layout.chains}
         bufs = torch.empty((3, sl, 32), dtype=torch.uint8, device=ev_dev)

@@ -115,6 +115,51 @@ def test_round_commitment_exchange(zkey):
     assert total == O.g1_msm(pts[:64 * 64], sc, 64)
 
 
+def _scatter_worker(rank, world, port, q):
+    """bench.py's exchange of the evaluation slices when the ranks' h ranges are UNEVEN (the chain ranks of a bucket-class layout
+    hold none): equal padded pieces from every rank's first element on (bench.padded_h_slices), three roots"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    import ultragroth_amd as ug
+    n_dom = 1 << 10
+    lays = [ug.ShardedGroth16Prover.shard_layout(n_dom - 1, 1, n_dom, r, world, 1) for r in range(world)]
+    h_first, sl = bench.padded_h_slices([L.h for L in lays])
+    ok = True
+    for k in range(3):
+        src = k % world
+        full = None
+        if rank == src:                                  # the chain's vector, padded behind its end
+            full = (torch.arange((n_dom + sl) * 32, dtype=torch.int64) * (k + 3) % 251).to(torch.uint8).reshape(n_dom + sl, 32)
+        out = torch.empty((sl, 32), dtype=torch.uint8)
+        dist.scatter(out, [full[h_first[r]:h_first[r] + sl].contiguous() for r in range(world)] if rank == src else None, src=src)
+        h0, h1 = lays[rank].h
+        exp = (torch.arange((n_dom + sl) * 32, dtype=torch.int64) * (k + 3) % 251).to(torch.uint8).reshape(n_dom + sl, 32)[h0:h1]
+        ok = ok and bool((out[:h1 - h0] == exp).all())
+    q.put((rank, ok, lays[rank].h))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_uneven_h_slices_travel_padded():
+    world = 5                                            # five ranks: the three chain ranks of a class layout take no part of h
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_scatter_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in got)
+    hs = [h for _, _, h in got]
+    assert hs[0] == (0, 0) and hs[2] == (0, 0) and hs[3][0] == 0 and hs[4][1] == 1 << 10 and hs[3][1] == hs[4][0]
+
+
 def test_bench_witness_slices_tile_the_witness():
     """bench.py gives the ranks that also run an NTT chain smaller witness slices: for every world size the slices are
     contiguous, ordered, cover [0, nVars) exactly, and the chain-carrying ranks get the smaller ones"""
