@@ -278,6 +278,18 @@ def test_msm_bucket_classes_errors(device, zkey):
     assert device.msm(b, device.schedule(v, 0, 10, table_c=16, classes=(0, 0, 0, 0, 0, 0))) == O.g1_msm(pts, b"".join(O.to_le(i + 1) for i in range(10)), 10)
 
 
+def test_schedule_refuses_more_than_2_30_entries(device):
+    """a look-back status word of the radix partition carries a 30-bit pair count (one bin may hold every pair: equal scalars), so a
+    schedule of more than 2^30 (scalar, window) entries is refused before any kernel runs -- the provers stay below it (ranges of
+    at most 2^26 scalars x 16 windows; larger ranges are proved in pieces)"""
+    import ultragroth_amd as ug
+    n = (1 << 30) // 12 + 4096                          # 12 windows of 22 bits: just above the limit
+    v = device.dvec(n)                                  # (2.9 GB of device memory, never read)
+    with pytest.raises(ug.DeviceError, match="exceeds 2\\^30 entries"):
+        device.schedule(v, 0, n, table_c=22)
+    device.schedule(v, 0, 1 << 10, table_c=22)          # the same vector, a legal range: fine
+
+
 def test_msm_window_tables_errors(device, zkey):
     pts = _sec(zkey, "zkey", 5)[:64 * 10]
     sc = b"".join(O.to_le(i + 1) for i in range(10))
