@@ -3,7 +3,7 @@
 # 128-byte runs): ultragroth_amd/csrc/build/variants/libug_sort512.so (sort.hip built with -DUG_SORT_THREADS=512 and linked with
 # the other objects of build/) against the product library, under rocprofv3 kernel statistics on ONE box; --check first.
 cd $GRAFT_REPO_ROOT
-V=$GRAFT_REPO_ROOT/ultragroth_amd/csrc/build/variants/libug_sort512.so
+V=$GRAFT_REPO_ROOT/ultragroth_amd/csrc/build/variants/libug_${CHECK_VARIANT:-sort512}.so
 ULTRAGROTH_LIB=$V python bench.py --log-domain 20 --steps 1 --warmup 1 --no-cpu-baseline --check > gpurun_out/s512_check.json 2> gpurun_out/s512_check.err; echo "variant --check 2^20 U rc=$?"
 ULTRAGROTH_LIB=$V python bench.py --log-domain 20 --mix C --steps 1 --warmup 1 --no-cpu-baseline --check > gpurun_out/s512_checkc.json 2> gpurun_out/s512_checkc.err; echo "variant --check 2^20 C rc=$?"
 cd /tmp && export TMPDIR=/tmp
