@@ -20,6 +20,7 @@
 // Keys are sorted on the low `bits` bits only (enough to tell the sentinel, = number of buckets, from every bucket id), in
 // ceil(bits / 8) passes of nearly equal width. Pairs that exist only to fill the last tile carry the key 0xffffffff: they sort
 // behind everything and land beyond the `total` positions any consumer reads.
+#include <atomic>
 #include <cstdlib>
 #include "dev_common.hpp"
 #include "internal.hpp"
@@ -469,16 +470,18 @@ int RadixSorter::sort(const u32* scalars, const MsmGeometry& geo, u32 sentinel, 
         const unsigned grid = (unsigned)std::min<u64>(tiles, SORT_MAX_GRID);
         // the fused first pass with the window width as a compile-time constant where the provers' sizes use it
         const int cw = first_fused ? (plan.c == 22 || plan.c == 20 ? plan.c : 0) : 0;
-        if (lds > 64 * 1024) {                                 // (tiles of more than 64 KiB of LDS)
-            static const bool once = [] {
+        if (lds > 64 * 1024) {                                 // (tiles of more than 64 KiB of LDS: the attribute is per device)
+            static std::atomic<bool> allowed[64];
+            int dev = 0;
+            UG_HIP(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 64 || !allowed[dev].load(std::memory_order_acquire)) {
                 const int cap = 160 * 1024;
                 UG_HIP(hipFuncSetAttribute((const void*)radix_pass_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
                 UG_HIP(hipFuncSetAttribute((const void*)radix_pass_kernel<true, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
                 UG_HIP(hipFuncSetAttribute((const void*)radix_pass_kernel<true, 22>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
                 UG_HIP(hipFuncSetAttribute((const void*)radix_pass_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-                return true;
-            }();
-            (void)once;
+                if (dev >= 0 && dev < 64) allowed[dev].store(true, std::memory_order_release);
+            }
         }
         if (!first_fused) hipLaunchKernelGGL((radix_pass_kernel<false, 0>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
         else if (cw == 22) hipLaunchKernelGGL((radix_pass_kernel<true, 22>), dim3(grid), dim3(SORT_THREADS), lds, stream, a);
