@@ -673,8 +673,18 @@ int ug_dvec_copy(ug_dvec* dst, uint64_t dst_first, const ug_dvec* src, uint64_t 
     const size_t bytes = (size_t)count * 32;
     if (src->ctx->device == c->device)
         UG_HIP(hipMemcpyAsync(dst->data + dst_first * 8, src->data + src_first * 8, bytes, hipMemcpyDeviceToDevice, c->stream));
-    else
+    else {
+        // two devices of the node: direct access over xGMI is switched on once per ordered pair (the copy works without it, staged
+        // by the runtime; "already enabled" and "not supported" are not errors here)
+        static std::atomic<bool> tried[64][64];
+        const int a = c->device, b = src->ctx->device;
+        if (a >= 0 && a < 64 && b >= 0 && b < 64 && !tried[a][b].exchange(true)) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(b, 0);      // (current device is a: c->use())
+            (void)hipGetLastError();
+        }
         UG_HIP(hipMemcpyPeerAsync(dst->data + dst_first * 8, c->device, src->data + src_first * 8, src->ctx->device, bytes, c->stream));
+    }
     UG_HIP(hipStreamSynchronize(c->stream));
     UG_CATCH
 }
