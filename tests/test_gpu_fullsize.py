@@ -156,6 +156,81 @@ def test_reference_api_on_eight_ranks_at_configs2_size(full_zkey, monkeypatch):
             assert got == exp, mix
 
 
+def test_eight_bucket_class_ranks_at_configs2_size(device, full_zkey):
+    """The bucket-class layout (ULTRAGROTH_SHARD=1x8, DESIGN.md section 7: every rank the WHOLE window tables and its residues of the
+    bucket ids; an option, not the library's choice) rehearsed at the full 2^24 size, eight ranks one after the other on the one
+    device (each holds 60 GiB of tables), circom-like scalars -- the million-entry bucket of the ones is split by scalar range over
+    the eight ranks: every rank from its slices only, chain ranks 0-2 run their chain and take no part of h, ranks 3-7 a fifth of
+    the H product each; the 384-byte blocks add up to the expected proof, byte for byte."""
+    import ctypes as C
+    import torch
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, info = full_zkey
+    world, n_dom, nv = 8, info["domainSize"], info["nVars"]
+    wtns = synth.build_witness(FULL_LOG, "C")
+    exp = _expected(zkey, wtns, FULL_LOG, "C")
+    view = memoryview(zkey).cast("B")
+
+    def sec(sid, skip=0):
+        off, sz = O.section(zkey, "zkey", sid)
+        return off + skip, sz - skip
+    header = bytes(view[sec(2)[0]:sec(2)[0] + sec(2)[1]])
+    c_off, c_sz = sec(4, 4)
+    coefs = (C.c_char * c_sz).from_buffer(view[c_off:c_off + c_sz])
+
+    def part(sid, rec, lo, hi):
+        off, _ = sec(sid)
+        n = (hi - lo) * rec
+        return (C.c_char * n).from_buffer(view[off + lo * rec:off + lo * rec + n]) if n else (C.c_char * 0)()
+
+    lays = [ug.ShardedGroth16Prover.shard_layout(nv, info["nPublic"], n_dom, k, world, 1) for k in range(world)]
+    assert all(L.witness == (0, nv) and L.q_log == 7 for L in lays) and [L.chains for L in lays[:4]] == [[0], [1], [2], []]
+    full = torch.empty((3, n_dom, 32), dtype=torch.uint8, device="cuda")
+    total, first_rank = None, None
+    r, s = fixed_rs()
+    try:
+        for k, L in enumerate(lays):
+            (w0, w1), (c0, c1), (h0, h1) = L.ranges
+            slices = (part(5, 64, w0, w1), part(6, 64, w0, w1), part(7, 128, w0, w1), part(8, 64, c0, c1), part(9, 64, h0, h1))
+            _progress("2^%d classes x8: rank %d (%d residues, h %d..%d)" % (FULL_LOG, k, L.residues, h0, h1))
+            p = ug.ShardedGroth16Prover.from_slices(header, coefs if L.chains else None, info["nCoefs"], slices, 0, k, world,
+                                                    public_size=82 * info["nPublic"] + 4, layout=L)
+            try:
+                p.load_witness_part(wtns, 0)
+                if L.chains:
+                    p.load_witness_part(wtns, 1)
+                    for c in L.chains:
+                        p.hpoly_chain(c, full[c].data_ptr())
+                if k == 0:
+                    ug.set_test_blinding(r + s)             # rank 0 draws r and s when its products are queued
+                try:
+                    p.witness_msm_begin()
+                finally:
+                    ug.set_test_blinding(b"")
+                assert p.h_range() == (h0, h1 - h0, n_dom)
+                bufs = [full[c, h0:max(h1, h0 + 1)] for c in range(3)]
+                torch.cuda.current_stream().synchronize()
+                p.hpoly_combine(*(b.data_ptr() for b in bufs))
+                hblk = p.run_h_msm()
+                blk = p.witness_msm_end()[:320] + hblk[320:384]
+            except BaseException:
+                p.close()
+                raise
+            total = blk if total is None else ug.ShardedGroth16Prover.add_partials(total, blk)
+            if k == 0:
+                first_rank = p                             # (it finishes at the end -- it holds the blinding; one more rank fits beside it)
+            else:
+                p.close()
+        got = first_rank.finish(total)
+    finally:
+        if first_rank is not None:
+            first_rank.close()
+        del coefs, view
+    assert got == exp
+    _progress("2^%d classes x8: done" % FULL_LOG)
+
+
 @pytest.fixture(scope="module")
 def huge(device):
     """BASELINE.json configs[3]'s circuit (2^HUGE_LOG constraints) with its expected proof, made once for the single-GPU
