@@ -278,6 +278,51 @@ def test_shard_layouts_tile_everything(monkeypatch):
             assert rs[0][part][0] == 0 and rs[-1][part][1] == end and all(a[part][1] == b[part][0] for a, b in zip(rs, rs[1:]))
 
 
+def test_sliced_creation_checks_its_buffers_before_any_device_work(lib):
+    """ug_groth16_prover_create_sharded_slices / _layout and ug_ultra_groth_prover_create_sharded_slices refuse a slice that is shorter
+    than the rank's range (or missing) with the reason -- host checks that come before the first HIP call, so they hold without a
+    GPU; with buffers of the right size the call gets as far as the device (and fails there on a box without one)"""
+    import struct
+    from ultragroth_amd import synth
+    r_le, q_le = synth.R_MOD.to_bytes(32, "little"), synth.Q_MOD.to_bytes(32, "little")
+    n_vars, dom = 1000, 1024
+    hdr = struct.pack("<I", 32) + q_le + struct.pack("<I", 32) + r_le + struct.pack("<III", n_vars, 1, dom) + bytes(64 + 64 + 128 + 128 + 64 + 128)
+    S = ug.ShardedGroth16Prover
+    (w0, w1), (c0, c1), (h0, h1) = S.shard_ranges(n_vars, 1, dom, 1, 4)
+    good = [bytes((w1 - w0) * 64), bytes((w1 - w0) * 64), bytes((w1 - w0) * 128), bytes((c1 - c0) * 64), bytes((h1 - h0) * 64)]
+    for k, name in enumerate(("points_a", "points_b1", "points_b2", "points_c", "points_h")):
+        short = list(good)
+        short[k] = short[k][:-1]
+        with pytest.raises(ug.ProverError, match=name + " slice is shorter"):
+            S.from_slices(hdr, None, 0, short, 0, 1, 4, public_size=86)
+    lay = S.shard_layout(n_vars, 1, dom, 1, 4)
+    with pytest.raises(ug.ProverError, match="points_h slice is shorter"):
+        S.from_slices(hdr, None, 0, good[:4] + [b""], 0, 1, 4, public_size=86, layout=lay)
+    bad = ug.ShardLayout(lay.raw[:6] + [9, 0, 1] + lay.raw[9:])
+    with pytest.raises(ug.ProverError, match="invalid bucket classes"):
+        S.from_slices(hdr, None, 0, good, 0, 1, 4, public_size=86, layout=bad)
+    if ug.device_count() < 1:
+        with pytest.raises(ug.ProverError, match="HIP"):
+            S.from_slices(hdr, None, 0, good, 0, 1, 4, public_size=86)
+    # UltraGroth: eight buffers
+    n1, n2 = 249, 748
+    uh = struct.pack("<I", 32) + q_le + struct.pack("<I", 32) + r_le + struct.pack("<IIIIII", n_vars, 2, dom, n1, n2, 2) + bytes(64 + 64 + 128 + 128 + 64 + 128 + 64 + 128)
+    U = ug.ShardedUltraGrothProver
+    (w0, w1), (a0, a1), (f0, f1), (h0, h1) = U.shard_ranges(n_vars, dom, n1, n2, 2, 3)
+    ugood = [bytes((w1 - w0) * 64), bytes((w1 - w0) * 64), bytes((w1 - w0) * 128), bytes((a1 - a0) * 64), bytes((f1 - f0) * 64), bytes((h1 - h0) * 64),
+             bytes((a1 - a0) * 4), bytes((f1 - f0) * 4)]
+    for k, name in enumerate(("points_a", "points_b1", "points_b2", "points_round_c", "points_final_c", "points_h", "round_indexes", "final_round_indexes")):
+        short = list(ugood)
+        short[k] = short[k][:-1]
+        with pytest.raises(ug.ProverError, match=name + " slice is shorter"):
+            U.from_slices(uh, None, 0, short, 0, 2, 3, public_size=86)
+    with pytest.raises(ug.ProverError, match="Invalid section size"):
+        U.from_slices(uh[:40], None, 0, ugood, 0, 2, 3, public_size=86)
+    if ug.device_count() < 1:
+        with pytest.raises(ug.ProverError, match="HIP"):
+            U.from_slices(uh, None, 0, ugood, 0, 2, 3, public_size=86)
+
+
 @pytest.mark.parametrize("order", ["library_first", "torch_first"])
 def test_one_hip_runtime_whatever_the_import_order(order):
     """torch bundles a HIP runtime of its own: the loader must leave ONE copy in the process whichever is imported first
