@@ -9,7 +9,7 @@ python3 - <<'PY'
 import csv,glob,json
 f=glob.glob('gpurun_out/prof_c/*/*kernel_stats.csv')[0]
 rows=list(csv.DictReader(open(f)))
-for r in rows[:26]:
+for r in rows[:40]:
     print("%-62s calls=%4s total_ms=%9.3f avg_us=%9.1f" % (r['Name'].replace('ug::(anonymous namespace)::','').replace('void ','')[:62], r['Calls'], float(r['TotalDurationNs'])/1e6, float(r['AverageNs'])/1e3))
 d=json.load(open('gpurun_out/prof_c.json'))
 print(d['ms_per_step'], d['msm_ms_per_proof'], d['fft_ms_per_proof'])
