@@ -20,3 +20,6 @@ for N in 2 3; do
 timeout -k 10 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus $N --steps 2 --warmup 1 --log-domain 14 --ultra --check > gpurun_out/multiu$N.json 2> gpurun_out/multiu$N.err; echo "ultra N=$N rc=$?"; grep -v "socket.cpp\|Gloo\|amdgpu.ids" gpurun_out/multiu$N.err | tail -5 | cut -c1-300; python -c "
 import json; d=json.loads(open('gpurun_out/multiu$N.json').read().strip().splitlines()[-1]); print(d['n_gpus'], d['ms_per_step'], d['config']['parallelism'], d['config']['workload'][-20:])"
 done
+# the driver's line at its own size: four ranks at 2^24 on the one device (32 s wall; the time per step means nothing here)
+( time timeout -k 10 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29661 bench.py --gpus 4 --steps 3 --warmup 1 --check ) > gpurun_out/multi4_full.json 2> gpurun_out/multi4_full.err; echo "2^24 N=4 rc=$?"; python -c "
+import json; d=json.loads(open('gpurun_out/multi4_full.json').read().strip().splitlines()[-1]); print(d['n_gpus'], d['config']['parallelism'], d.get('check'), 'create', d['create_s'])"
