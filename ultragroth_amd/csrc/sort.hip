@@ -17,8 +17,9 @@
 //                         fence). The FIRST pass reads the scalars and makes its pairs on the fly -- the pair arrays are
 //                         never written in unsorted form (1.6 GB written and read again per 2^24-scalar schedule before).
 //
-// Keys are sorted on the low `bits` bits only (enough to tell the sentinel, = number of buckets, from every bucket id), in
-// ceil(bits / 8) passes of nearly equal width. Pairs that exist only to fill the last tile carry the key 0xffffffff: they sort
+// Keys are sorted on the low `bits` bits only (enough to tell the sentinel, = number of buckets, from every bucket id -- or, when
+// the first pass drops the sentinel pairs, just the bucket ids: one bit less, 7 | 7 | 7 for 2^21 buckets), in ceil(bits / 8) passes
+// of nearly equal width. A pass is launched as at most SORT_MAX_GRID workgroups that take tiles until none is left. Pairs that exist only to fill the last tile carry the key 0xffffffff: they sort
 // behind everything and land beyond the `total` positions any consumer reads.
 #include <atomic>
 #include <cstdlib>
