@@ -691,12 +691,23 @@ def main():
         ug.set_test_blinding(b"")
 
     # --replicas: the node used the other way round -- N independent provers, each proving whole proofs on its own GPU (what a
-    # batch of unrelated proofs wants: no exchange, linear by construction). An extra figure; a failure here costs the figure,
-    # not the line.
+    # batch of unrelated proofs wants: no exchange, linear by construction). An extra figure; a failure on any rank costs the
+    # figure, not the line (the failure is made collective, below).
     replicated = None
     if dist is not None and args.replicas:
+        # Every collective of this block sits OUTSIDE the per-rank try: a rank that fails (out of memory building the whole circuit,
+        # say) still takes part in the agreement below, so that no rank waits in a barrier for one that has left. The ranks agree on
+        # an ok flag (MIN) before the timed loop and after it; if any rank failed, all skip the rest and report the error.
+        flag_dev = "cuda" if backend == "nccl" else "cpu"
+
+        def all_ok(mine):
+            f = torch.tensor([1 if mine else 0], dtype=torch.int32, device=flag_dev)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            return bool(f.item())
+
+        ms_sharded = 1e3 * elapsed / args.steps
+        own, err, dt_all = None, None, None
         try:
-            ms_sharded = 1e3 * elapsed / args.steps
             prover.close()
             os.environ["ULTRAGROTH_DEVICE"] = str(local_rank)       # (the reference's create call takes its device from here)
             full_zkey, full_wtns, _ = synth.build_circuit(dev, log_domain, mix=args.mix, g1_only=args.g1_only)
@@ -704,20 +715,33 @@ def main():
             del full_zkey
             own.load_witness(full_wtns)
             own.prove_resident()
+        except Exception as e:                          # noqa: BLE001 -- reported, not fatal
+            err = str(e)[:300]
+        if all_ok(err is None):
             barrier()
             t1 = time.perf_counter()
-            for _ in range(args.steps):
-                own.prove_resident()
+            try:
+                for _ in range(args.steps):
+                    own.prove_resident()
+            except Exception as e:                      # noqa: BLE001
+                err = str(e)[:300]
             barrier()
             dt = time.perf_counter() - t1
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            own.close()
-            replicated = {"proofs_per_s": world * args.steps / float(tt.item()), "ms_per_proof_per_rank": 1e3 * float(tt.item()) / args.steps,
+            if all_ok(err is None):
+                tt = torch.tensor([dt], dtype=torch.float64, device=flag_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt_all = float(tt.item())
+        if own is not None:
+            try:
+                own.close()
+            except Exception:                           # noqa: BLE001
+                pass
+        if dt_all is not None:
+            replicated = {"proofs_per_s": world * args.steps / dt_all, "ms_per_proof_per_rank": 1e3 * dt_all / args.steps,
                           "note": "every rank a whole prover of its own proving its own proofs (no exchange); against %.2f ms per proof "
                                   "for ONE proof sharded over the %d ranks" % (ms_sharded, world)}
-        except Exception as e:                          # noqa: BLE001 -- reported, not fatal
-            replicated = {"proofs_per_s": None, "error": str(e)[:300]}
+        else:
+            replicated = {"proofs_per_s": None, "error": err or "another rank failed"}
 
     # The process group ends HERE, before rank 0 assembles the line: what follows on rank 0 (the --check comparison, which
     # synthesises the whole circuit once more; at N = 1 the CPU baseline) is host work of tens of seconds, and the other ranks

@@ -271,6 +271,11 @@ def test_shard_layouts_tile_everything(monkeypatch):
     assert S.shard_layout((1 << 24) - 1, 1, 1 << 24, 0, 2).q_log == 0                          # fewer than four ranks: base-point form
     with pytest.raises(ug.ProverError):
         S.shard_layout(100, 1, 128, 4, 4)
+    monkeypatch.delenv("ULTRAGROTH_SHARD", raising=False)
+    with pytest.raises(ug.ProverError):                # a caller's point_ranges that does not divide the ranks is refused, not replaced
+        S.shard_layout((1 << 24) - 1, 1, 1 << 24, 0, 8, 3)
+    with pytest.raises(ug.ProverError):                # more class ranks per range than residues (Q is capped at 2^7)
+        S.shard_layout((1 << 24) - 1, 1, 1 << 24, 0, 256, 1)
     U = ug.ShardedUltraGrothProver
     for world in (1, 3, 8):
         rs = [U.shard_ranges(1000, 1024, 249, 748, k, world) for k in range(world)]

@@ -40,6 +40,11 @@ class ShortBufferException : public std::invalid_argument {
 public:
     explicit ShortBufferException(const std::string& m) : std::invalid_argument(m) {}
 };
+// a rank of a bucket-class layout could not get its window tables: the one failure a many-device create answers with another layout
+class TablesUnavailable : public std::runtime_error {
+public:
+    explicit TablesUnavailable(const std::string& m) : std::runtime_error(m) {}
+};
 class InvalidWitnessLengthException : public std::invalid_argument {
 public:
     explicit InvalidWitnessLengthException(const std::string& m) : std::invalid_argument(m) {}
@@ -719,7 +724,7 @@ private:
             // Bucket classes: this rank's witness schedule keeps its residues' entries only. They exist for the window-table form
             // (ONE bucket set per product, so that a class is a slice of it): without the tables every window would bring its own
             // sets of every owned residue, and the result blocks would not hold them.
-            if (!tableW_) throw std::runtime_error("a bucket-class layout needs the fixed-base window tables (device memory short, or ULTRAGROTH_TABLES=0)");
+            if (!tableW_) throw TablesUnavailable("a bucket-class layout needs the fixed-base window tables (device memory short, or ULTRAGROTH_TABLES=0)");
             if (layout_.sp.lo > layout_.sp.hi || layout_.sp.hi > M) throw std::invalid_argument("special-bucket range outside [0, nVars]");
             ugCheck(ug_schedule_set_classes(d_.sw, layout_.qLog, layout_.r0, layout_.cnt, SHARD_SPECIALS, layout_.sp.lo, layout_.sp.hi - layout_.sp.lo));
         }
@@ -1673,7 +1678,10 @@ uint64_t classTablesNeed(uint64_t n) {
 // 0 = 256 GiB), in as few groups as that allows.
 int pointRangeGroups(uint64_t M, int R, int wanted, uint64_t hbmBytes) {
     auto valid = [&](int P) { return P >= 1 && P <= R && R % P == 0; };
-    if (wanted && valid(wanted)) return wanted;
+    if (wanted) {                                   // a caller's own choice is taken or refused, never silently replaced
+        if (!valid(wanted)) throw std::invalid_argument("point_ranges " + std::to_string(wanted) + " does not divide shard_count " + std::to_string(R));
+        return wanted;
+    }
     const char* e = getenv("ULTRAGROTH_SHARD");
     if (!e || !*e) return R;
     int P = 0, B = 0;
@@ -1726,6 +1734,8 @@ std::vector<ShardLayout> shardLayouts(uint64_t M, uint64_t N, int R, int P) {
     }
     const int qLog = shardQLog(B);
     const uint32_t Q = 1u << qLog;
+    if ((uint32_t)B > Q)                            // (every rank of a group owns at least one residue; Q is capped at 2^7)
+        throw std::invalid_argument("bucket-class layout: " + std::to_string(B) + " ranks per point range, at most " + std::to_string(Q) + " residues");
     double before = 0;
     uint64_t wlo = 0;
     for (int p = 0; p < P; p++) {
@@ -1796,8 +1806,16 @@ public:
             for (auto& j : jobs) { try { j.get(); } catch (...) { if (!failure) failure = std::current_exception(); } }
             if (!failure) { layouts_ = lay; break; }
             ranks_.clear();
-            if (P == R) std::rethrow_exception(failure);
-            P = R;                                      // once more with base-point ranges
+            // once more with base-point ranges ONLY when a class rank could not get its window tables or its memory; a bad
+            // zkey, a HIP error or a failed device fails the same way again, seconds to minutes later: rethrown as it is
+            bool tablesOrMemory = false;
+            try { std::rethrow_exception(failure); }
+            catch (const TablesUnavailable&) { tablesOrMemory = true; }
+            catch (const std::bad_alloc&) { tablesOrMemory = true; }
+            catch (const std::exception& e) { tablesOrMemory = strstr(e.what(), "not enough device memory") || strstr(e.what(), "out of memory"); }
+            catch (...) {}
+            if (P == R || !tablesOrMemory) std::rethrow_exception(failure);
+            P = R;
         }
         // the evaluation vectors of the three chains (on the devices of ranks k mod R) and every rank's slices of them
         for (int c = 0; c < 3; c++) {

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(SortHistArgs a
     for (int i = threadIdx.x; i < 4 * SORT_MAX_BINS; i += SORT_THREADS) h[i] = 0;
     __syncthreads();
     // The sentinel key (a zero digit) is counted in a register and added once per lane: a circom-like witness is mostly zeros and
-    // ones, i.e. nearly every pair of it carries the sentinel, and 256 lanes adding to ONE LDS counter serialise (measured at
+    // ones, i.e. nearly every pair of it carries the sentinel, and a workgroup's lanes adding to ONE LDS counter serialise (measured at
     // 2^24, circom-like mix: 1.3 ms for the witness schedule's histogram against 0.32 ms for uniform scalars).
     u32 zeros = 0;
     auto count = [&](u32 key) {
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; w++) { const u32 cw = wcnt[w * SORT_MAX_BINS + tid]; wcnt[w * SORT_MAX_BINS + tid] = total; total += cw; }
     }
-    // exclusive scan of `total` over tid (256 lanes): wave scan by shuffles, wave totals through LDS
+    // exclusive scan of `total` over tid (the first `bins` <= 256 of the tile's 512 lanes hold a count): wave scan by shuffles, wave totals through LDS
     u32 incl = total;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const u32 up = __shfl_up(incl, off, 64); if (lane >= off) incl += up; }
@@ -370,7 +370,7 @@ void digit_pairs(const u32* scalars, const DigitPlan& plan, u32* keys, u32* vals
 }
 
 void RadixSorter::reserve(u64 n_pairs, int ipt_min) {
-    // (later passes move the pair count rounded up to the FIRST pass's tile, at most 256 * 16 - 1 pairs more, in tiles of their own)
+    // (later passes move the pair count rounded up to the FIRST pass's tile, at most SORT_THREADS * 16 - 1 = 8 191 pairs more, in tiles of their own)
     const u64 tiles = (n_pairs + (u64)SORT_THREADS * SORT_MAX_IPT) / ((u64)SORT_THREADS * (u64)(ipt_min < 1 ? 1 : ipt_min)) + 2;
     if (tiles > tiles_cap) {
         sort_alloc(lookback, (size_t)tiles * SORT_MAX_BINS * 4);
@@ -476,7 +476,12 @@ int RadixSorter::sort(const u32* scalars, const MsmGeometry& geo, u32 sentinel, 
             int dev = 0;
             UG_HIP(hipGetDevice(&dev));
             if (dev < 0 || dev >= 64 || !allowed[dev].load(std::memory_order_acquire)) {
-                const int cap = 160 * 1024;
+                // what the device really grants a workgroup (gfx950: 160 KiB); a tile that does not fit is refused with the reason
+                int cap = 0;
+                UG_HIP(hipDeviceGetAttribute(&cap, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+                if ((size_t)cap < lds)
+                    throw std::runtime_error("radix sort: a tile of " + std::to_string(SORT_THREADS) + " lanes x " + std::to_string(a.ipt) + " pairs needs " +
+                                             std::to_string((lds + 1023) / 1024) + " KiB of LDS per workgroup, the device grants " + std::to_string(cap / 1024) + " KiB");
                 UG_HIP(hipFuncSetAttribute((const void*)radix_pass_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
                 UG_HIP(hipFuncSetAttribute((const void*)radix_pass_kernel<true, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
                 UG_HIP(hipFuncSetAttribute((const void*)radix_pass_kernel<true, 22>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
