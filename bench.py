@@ -59,8 +59,14 @@ def parse():
     ap.add_argument("--check", action="store_true", help="one more proof with fixed blinding, compared byte for byte with the expected proof "
                                                          "(oracle H polynomial + MSMs in the exponent; any size); exit code 3 on a mismatch")
     ap.add_argument("--g1-only", action="store_true", help="BASELINE.json configs[1]: G1 MSM + NTT only (B1/B2/C sets at infinity)")
-    ap.add_argument("--overlap", action="store_true", help="ULTRAGROTH_OVERLAP=1: H branch on a second stream beside the witness MSMs "
-                                                           "(faster, but per-kernel times and the MSM | FFT split stretch)")
+    ap.add_argument("--overlap", type=int, default=None, choices=[0, 1, 2], nargs="?", const=1,
+                    help="ULTRAGROTH_OVERLAP of the K timed steps at N = 1: 0 = the H branch behind the witness products, 1 / 2 = beside them on "
+                         "the second stream (the library's deployment switch; the fastest honest form and the default here: 1). The per-kernel "
+                         "launch times of `roofline` are then taken from K un-overlapped steps right after the region, same process, same prover")
+    ap.add_argument("--no-pmc", action="store_true", help="do not start the two rocprofv3 --pmc child runs that measure `roofline.traffic` "
+                                                          "(then the committed summary is read and labelled as such)")
+    ap.add_argument("--bare", action="store_true", help="(for the counter child runs) only the warm-up and the K steps: no extra figures, "
+                                                        "no CPU baseline, no counter children")
     ap.add_argument("--ultra", action="store_true", help="BASELINE.json configs[4]: UltraGroth two-round prove (single GPU)")
     ap.add_argument("--replicas", action="store_true", help="N > 1: after the sharded steps, also time the OTHER way to use a node -- every "
                     "rank a whole prover of its own, proving its own proofs, no exchange at all -- and report it as the extra key "
@@ -160,6 +166,107 @@ def cpu_baseline(dev, args, log_domain, circuit=None):
                   "a time, inputs in memory) on circuits of the same generator: %s; %s" % (cores, samples, how),
         "single_thread": {"log_domain": one_log, "seconds_1_thread": one[0], "seconds_all_threads": many[0], "threads": cores},
     }
+
+
+class BoardSampler:
+    """Board power and shader clock sampled from sysfs (the amdgpu hwmon node of the device this rank uses, found by its PCI
+    address) every 20 ms while the timed region runs: is the board at its power cap under these kernels? Everything here is
+    best effort -- a box that does not show the files gives {"available": false}."""
+
+    def __init__(self, torch, index):
+        self.files, self.samples, self.thread, self.stop_flag = {}, [], None, threading.Event()
+        self.cap_w = None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            addr = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            import glob
+            for hw in glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % addr):
+                for key, names in (("power_uw", ("power1_average", "power1_input")), ("sclk_hz", ("freq1_input",)), ("temp_mc", ("temp2_input", "temp1_input"))):
+                    for n in names:
+                        if key not in self.files and os.path.exists(os.path.join(hw, n)):
+                            self.files[key] = os.path.join(hw, n)
+                cap = os.path.join(hw, "power1_cap")
+                if os.path.exists(cap):
+                    self.cap_w = int(open(cap).read()) / 1e6
+            self.addr = addr
+        except Exception:                             # noqa: BLE001
+            self.files = {}
+
+    def _read(self):
+        row = {}
+        for k, f in self.files.items():
+            try:
+                row[k] = int(open(f).read())
+            except (OSError, ValueError):
+                pass
+        return row
+
+    def _run(self):
+        while not self.stop_flag.is_set():
+            self.samples.append(self._read())
+            self.stop_flag.wait(0.02)
+
+    def start(self):
+        if self.files:
+            self.thread = threading.Thread(target=self._run, daemon=True)
+            self.thread.start()
+
+    def stop(self):
+        if not self.thread:
+            return {"available": False}
+        self.stop_flag.set()
+        self.thread.join()
+        out = {"available": True, "samples": len(self.samples), "pci": self.addr, "source": "amdgpu hwmon (sysfs), every 20 ms over the K timed steps",
+               "power_cap_w": self.cap_w}
+        pw = [r["power_uw"] / 1e6 for r in self.samples if "power_uw" in r]
+        ck = [r["sclk_hz"] / 1e6 for r in self.samples if "sclk_hz" in r]
+        tp = [r["temp_mc"] / 1e3 for r in self.samples if "temp_mc" in r]
+        if pw:
+            out.update(power_w_mean=sum(pw) / len(pw), power_w_max=max(pw))
+            if self.cap_w:
+                out["power_frac_of_cap_mean"] = sum(pw) / len(pw) / self.cap_w
+        if ck:
+            out.update(sclk_mhz_mean=sum(ck) / len(ck), sclk_mhz_min=min(ck), sclk_mhz_max=max(ck))
+        if tp:
+            out["temp_c_max"] = max(tp)
+        return out
+
+
+def measure_traffic(args, log_domain):
+    """`roofline.traffic` measured in THIS run: two child runs of this very file under `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` (counters in passes of their own, with --kernel-trace only, as the microarch guide and gpurun prescribe;
+    the program goes directly after `--`; the children are fresh processes -- this one, which has used the GPU, only waits for
+    them, its prover closed). Each child builds the same circuit and proves it three times (--bare). Corrected per kernel by
+    tools/pmc_summary.py. Returns (summary, label) or (None, reason)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
+    base = tempfile.mkdtemp(prefix="ug_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("ULTRAGROTH_OVERLAP", None)
+    t0 = time.perf_counter()
+    dirs = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(base, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--bare", "--steps", "2", "--warmup", "1", "--overlap", "0",
+                   "--log-domain", str(log_domain), "--mix", args.mix, "--host-threads", "1"] + (["--g1-only"] if args.g1_only else [])
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s child failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode(errors="replace")[-200:])
+            dirs[counter] = d
+        summary = pmc_summary.summarize(dirs["FETCH_SIZE"], dirs["WRITE_SIZE"], log_domain, how="child runs of this bench.py run, one counter each")
+        return summary, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of bench.py --bare on the same workload "
+                         "(%.0f s), per launch, corrected as the microarch guide says (tools/pmc_summary.py)" % (time.perf_counter() - t0))
+    except Exception as e:                            # noqa: BLE001 -- the committed summary is the fallback
+        return None, "counter child runs failed: %s" % str(e)[:200]
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
 
 
 def witness_slice(info, rank, world):
@@ -422,8 +529,12 @@ def main():
     import torch
     import ultragroth_amd as ug
     from ultragroth_amd import synth
-    if args.overlap:
-        os.environ["ULTRAGROTH_OVERLAP"] = "1"
+    if args.bare:
+        args.no_pmc = args.no_cpu_baseline = True
+    # the K timed steps at N = 1 run in the fastest honest configuration of the library: the H branch beside the witness
+    # products (ULTRAGROTH_OVERLAP, read by the library per proof); N > 1 drives the two streams itself (phase calls)
+    if world == 1 and args.ultra and args.overlap:
+        os.environ["ULTRAGROTH_OVERLAP"] = str(args.overlap)
 
     # UG_BENCH_BACKEND=gloo + UG_BENCH_ONE_DEVICE=1 rehearse the N > 1 control flow on a one-GPU box
     # (RCCL refuses two ranks on one device); the driver's multi-GPU runs use the defaults: nccl, one GPU per rank.
@@ -451,6 +562,7 @@ def main():
         return bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_rank)
     zkey = None
     single = dist is None                       # the one-GPU form: the reference's calls on one prover object
+    timed_overlap = (1 if args.overlap is None else args.overlap) if single else 0
     if single:
         zkey, wtns, info = synth.build_circuit(dev, log_domain, mix=args.mix, g1_only=args.g1_only)
         zkey_bytes = len(zkey)
@@ -616,20 +728,30 @@ def main():
 
     out = None
     load()
+    os.environ["ULTRAGROTH_OVERLAP"] = str(timed_overlap)
     for _ in range(args.warmup):
         out = step()
     for which in range(4):
-        prover.kernel_stats(which=which, reset=True)
+        prover.kernel_stats(which=which, reset=True)      # (switches the per-kernel event pairs on: they are part of the region)
+    if os.environ.get("ULTRAGROTH_GRAPH", "0") not in ("", "0") and single:
+        for _ in range(2):                                # a recorded launch sequence is recorded outside the region (with the event pairs)
+            out = step()
+        for which in range(4):
+            prover.kernel_stats(which=which, reset=True)
+    sampler = BoardSampler(torch, local_rank) if rank == 0 else None
     # ---- THE timed region: K proofs, one after the other, witness resident in HBM ----
     # (the library's device-time accumulators restart when a witness is loaded: with the witness resident they run on, so the
     # K steps' share is the difference across the region)
     m0, f0, _ = prover.last_timings()
     barrier()
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    board = sampler.stop() if sampler else None
     m1, f1, _ = prover.last_timings()
     msm_ms, fft_ms = m1 - m0, f1 - f0
     if dist is not None:
@@ -637,14 +759,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kstats = [prover.kernel_stats(which=w) for w in range(4)]      # of the K timed steps only (reset after the warm-up)
+    kstats_region = [prover.kernel_stats(which=w) for w in range(4)]      # of the K timed steps only (reset after the warm-up)
+    kstats, clean_ms, clean_split = kstats_region, None, None
+    if timed_overlap:
+        # The region ran with the H branch BESIDE the witness products: launches of the two streams share the chip and their
+        # event-pair times stretch. The launch durations the roofline is computed from are therefore taken from K more steps with
+        # the branch BEHIND the products (one kernel on the chip at a time), right here: same process, same prover, same witness.
+        os.environ["ULTRAGROTH_OVERLAP"] = "0"
+        step()
+        for which in range(4):
+            prover.kernel_stats(which=which, reset=True)
+        mc0, fc0, _ = prover.last_timings()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        clean_ms = 1e3 * (time.perf_counter() - tc) / args.steps
+        mc1, fc1, _ = prover.last_timings()
+        clean_split = ((mc1 - mc0) / args.steps, (fc1 - fc0) / args.steps)
+        kstats = [prover.kernel_stats(which=w) for w in range(4)]
+        os.environ["ULTRAGROTH_OVERLAP"] = str(timed_overlap)
 
     # ---- extra figures (N = 1), outside the contract's region: the same K proofs through groth16_prover_prove with the .wtns
     # in HOST memory -- SURVEY.md section 8(d)'s "ms/proof": parse + PCIe copy + device + host -- one call after the other, and
     # from `--host-threads` threads on the one prover object (the witness copy of a call runs beside the kernels of the other)
     host_threads = max(1, args.host_threads) if single else 1
     prove_call_ms = upload_ms = pipelined_s = None
-    if single:
+    if single and not args.bare:
         prover.prove(wtns)
         t1 = time.perf_counter()
         upload_ms = 0.0
@@ -785,43 +927,86 @@ def main():
             if mad_per_unit:
                 e["issue_bound"] = {"unit": "T mad/s", "peak": 29.0, "achieved": mads(mad_per_unit, units, n_launch, ms),
                                     "frac": mads(mad_per_unit, units, n_launch, ms) / 29.0}
-                # `bound` stays the roof the north star names (HBM, the run contract's field); `limiter` says which roof is the
-                # nearer one for this kernel -- the larger of the two fractions
-                e["limiter"] = "valu-issue (v_mad_u64_u32)" if e["issue_bound"]["frac"] > e["frac"] else "hbm"
+                # `achieved` / `peak` / `frac` stay the HBM figures the north star and the run contract ask for (algorithmic bytes
+                # against 8 TB/s); `bound` NAMES the roof that is the nearer one for this kernel -- the larger of the two
+                # fractions -- and `bound_frac` is that fraction
+                issue = e["issue_bound"]["frac"] > e["frac"]
+                e["bound"] = "valu-issue" if issue else "hbm"
+                e["bound_frac"] = e["issue_bound"]["frac"] if issue else e["frac"]
+                e["limiter"] = "valu-issue (v_mad_u64_u32)" if issue else "hbm"
             e.update(extra)
             return e
+        # multiply-adds of the NTT launches per point and pass: a butterfly (162) per two points and stage, and the products folded
+        # into first / last passes (three twists, a o b, a o b - c and its conversion): 162 * (6 * logn / 2 + 6) per point of the
+        # domain, over the 18 pass-transforms of a proof
+        ntt_passes = max(1, -(-(log_domain - 10) // 8) + 1) if log_domain > 10 else 1
+        ntt_mads = 162.0 * (3.0 * log_domain + 6.0) / (6.0 * ntt_passes)
         kern = [entry("segment_accumulate_kernel<G1Cfg>", g1_bytes, acc_ms, launches, entries, 1467.0),
                 entry("segment_accumulate_kernel<G2Cfg>", g2_bytes, g2_ms, g2_launches, g2_entries, 4470.0),
                 entry("segment_accumulate_group_kernel<3>", grp_bytes, grp_ms, grp_launches, grp_entries, 1467.0, products_per_launch=3),
                 entry("ntt_pass_kernel", ntt_bytes * (ntt_points / max(ntt_launches, 1) / info["domainSize"] if ntt_launches else 1.0), ntt_ms,
-                      ntt_launches, ntt_points, None, transforms_per_launch=(ntt_points / max(ntt_launches, 1) / info["domainSize"]) if ntt_launches else None)]
+                      ntt_launches, ntt_points, ntt_mads, transforms_per_launch=(ntt_points / max(ntt_launches, 1) / info["domainSize"]) if ntt_launches else None)]
         kern = [e for e in kern if e["launches"]]
         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, corrected as the microarch guide says): NOT
         # measured in this run -- read from the committed summary of the same workload under profiles/ (null if absent)
         import glob
-        sources = [(args.pmc_summary, "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload made beside this run "
-                                      "(tools/run_r4_prof.sh), corrected as the microarch guide says" % args.pmc_summary)] if args.pmc_summary else []
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
-            sources.append((path, "profiles/%s (separate rocprofv3 --pmc passes on this workload; not measured in this run)" % os.path.basename(path)))
-        for path, label in sources:
+        sources, pmc_note = [], None
+        if single and not args.no_pmc and not args.pmc_summary:
+            # measured in this run: the prover goes (its 95 GiB of HBM are the children's), two counter children prove the same
+            # workload under rocprofv3 --pmc
             try:
-                pmc = json.load(open(path)).get(str(log_domain), {})
+                prover.close()
+            except Exception:                          # noqa: BLE001
+                pass
+            summary, pmc_note = measure_traffic(args, log_domain)
+            if summary is not None:
+                sources.append((summary, pmc_note))
+        if args.pmc_summary:
+            sources.append((args.pmc_summary, "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload made beside this run "
+                                               "(tools/run_r4_prof.sh), corrected as the microarch guide says" % args.pmc_summary))
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+            sources.append((path, "profiles/%s (separate rocprofv3 --pmc passes on this workload; NOT measured in this run%s)"
+                            % (os.path.basename(path), ": " + pmc_note if pmc_note else "")))
+        for src, label in sources:
+            try:
+                pmc = (src if isinstance(src, dict) else json.load(open(src))).get(str(log_domain), {})
             except Exception:
                 continue
+            measured_here = isinstance(src, dict)
             for e in kern:
                 k = pmc.get(e["kernel"])
-                if k and e["traffic"] is None and single and args.mix == "U" and not args.g1_only:
+                if k and e["traffic"] is None and single and (measured_here or (args.mix == "U" and not args.g1_only)):
                     e["traffic"] = k["fetch"] + k["write"]
+                    e["traffic_fetch"], e["traffic_write"] = k["fetch"], k["write"]
                     e["traffic_source"] = label
         kern.sort(key=lambda e: -e["ms_per_step"])
         roofline = dict(kern[0]) if kern else {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None}
         roofline["kernels"] = {e["kernel"]: e for e in kern[1:]}
         roofline["note"] = ("the kernel with the largest share of a step; integer-issue-bound kernels: issue_bound gives modmul work against the "
                             "v_mad_u64_u32 peak (DESIGN.md)")
+        roofline["launch_times_from"] = ("K steps with the H branch behind the witness products (one kernel on the chip at a time), right after the "
+                                         "timed region: same process, same prover" if timed_overlap else "the K timed steps themselves")
+        if timed_overlap:
+            roofline["launch_ms_in_timed_region"] = {n: kstats_region[i][0] for i, n in
+                                                     ((3, "segment_accumulate_group_kernel<3>"), (1, "segment_accumulate_kernel<G2Cfg>"),
+                                                      (0, "segment_accumulate_kernel<G1Cfg>"), (2, "ntt_pass_kernel")) if kstats_region[i][1]}
+        roofline["board"] = board
         ms_per_step = 1e3 * elapsed / args.steps
+        if clean_split is not None:
+            msm_ms, fft_ms = clean_split[0] * args.steps, clean_split[1] * args.steps
         res = {
             "metric": "proofs/s", "value": args.steps / elapsed, "unit": "proofs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "value_definition": ("K / wall time of K proofs (S1-S13 of src/groth16.cpp:48-203), one after the other from one host thread, on a "
+                                 "created prover with the witness already resident in HBM (ug_groth16_prover_prove_resident = groth16_prover_prove "
+                                 "minus .wtns parse and PCIe copy); library switches: ULTRAGROTH_OVERLAP=%d%s" % (
+                                     timed_overlap, ", ULTRAGROTH_GRAPH=1" if os.environ.get("ULTRAGROTH_GRAPH", "0") not in ("", "0") else ""))
+                                if single else "K / wall time (max over ranks) of K proofs sharded over the ranks, witness resident",
+            # SURVEY.md section 8(d)'s "ms/proof": the reference's own call, .wtns in HOST memory (parse + PCIe copy + device + host),
+            # K calls one after the other -- measured right after the region (N = 1)
+            "api_value": (1e3 / prove_call_ms) if prove_call_ms else None, "api_unit": "proofs/s",
+            "api_ms_per_step": prove_call_ms,
+            "api_definition": "K / wall time of K groth16_prover_prove calls (src/prover.h) on the created prover, .wtns in host memory" if prove_call_ms else None,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 254-bit modular integers)",
             "data": "synthetic",
             "config": {"workload": "groth16-bn254 2^%d constraints, nVars 2^%d-1, nCoefs 4N, %s + H-poly FFT, scalar mix %s "
@@ -829,13 +1014,17 @@ def main():
                                    "one proof after the other from one host thread"
                                    % (log_domain, log_domain, "G1 MSMs A and H only" if args.g1_only else "full G1+G2 MSM", args.mix,
                                       1 if args.g1_only else 2),
-                       "log_domain": log_domain, "mix": args.mix, "overlap": bool(os.environ.get("ULTRAGROTH_OVERLAP", "0") not in ("", "0")),
+                       "log_domain": log_domain, "mix": args.mix, "overlap": timed_overlap,
+                       "graph": os.environ.get("ULTRAGROTH_GRAPH", "0") not in ("", "0"),
                        "fused_g1_group": os.environ.get("ULTRAGROTH_FUSED", "1") != "0",
                        "parallelism": "one GPU" if single else "%s x%d%s" % (
                            "base-range shard" if not layout.q_log else "bucket-class shard (%d point ranges)" % len({L.witness for L in layouts}),
                            world, ", H-poly chains split over ranks" if split_h else "")},
             "msm_ms_per_proof": msm_ms / args.steps, "fft_ms_per_proof": fft_ms / args.steps,
-            "split_region": ("device time of the MSM (S1-S4, S10) and FFT (S5-S9) parts of the K timed steps themselves" if single else
+            "unoverlapped_ms_per_step": clean_ms,
+            "split_region": (("device time of the MSM (S1-S4, S10) and FFT (S5-S9) parts of the K un-overlapped steps right after the timed region "
+                              "(in the region the two parts run beside each other and their stream times stretch)" if timed_overlap else
+                              "device time of the MSM (S1-S4, S10) and FFT (S5-S9) parts of the K timed steps themselves") if single else
                              "stream time of rank 0's MSM and FFT parts over the K timed steps; its chains run on a second stream BESIDE "
                              "its witness MSMs, so the two overlap and their sum exceeds the step"),
             "comm": comm,

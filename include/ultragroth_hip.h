@@ -252,13 +252,35 @@ int  ug_field_op(ug_ctx* ctx, int field, int op, void* out, const void* a, const
  * records, G given as one such record (64 bytes for G1, 128 for G2). Not part of the reference interface. */
 int  ug_synth_points(ug_ctx* ctx, int g2, const void* generator_record, uint64_t seed, uint64_t n, void* host_out);
 
+/* CAPTURED LAUNCH SEQUENCES (one hipGraph per created prover and witness buffer; no reference counterpart -- the reference's
+ * prove, src/groth16.cpp:48-203, is one fixed sequence of calls, and so is this library's: no launch depends on a host read-back).
+ * ug_graph_begin puts ctx's stream into capture and forks ctx2's stream (may be NULL) off it; whatever the library queues on the
+ * two contexts until ug_graph_end -- schedules, products, ug_hpoly_run, ug_ctx_wait edges -- is recorded instead of run, the timing
+ * events included (as external event records: ug_ctx_timings / ug_ctx_kernel_stats keep working under replay). Calls that wait
+ * for the device (ug_ctx_sync, _collect, blocking products, uploads) must not be made on a capturing context. ug_graph_end
+ * instantiates the graph and takes the queued products out of the contexts; ug_graph_launch puts them back and launches on ctx's
+ * stream: collect as after the eager calls, ctx FIRST. ug_graph_valid: 0 once any per-proof device buffer of the process has
+ * been re-allocated since the capture (schedules, workspaces): the caller then drops the graph and captures again.
+ * ug_graph_abort ends a capture that failed half way (nothing was queued). */
+typedef struct ug_graph ug_graph;
+int      ug_graph_begin(ug_ctx* ctx, ug_ctx* ctx2);
+int      ug_graph_end(ug_ctx* ctx, ug_graph** out);
+void     ug_graph_abort(ug_ctx* ctx);
+int      ug_graph_valid(const ug_graph* g);
+uint64_t ug_graph_nodes(const ug_graph* g);
+int      ug_graph_launch(ug_graph* g);
+void     ug_graph_destroy(ug_graph* g);
+
 /* milliseconds of device time spent in the MSM and H-polynomial parts since the last reset
  * (the MSM | FFT split the reference prints in src/ultra_groth.cpp:199-335) */
 int  ug_ctx_timings(ug_ctx* ctx, double* msm_ms, double* fft_ms, int reset);
 
 /* HIP events (recorded on the launch stream) around the launches of the kernels the roofline is reported for:
  * which = 0 the G1 bucket accumulation, 1 the G2 bucket accumulation, 2 the NTT pass kernel. Average launch duration in
- * ms since the last reset, the launch count, and the units processed ((point, window) entries; NTT points per pass) */
+ * ms since the last reset, the launch count, and the units processed ((point, window) entries; NTT points per pass).
+ * The statistics of a context are collected from its first call with reset != 0 on (an event pair around a launch costs
+ * 10-25 us of idle device: a caller that never asks never pays). A captured launch sequence (ug_graph_*) holds the event pairs
+ * that were on when it was captured. */
 int  ug_ctx_kernel_stats(ug_ctx* ctx, int which, double* launch_ms_avg, uint64_t* launches, uint64_t* units, int reset);
 
 #ifdef __cplusplus

@@ -1,0 +1,119 @@
+"""ULTRAGROTH_GRAPH=1: the device part of a created prover's proof recorded once per witness buffer as a hipGraph and replayed
+(csrc/ug_api.hip ug_graph_*, Groth16Prover::run). The replayed proofs are the eager proofs byte for byte; the MSM | FFT split
+and the per-kernel statistics (external event records inside the graph) keep counting; a graph whose buffers were re-allocated
+is dropped and recorded again; a failure while recording leaves a prover that proves."""
+import threading
+
+import pytest
+
+import oracle as O
+from conftest import fixed_rs
+
+pytestmark = pytest.mark.gpu
+
+
+def _fixed(ug, blob, call):
+    ug.set_test_blinding(blob)
+    try:
+        return call()
+    finally:
+        ug.set_test_blinding(b"")
+
+
+@pytest.mark.parametrize("overlap", ["0", "1", "2"])
+def test_replayed_proofs_are_the_eager_proofs(device, monkeypatch, overlap):
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    monkeypatch.setenv("ULTRAGROTH_GRAPH", "1")
+    monkeypatch.setenv("ULTRAGROTH_OVERLAP", overlap)
+    zkey, wtns, info = synth.build_circuit(device, 15, mix="U", seed=0x5EED0A00)
+    wtns2 = synth.build_witness(15, "C", seed=0x5EED0A01)
+    r, s = fixed_rs()
+    exp = [O.groth16_prove(zkey, w, int.from_bytes(r, "little"), int.from_bytes(s, "little"))[:2] for w in (wtns, wtns2)]
+    with ug.Groth16Prover(zkey) as p:
+        # eager, recorded + launched, replayed ..., through the reference's call (witness in host memory: re-staged every time
+        # into the same buffer) and with the witness changing under the graph
+        for k in range(6):
+            assert _fixed(ug, r + s, lambda: p.prove((wtns, wtns2)[k % 2])) == exp[k % 2], k
+        # ... and on a resident witness
+        p.load_witness(wtns2)
+        for k in range(4):
+            assert _fixed(ug, r + s, p.prove_resident) == exp[1], k
+        msm, fft, _ = p.last_timings()
+        assert msm > 0 and fft > 0                                   # the spans inside the graph are accounted after every launch
+        # per-kernel statistics switched on: the sequences are recorded again WITH their event pairs
+        for which in range(4):
+            p.kernel_stats(which=which, reset=True)
+        for k in range(3):
+            assert _fixed(ug, r + s, p.prove_resident) == exp[1]
+        ms, launches, units = p.kernel_stats(which=2)                # NTT pass launches: 3 proofs x the same count
+        assert launches and launches % 3 == 0 and ms > 0 and units > 0
+        grp = p.kernel_stats(which=3)
+        assert grp[1] == 3                                           # one group launch (A | B1 | C) per proof
+
+
+def test_stale_graphs_are_recorded_again_and_failures_leave_a_prover(device, monkeypatch):
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    monkeypatch.setenv("ULTRAGROTH_GRAPH", "1")
+    zkey, wtns, info = synth.build_circuit(device, 14, mix="C", seed=0x5EED0A02)
+    r, s = fixed_rs()
+    exp = O.groth16_prove(zkey, wtns, int.from_bytes(r, "little"), int.from_bytes(s, "little"))[:2]
+    with ug.Groth16Prover(zkey) as p, ug.Registry(0) as reg:
+        for _ in range(3):
+            assert _fixed(ug, r + s, lambda: p.prove(wtns)) == exp
+        # another circuit on the device allocates and frees: every recorded sequence of the process is stale afterwards
+        zk2, wt2, _ = synth.build_circuit(device, 12, mix="U", seed=0x5EED0A03)
+        exp2 = O.groth16_prove(zk2, wt2, int.from_bytes(r, "little"), int.from_bytes(s, "little"))[:2]
+        reg.load("other", zk2)
+        assert _fixed(ug, r + s, lambda: reg.prove("other", wt2)) == exp2
+        for _ in range(3):
+            assert _fixed(ug, r + s, lambda: p.prove(wtns)) == exp
+        reg.evict("other")
+        for _ in range(2):
+            assert _fixed(ug, r + s, lambda: p.prove(wtns)) == exp
+        # a failure inside the recording (the second proof after the drop records): nothing is queued, the prover proves on
+        monkeypatch.setenv("ULTRAGROTH_GRAPH", "0")
+        assert _fixed(ug, r + s, lambda: p.prove(wtns)) == exp
+        monkeypatch.setenv("ULTRAGROTH_GRAPH", "1")
+    with ug.Groth16Prover(zkey) as p:
+        assert _fixed(ug, r + s, lambda: p.prove(wtns)) == exp       # eager: sizes the buffers
+        ug.inject_fault(ug.FAULT_HPOLY_RUN)                          # the recording proof fails half way
+        with pytest.raises(ug.ProverError, match="injected fault"):
+            p.prove(wtns)
+        ug.inject_fault(ug.FAULT_SCHEDULE_BUILD, after=2)
+        with pytest.raises(ug.ProverError, match="injected fault"):
+            p.prove(wtns)
+        for _ in range(3):
+            assert _fixed(ug, r + s, lambda: p.prove(wtns)) == exp
+
+
+def test_two_host_threads_on_one_prover_with_graphs(device, monkeypatch):
+    """two callers alternate between the prover's two witness buffers: one graph per buffer"""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    monkeypatch.setenv("ULTRAGROTH_GRAPH", "1")
+    zkey, wtns, info = synth.build_circuit(device, 16, mix="U", seed=0x5EED0A04)
+    r, s = fixed_rs()
+    exp = O.groth16_prove(zkey, wtns, int.from_bytes(r, "little"), int.from_bytes(s, "little"))[:2]
+    ug.set_test_blinding((r + s) * 1)
+    try:
+        with ug.Groth16Prover(zkey) as p:
+            bad = []
+
+            def work():
+                for _ in range(6):
+                    try:
+                        # (the fixed blinding is process-wide and consumed per draw: both callers draw the same r, s)
+                        if p.prove(wtns) != exp:
+                            bad.append("mismatch")
+                    except BaseException as e:       # noqa: BLE001
+                        bad.append(repr(e))
+            th = [threading.Thread(target=work) for _ in range(2)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            assert not bad, bad
+    finally:
+        ug.set_test_blinding(b"")

@@ -423,7 +423,7 @@ def test_bench_driver_line_with_four_ranks_over_gloo():
     assert d["cpu_baseline"] is None and "N = 1" in d["cpu_baseline_note"]
     assert "base-range shard x4, H-poly chains split over ranks" in d["config"]["parallelism"] and "workload" in d["config"]
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["launches"] > 0 and 0 < rf["frac"] < 1
+    assert rf["bound"] in ("hbm", "valu-issue") and rf["launches"] > 0 and 0 < rf["frac"] < 1
     # the same launch with --check: the four ranks' proof is the single-device proof, byte for byte
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
                         "--master-port", "29634", os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1",
@@ -490,11 +490,22 @@ def test_bench_line_contract_one_gpu():
     assert "resident in HBM" in d["config"]["workload"] and d["comm"] is None
     assert d["prove_call_ms_per_step"] > d["ms_per_step"] * 0.5 and d["witness_upload_ms_per_proof"] > 0
     assert d["pipelined_proofs_per_s"] > 0 and d["pipelined_host_threads"] == 2
-    assert d["msm_ms_per_proof"] > 0 and d["fft_ms_per_proof"] > 0 and d["msm_ms_per_proof"] + d["fft_ms_per_proof"] < d["ms_per_step"] * 1.05
+    # the headline runs in the library's fastest honest configuration (H branch beside the witness products); the MSM | FFT split
+    # and the launch times of the roofline come from K un-overlapped steps right after the region
+    assert d["config"]["overlap"] == 1 and "ULTRAGROTH_OVERLAP=1" in d["value_definition"] and "resident" in d["value_definition"]
+    assert d["unoverlapped_ms_per_step"] > 0
+    assert d["msm_ms_per_proof"] > 0 and d["fft_ms_per_proof"] > 0 and d["msm_ms_per_proof"] + d["fft_ms_per_proof"] < d["unoverlapped_ms_per_step"] * 1.05
+    # SURVEY 8(d)'s ms/proof -- groth16_prover_prove with the .wtns in host memory -- is a first-class figure of the line
+    assert abs(d["api_value"] * d["api_ms_per_step"] - 1e3) < 1e-6 * 1e3 and d["api_ms_per_step"] == d["prove_call_ms_per_step"]
+    assert "groth16_prover_prove" in d["api_definition"]
     rf = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernels"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernels", "board", "launch_times_from"):
         assert key in rf, key
-    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches"] > 0
+    # achieved / peak / frac are the HBM figures (algorithmic bytes against 8 TB/s); `bound` names the nearer roof
+    assert rf["bound"] in ("hbm", "valu-issue") and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches"] > 0
+    assert rf["bound_frac"] == max(rf["frac"], rf["issue_bound"]["frac"])
+    # the counter traffic is measured by this very run (two rocprofv3 --pmc children), not read from a committed file
+    assert rf["traffic"] and rf["traffic"] > 0 and rf["traffic_source"].startswith("measured in this run"), rf["traffic_source"]
     assert all(rf["ms_per_step"] >= k["ms_per_step"] for k in rf["kernels"].values())        # the top entry is the dominant kernel
     assert rf["launches"] % 3 == 0                                                            # counted over the K timed steps only
     cb = d["cpu_baseline"]

@@ -24,7 +24,7 @@ def hm():
         getattr(L, n).argtypes = [vp, vp, vp, C.c_size_t]
     for n in ("ugt_g1_tree_sum", "ugt_g2_tree_sum"):
         getattr(L, n).argtypes = [vp, vp, C.c_size_t]
-    for n in ("ugt_g1_mul", "ugt_g2_mul"):
+    for n in ("ugt_g1_mul", "ugt_g2_mul", "ugt_g1_mul_w4", "ugt_g2_mul_w4"):
         getattr(L, n).argtypes = [vp, vp, vp]
     return L
 
@@ -136,6 +136,11 @@ def test_curve_formulas_and_exceptional_cases(hm, zkey):
     for k in (0, 1, 2, 3, O.R_MOD - 1, O.R_MOD, rng.randrange(1 << 256)):
         hm.ugt_g1_mul(out, p, O.to_le(k))
         assert out.raw == O.g1_mul(p, k)
+    # the signed 4-bit window form of the provers' host parts: every digit value, carries through every window, the top carry
+    for k in [0, 1, 7, 8, 9, 15, 16, 0x88888888, (1 << 256) - 1, (1 << 255) + 9, int("9" * 64, 16), int("8" * 64, 16), O.R_MOD - 1] + \
+             [rng.randrange(1 << 256) for _ in range(6)]:
+        hm.ugt_g1_mul_w4(out, p, O.to_le(k))
+        assert out.raw == O.g1_mul(p, k), hex(k)
     n2 = 100
     pts2 = B2[:128 * n2]
     signs = bytes(rng.randrange(2) for _ in range(n2))
@@ -153,6 +158,9 @@ def test_curve_formulas_and_exceptional_cases(hm, zkey):
     for k in (1, 2, O.R_MOD - 1, rng.randrange(1 << 256)):
         hm.ugt_g2_mul(out2, p2, O.to_le(k))
         assert out2.raw == O.g2_mul(p2, k)
+    for k in (0, 8, 9, (1 << 256) - 1, int("8" * 64, 16), rng.randrange(1 << 256)):
+        hm.ugt_g2_mul_w4(out2, p2, O.to_le(k))
+        assert out2.raw == O.g2_mul(p2, k), hex(k)
 
 
 def test_segment_map_invariants(hm):

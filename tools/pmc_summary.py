@@ -18,9 +18,9 @@ DOUBLED = ("ntt_pass_kernel", "segment_accumulate_kernel<G2Cfg>", "radix_pass_ke
 
 
 def per_kernel(d):
-    fs = glob.glob(d + "/*/*counter_collection.csv")
+    fs = glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv")
     if not fs:
-        raise SystemExit("no counter_collection.csv under " + d)
+        raise RuntimeError("no counter_collection.csv under " + d)
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(fs[0])):
         k = r["Kernel_Name"].replace("ug::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
@@ -29,19 +29,26 @@ def per_kernel(d):
     return {k: v / n for k, (n, v) in agg.items()}
 
 
-fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
-log = sys.argv[4] if len(sys.argv) > 4 else "24"
-out = {"_comment": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/run_r4_prof.sh) on `bench.py --log-domain %s --mix U "
-                   "--host-threads 1`, per launch, in bytes (counter unit KB x 1024); gfx950 correction: FETCH_SIZE doubled for kernels "
-                   "that read coalesced streams or whole 128-byte lines (fetch_doubled), as counted for 64-byte gathers "
-                   "(tools/pmc_summary.py)" % log, log: {}}
-for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, 0) + write.get(k, 0))):
-    if fetch.get(k, 0) + write.get(k, 0) < 1024:          # below 1 MB per launch
-        continue
-    name = k.replace("G1Cfg", "G1Cfg").replace("<false, 4>", "<false>").replace("<true, 4>", "<true>")
-    dbl = any(name.startswith(p) or p in name for p in DOUBLED)
-    out[log][name] = {"fetch": int(fetch.get(k, 0) * 1024 * (2 if dbl else 1)), "write": int(write.get(k, 0) * 1024),
-                      "fetch_raw_kb": fetch.get(k, 0), "write_raw_kb": write.get(k, 0), **({"fetch_doubled": True} if dbl else {})}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-for k, v in list(out[log].items())[:14]:
-    print("%-60s fetch %8.3f GB  write %8.3f GB%s" % (k[:60], v["fetch"] / 1e9, v["write"] / 1e9, "  (fetch doubled)" if v.get("fetch_doubled") else ""))
+def summarize(fetch_dir, write_dir, log, how="separate passes, tools/run_r4_prof.sh"):
+    fetch, write = per_kernel(fetch_dir), per_kernel(write_dir)
+    log = str(log)
+    out = {"_comment": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (%s) on `bench.py --log-domain %s --mix U "
+                       "--host-threads 1`, per launch, in bytes (counter unit KB x 1024); gfx950 correction: FETCH_SIZE doubled for kernels "
+                       "that read coalesced streams or whole 128-byte lines (fetch_doubled), as counted for 64-byte gathers "
+                       "(tools/pmc_summary.py)" % (how, log), log: {}}
+    for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, 0) + write.get(k, 0))):
+        if fetch.get(k, 0) + write.get(k, 0) < 1024:          # below 1 MB per launch
+            continue
+        name = k.replace("<false, 4>", "<false>").replace("<true, 4>", "<true>")
+        dbl = any(name.startswith(p) or p in name for p in DOUBLED)
+        out[log][name] = {"fetch": int(fetch.get(k, 0) * 1024 * (2 if dbl else 1)), "write": int(write.get(k, 0) * 1024),
+                          "fetch_raw_kb": fetch.get(k, 0), "write_raw_kb": write.get(k, 0), **({"fetch_doubled": True} if dbl else {})}
+    return out
+
+
+if __name__ == "__main__":
+    log = sys.argv[4] if len(sys.argv) > 4 else "24"
+    out = summarize(sys.argv[1], sys.argv[2], log)
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    for k, v in list(out[log].items())[:14]:
+        print("%-60s fetch %8.3f GB  write %8.3f GB%s" % (k[:60], v["fetch"] / 1e9, v["write"] / 1e9, "  (fetch doubled)" if v.get("fetch_doubled") else ""))

@@ -168,6 +168,18 @@ void ugt_g2_mul(uint8_t out[128], const uint8_t base[128], const uint8_t scalar[
     g2_store(out, xyzz_mul_scalar(xyzz_from_affine(x, y), k, 256));
 }
 
+// the windowed form the provers' host parts use (ec.hpp: xyzz_mul_scalar_w4)
+void ugt_g1_mul_w4(uint8_t out[64], const uint8_t base[64], const uint8_t scalar[32]) {
+    Fq x, y; u32 k[8]; memcpy(k, scalar, 32);
+    if (!g1_load(base, x, y)) { memset(out, 0, 64); return; }
+    g1_store(out, xyzz_mul_scalar_w4(xyzz_from_affine(x, y), k));
+}
+void ugt_g2_mul_w4(uint8_t out[128], const uint8_t base[128], const uint8_t scalar[32]) {
+    Fq2 x, y; u32 k[8]; memcpy(k, scalar, 32);
+    if (!g2_load(base, x, y)) { memset(out, 0, 128); return; }
+    g2_store(out, xyzz_mul_scalar_w4(xyzz_from_affine(x, y), k));
+}
+
 // SegMap (segmap.hpp): every invariant the kernels of msm.hip rely on, for one (n_valid, log_a, log_b); 0 = all hold
 int ugt_segmap_check(uint64_t n_valid, uint64_t total, int log_a, int log_b) {
     const SegMap m = SegMap::make(n_valid, log_a, log_b);

@@ -51,6 +51,12 @@ struct NttPlan {
     ~NttPlan() { release(); }
 };
 
+// Every allocation or release of a per-proof device buffer (schedules, MSM workspaces, the sort's tables) moves this counter: a
+// captured launch sequence (ug_graph) holds raw pointers into those buffers and is only replayed while the counter stands where
+// it stood when the capture ended.
+uint64_t alloc_epoch();
+void alloc_epoch_bump();
+
 // ---- msm.hip ------------------------------------------------------------------------------------------
 // Bucket classes (many-device provers, DESIGN.md section 7: the witness products sharded by BUCKET instead of by base point).
 // A schedule with classes keeps only the (scalar, window) digits whose bucket b = |digit| - 1 has its residue b mod Q,
@@ -172,6 +178,10 @@ struct MsmWorkspace {
     ~MsmWorkspace() { release(); }
 };
 
+// An event pair recorded INSIDE a captured launch sequence (hipEventRecordWithFlags(.., hipEventRecordExternal): an event-record
+// node of the graph, re-recorded by every launch of it), with what the elapsed time is accounted to once a launch has completed.
+struct CapturedSpan { hipEvent_t e0 = nullptr, e1 = nullptr; u64 units = 0; };
+
 struct MsmStats {                 // HIP-event timing of one kernel's launches (bucket accumulation G1 / G2, NTT passes)
     static constexpr int SLOTS = 64;                // launches that may be in flight before collect()
     static constexpr int MAX_BATCH = 8;             // MSMs queued back to back by ug_msm_batch
@@ -179,6 +189,10 @@ struct MsmStats {                 // HIP-event timing of one kernel's launches (
     u64 slot_entries[SLOTS] = {};
     int pending = 0;
     double accumulate_ms = 0; u64 launches = 0; u64 entries = 0;
+    // while the stream is being captured into a graph (ug_graph_begin .. _end) the pairs go here instead, as external event
+    // records that belong to the graph; account() adds one completed launch of the graph
+    std::vector<CapturedSpan>* capture = nullptr;
+    void account(const std::vector<CapturedSpan>& spans);
     void create();
     void destroy();
     void collect();                                 // after the stream has been synchronised

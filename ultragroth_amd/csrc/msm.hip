@@ -31,6 +31,7 @@
 #include <hipcub/hipcub.hpp>      // the library sort of rounds 1-2, kept for A/B runs (UG_SORT=cub) in -DUG_MEASURE builds only
 #endif
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include "dev_common.hpp"
@@ -752,10 +753,14 @@ int reduce_chunk(const MsmGeometry& g, int sets = 1, bool g2 = false) {
     return chunk;
 }
 
-template <class T> void dev_alloc(T*& p, size_t bytes) { if (p) hipFree(p); p = nullptr; UG_HIP(hipMalloc(&p, bytes ? bytes : 4)); }
-template <class T> void dev_free(T*& p) { if (p) hipFree(p); p = nullptr; }
+template <class T> void dev_alloc(T*& p, size_t bytes) { alloc_epoch_bump(); if (p) hipFree(p); p = nullptr; UG_HIP(hipMalloc(&p, bytes ? bytes : 4)); }
+template <class T> void dev_free(T*& p) { if (p) { alloc_epoch_bump(); hipFree(p); } p = nullptr; }
+std::atomic<uint64_t> g_alloc_epoch{1};
 
 }  // namespace
+
+uint64_t alloc_epoch() { return g_alloc_epoch.load(std::memory_order_acquire); }
+void alloc_epoch_bump() { g_alloc_epoch.fetch_add(1, std::memory_order_acq_rel); }
 
 // ---- geometry ---------------------------------------------------------------------------------------------
 namespace {
@@ -1187,6 +1192,15 @@ void MsmStats::collect_ready() {
     pending = keep;
 }
 int MsmStats::begin(hipStream_t stream, u64 units) {
+    if (capture) {                                 // the stream is being captured: an event pair of the graph's own
+        CapturedSpan sp;
+        sp.units = units;
+        UG_HIP(hipEventCreate(&sp.e0));
+        if (hipEventCreate(&sp.e1) != hipSuccess) { hipEventDestroy(sp.e0); throw HipError("HIP error: hipEventCreate"); }
+        capture->push_back(sp);
+        UG_HIP(hipEventRecordWithFlags(sp.e0, stream, hipEventRecordExternal));
+        return SLOTS + (int)capture->size() - 1;
+    }
     if (pending == SLOTS) collect_ready();
     if (pending == SLOTS) return -1;               // a caller that never waits: this launch goes untimed
     int slot = pending++;
@@ -1194,7 +1208,22 @@ int MsmStats::begin(hipStream_t stream, u64 units) {
     UG_HIP(hipEventRecord(ev0[slot], stream));
     return slot;
 }
-void MsmStats::end(int slot, hipStream_t stream) { if (slot >= 0) UG_HIP(hipEventRecord(ev1[slot], stream)); }
+void MsmStats::end(int slot, hipStream_t stream) {
+    if (slot >= SLOTS) {
+        if (!capture || (size_t)(slot - SLOTS) >= capture->size()) throw std::logic_error("kernel statistics: captured slot without a capture");
+        UG_HIP(hipEventRecordWithFlags((*capture)[slot - SLOTS].e1, stream, hipEventRecordExternal));
+        return;
+    }
+    if (slot >= 0) UG_HIP(hipEventRecord(ev1[slot], stream));
+}
+// one completed launch of a graph that holds these pairs
+void MsmStats::account(const std::vector<CapturedSpan>& spans) {
+    for (const CapturedSpan& sp : spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, sp.e0, sp.e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+        accumulate_ms += ms; launches++; entries += sp.units;
+    }
+}
 void MsmStats::collect() {
     for (int i = 0; i < pending; i++) {
         float ms = 0;

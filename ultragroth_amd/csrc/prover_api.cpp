@@ -164,10 +164,10 @@ BlindingTerms blindingTerms(const ZkeyHeader& h, const uint8_t r[32], const uint
     const G1XYZZ delta1 = g1FromRecord(h.delta1);
     const G2XYZZ delta2 = g2FromRecord(h.delta2);
     BlindingTerms t;
-    auto f2 = std::async(std::launch::async, [&] { return xyzz_mul_scalar(delta2, sw, 256); });     // :176-177
-    auto fr = std::async(std::launch::async, [&] { return xyzz_mul_scalar(delta1, rw, 256); });     // :172-173
-    auto fs = std::async(std::launch::async, [&] { return xyzz_mul_scalar(delta1, sw, 256); });     // :180-181
-    t.rsDelta1 = xyzz_mul_scalar(delta1, rsw, 256);                                                 // :194-195
+    auto f2 = std::async(std::launch::async, [&] { return xyzz_mul_scalar_w4(delta2, sw); });        // :176-177
+    auto fr = std::async(std::launch::async, [&] { return xyzz_mul_scalar_w4(delta1, rw); });        // :172-173
+    auto fs = std::async(std::launch::async, [&] { return xyzz_mul_scalar_w4(delta1, sw); });        // :180-181
+    t.rsDelta1 = xyzz_mul_scalar_w4(delta1, rsw);                                                    // :194-195
     t.sDelta1 = fs.get(); t.rDelta1 = fr.get(); t.sDelta2 = f2.get();
     return t;
 }
@@ -182,8 +182,8 @@ void blind(uint8_t* outA, uint8_t* outB, uint8_t* outC, const uint8_t* sumA, con
     pi_a = xyzz_add(xyzz_add(pi_a, g1FromRecord(h.alpha1)), t.rDelta1);   // :171-173
     pi_b = xyzz_add(xyzz_add(pi_b, g2FromRecord(h.beta2)), t.sDelta2);    // :175-177
     pib1 = xyzz_add(xyzz_add(pib1, g1FromRecord(h.beta1)), t.sDelta1);    // :179-181
-    auto fa = std::async(std::launch::async, [&] { return xyzz_mul_scalar(pi_a, sw, 256); });       // :185-186
-    G1XYZZ rB1 = xyzz_mul_scalar(pib1, rw, 256);                          // :188-189
+    auto fa = std::async(std::launch::async, [&] { return xyzz_mul_scalar_w4(pi_a, sw); });          // :185-186
+    G1XYZZ rB1 = xyzz_mul_scalar_w4(pib1, rw);                             // :188-189
     pi_c = xyzz_add(pi_c, pih);                                           // :183
     pi_c = xyzz_add(pi_c, fa.get());
     pi_c = xyzz_add(pi_c, rB1);
@@ -747,6 +747,7 @@ public:
     }
     void trimWorkspaces() override {
         std::lock_guard<std::mutex> turn(proveMutex);
+        dropGraphs();                                   // (they hold pointers into what goes now)
         ug_schedule_trim(d_.sw); ug_schedule_trim(d_.sh);
         ug_ctx_trim(d_.ctx); ug_ctx_trim(d_.ctx2);
         witness_.trim(wCur_);
@@ -1003,28 +1004,79 @@ public:
         const char* ov = getenv("ULTRAGROTH_OVERLAP");
         const int overlap = ov ? atoi(ov) : 0;
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
+        memset(runParts_, 0, sizeof runParts_);
         QueueGuard inFlight(d_.ctx, d_.ctx2);                   // from here to the collects below work is queued on both streams
-        buildSchedule(d_.sw, wCur_, wr_.lo, nw, tableW_);
-        // S1-S4 (src/groth16.cpp:55,58,61,64): A, B1, B2, C over the witness schedule, queued back to back
-        enqueueWitnessProducts(d_, d_.ctx, d_.sw, partials, partials + 64, partials + 128, partials + 256, (int64_t)hdr_.nPublic + 1, overlap == 2);
-        if (overlap == 0) ugCheck(ug_ctx_wait(d_.ctx2, d_.ctx));
-        ugCheck(ug_hpoly_run(d_.hp, wCur_, d_.h));                                              // S5-S9 :66-148
-        buildSchedule(d_.sh, d_.h, hr_.lo, nh, tableH_);
-        if (overlap == 2) ugCheck(ug_ctx_wait(d_.ctx2, d_.ctx));
-        {
+        // the whole device part: queued eagerly, or -- ULTRAGROTH_GRAPH=1 -- recorded once per witness buffer and replayed (the
+        // queued products write to runParts_, a member, so that a replay finds the same addresses)
+        auto queueAll = [&] {
+            uint8_t* out = runParts_;
+            buildSchedule(d_.sw, wCur_, wr_.lo, nw, tableW_);
+            // S1-S4 (src/groth16.cpp:55,58,61,64): A, B1, B2, C over the witness schedule, queued back to back
+            enqueueWitnessProducts(d_, d_.ctx, d_.sw, out, out + 64, out + 128, out + 256, (int64_t)hdr_.nPublic + 1, overlap == 2);
+            if (overlap == 0) ugCheck(ug_ctx_wait(d_.ctx2, d_.ctx));
+            ugCheck(ug_hpoly_run(d_.hp, wCur_, d_.h));                                          // S5-S9 :66-148
+            buildSchedule(d_.sh, d_.h, hr_.lo, nh, tableH_);
+            if (overlap == 2) ugCheck(ug_ctx_wait(d_.ctx2, d_.ctx));
             const ug_bases* sets[1] = {d_.H};
-            void* outs[1] = {partials + 320};
+            void* outs[1] = {out + 320};
             ugCheck(ug_msm_batch_enqueue(d_.ctx2, 1, sets, d_.sh, nullptr, outs));             // S10 :154
+        };
+        ug_graph* g = graphsWanted() ? graphFor(wCur_, overlap) : nullptr;
+        if (g) {
+            ugCheck(ug_graph_launch(g));
+        } else if (graphsWanted() && graphWarm(wCur_, overlap)) {
+            // second proof on this witness buffer with this geometry: every workspace has its size, record the sequence
+            ugCheck(ug_graph_begin(d_.ctx, d_.ctx2));
+            try { queueAll(); ugCheck(ug_graph_end(d_.ctx, &g)); }
+            catch (...) { ug_graph_abort(d_.ctx); throw; }
+            graphs_.push_back(GraphSlot{wCur_, overlap, g});
+            ugCheck(ug_graph_launch(g));
+        } else {
+            queueAll();
         }
         traceStep("device part fully queued");
-        ugCheck(ug_ctx_collect(d_.ctx2));                       // the one host wait of the device part ...
-        ugCheck(ug_ctx_collect(d_.ctx));                        // (... this one returns at once unless the streams overlap)
+        if (g) {                                                // a graph runs on the first context's stream: that one is waited for
+            ugCheck(ug_ctx_collect(d_.ctx));
+            ugCheck(ug_ctx_collect(d_.ctx2));
+        } else {
+            ugCheck(ug_ctx_collect(d_.ctx2));                   // the one host wait of the device part ...
+            ugCheck(ug_ctx_collect(d_.ctx));                    // (... this one returns at once unless the streams overlap)
+        }
         inFlight.done();
+        memcpy(partials, runParts_, UG_GROTH16_PARTIALS_SIZE);
         collectTimings(3);
+    }
+    // ---- one hipGraph per (witness buffer, overlap mode) of a created prover: ULTRAGROTH_GRAPH=1 ----
+    struct GraphSlot { const ug_dvec* w; int overlap; ug_graph* g; };
+    static bool graphsWanted() { const char* e = getenv("ULTRAGROTH_GRAPH"); return e && atoi(e) != 0; }      // (read per proof)
+    // a graph that is still valid for this witness buffer; stale ones (a workspace was re-allocated since) are dropped
+    ug_graph* graphFor(const ug_dvec* w, int overlap) {
+        for (size_t i = 0; i < graphs_.size();) {
+            if (!ug_graph_valid(graphs_[i].g)) { ug_graph_destroy(graphs_[i].g); graphs_.erase(graphs_.begin() + (long)i); warm_.clear(); continue; }
+            if (graphs_[i].w == w && graphs_[i].overlap == overlap) return graphs_[i].g;
+            i++;
+        }
+        return nullptr;
+    }
+    // true from the second proof on (w, overlap) on: the first one ran eagerly and sized every buffer
+    bool graphWarm(const ug_dvec* w, int overlap) {
+        for (auto& k : warm_) if (k.first == w && k.second == overlap) return true;
+        warm_.push_back({w, overlap});
+        return false;
+    }
+    void dropGraphs(bool keepWarm = false) {
+        for (auto& s : graphs_) ug_graph_destroy(s.g);
+        graphs_.clear();
+        if (!keepWarm) warm_.clear();
     }
     int kernelStats(int which, double* avgMs, unsigned long long* launches, unsigned long long* entries, int reset) override {
         double a1 = 0, a2 = 0;
         uint64_t l1 = 0, l2 = 0, e1 = 0, e2 = 0;
+        if (reset && !statsOn_) {                   // the statistics start here: sequences recorded without their event pairs are recorded again
+            std::lock_guard<std::mutex> turn(proveMutex);
+            dropGraphs(/*keepWarm*/ true);
+            statsOn_ = true;
+        }
         if (ug_ctx_kernel_stats(d_.ctx, which, &a1, &l1, &e1, reset) != UG_OK) return UG_ERROR;
         if (ug_ctx_kernel_stats(d_.ctx2, which, &a2, &l2, &e2, reset) != UG_OK) return UG_ERROR;
         if (avgMs) *avgMs = (l1 + l2) ? (a1 * (double)l1 + a2 * (double)l2) / (double)(l1 + l2) : 0.0;
@@ -1112,6 +1164,12 @@ private:
     uint8_t queuedParts_[UG_GROTH16_PARTIALS_SIZE] = {};
     uint8_t earlyR_[32] = {}, earlyS_[32] = {};
     std::future<BlindingTerms> earlyTerms_;
+    uint8_t runParts_[UG_GROTH16_PARTIALS_SIZE] = {};       // where run()'s queued products write (fixed: a replayed graph's too)
+    std::vector<GraphSlot> graphs_;
+    std::vector<std::pair<const ug_dvec*, int>> warm_;
+    bool statsOn_ = false;
+public:
+    ~Groth16Prover() override { dropGraphs(); }             // (before d_ goes: the graphs refer to its contexts)
 };
 
 // =================================================================================================================
@@ -1329,7 +1387,7 @@ public:
         drawBlinding(rk);
         memcpy(rkw_, rk, 32);
         haveRoundScalar_ = true;
-        G1XYZZ commit = xyzz_add(g1FromRecord(total64), xyzz_mul_scalar(g1FromRecord(hdr_.delta1), rkw_, 256));   // final_delta1
+        G1XYZZ commit = xyzz_add(g1FromRecord(total64), xyzz_mul_scalar_w4(g1FromRecord(hdr_.delta1), rkw_));   // final_delta1
         g1ToRecord(commit64, commit);
     }
     // on EVERY rank, with the blinded commitment: Fiat-Shamir challenge and the lookup signals it determines
@@ -1455,7 +1513,7 @@ public:
     HostTerms hostTerms(const uint8_t r[32], const uint8_t s[32]) {
         if (!haveRoundScalar_) throw std::invalid_argument("finish on a rank that did not close the round");
         HostTerms t;
-        auto fr = std::async(std::launch::async, [&] { return xyzz_mul_scalar(g1FromRecord(hdr_.roundDelta1), rkw_, 256); });   // :386-388
+        auto fr = std::async(std::launch::async, [&] { return xyzz_mul_scalar_w4(g1FromRecord(hdr_.roundDelta1), rkw_); });   // :386-388
         t.b = blindingTerms(hdr_, r, s);
         t.roundTerm = fr.get();
         return t;

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_pass_kernel(SortPassArgs a
     }      // the next tile
 }
 
-template <class T> void sort_alloc(T*& p, size_t bytes) { if (p) hipFree(p); p = nullptr; UG_HIP(hipMalloc(&p, bytes ? bytes : 4)); }
+template <class T> void sort_alloc(T*& p, size_t bytes) { alloc_epoch_bump(); if (p) hipFree(p); p = nullptr; UG_HIP(hipMalloc(&p, bytes ? bytes : 4)); }
 
 }  // namespace
 
@@ -379,6 +379,7 @@ void RadixSorter::reserve(u64 n_pairs, int ipt_min) {
     if (!small) sort_alloc(small, (4 * SORT_MAX_BINS + 16) * 4);
 }
 void RadixSorter::release() {
+    if (lookback || small) alloc_epoch_bump();
     if (lookback) hipFree(lookback);
     if (small) hipFree(small);
     lookback = small = nullptr; tiles_cap = 0;

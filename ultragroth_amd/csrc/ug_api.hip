@@ -113,6 +113,11 @@ struct ug_ctx {
     hipStream_t stream = nullptr;
     MsmWorkspace ws_g1, ws_g2;
     MsmStats stats[4];                     // [0] G1, [1] G2 bucket-accumulation launches, [2] NTT pass launches, [3] G1 group accumulation
+    // Per-kernel statistics are OFF until somebody asks for them (ug_ctx_kernel_stats with reset != 0 switches them on for the
+    // context): an event pair around a launch costs 10-25 us of idle device on this runtime (rocprofv3 trace of a 2^20 proof,
+    // profiles/r05_variants_ab.txt item 1) -- 0.2 ms per proof that only a measuring caller should pay.
+    bool kernel_stats_on = false;
+    MsmStats* stat(int k) { return kernel_stats_on ? &stats[k] : nullptr; }
     double msm_ms = 0, fft_ms = 0;
     // stream-time accounting without host waits: every timed span is an event pair that is resolved (elapsed time added
     // to its accumulator) the next time the stream is known to be idle -- ug_ctx_collect, ug_ctx_timings, ug_ctx_sync
@@ -122,6 +127,8 @@ struct ug_ctx {
     struct QueuedMsm { MsmPending pend; void* out; bool g2; };
     std::vector<QueuedMsm> pending_msm;
     hipEvent_t order_event = nullptr;      // ug_ctx_wait
+    ug_graph* recording = nullptr;         // the stream is being captured into this graph (ug_graph_begin .. ug_graph_end)
+    std::vector<ug_graph*> launched;       // graphs launched on this stream whose event pairs are not accounted yet (resolve_spans)
     NttPlan raw_ntt;                       // cache for ug_fr_ntt
     u32* lookup_last = nullptr; u64 lookup_last_n = 0;   // zeroed scratch of ug_dvec_apply_lookup
     u32* lookup_stage = nullptr; size_t lookup_stage_bytes = 0;   // staging of the lookup calls (kept: two allocations and
@@ -173,6 +180,22 @@ struct ug_hpoly {
     u32 *a = nullptr, *b = nullptr, *c = nullptr, *t = nullptr, *t2 = nullptr;     // domain elements each
 };
 
+// A fixed launch sequence of one or two contexts of a device, captured once and replayed (ug_graph_*). It owns the event pairs
+// that were recorded inside it -- the timed spans of the contexts' MSM | FFT accumulators and the per-kernel statistics -- and a
+// copy of the products that were queued while it was captured (their result blocks arrive in the same pinned memory every time).
+struct ug_graph {
+    ug_ctx* c[2] = {nullptr, nullptr};
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<ug_ctx::QueuedMsm> pend[2];
+    struct Timed { hipEvent_t e0, e1; double* acc; };
+    std::vector<Timed> spans;
+    std::vector<CapturedSpan> cap[2][4];       // per context and kernel class (ug_ctx::stats)
+    uint64_t epoch = 0;                        // alloc_epoch() when the capture ended
+    size_t nodes = 0;
+    bool capturing = false;
+};
+
 namespace {
 // blocking copy of a caller buffer into device memory; `after` as in StagedUploader::upload (called once for a small copy)
 // fresh: dst was allocated just now, nothing queued on the device refers to it -- the copy then neither waits for the
@@ -202,11 +225,24 @@ void fault_point(int site) {
     throw std::runtime_error("injected fault (test hook) at site " + std::to_string(site));
 }
 struct ScopedTimer {       // stream time between construction and stop() goes to *acc -- later: see ug_ctx::Span
-    ug_ctx* c; ug_ctx::Span span; bool stopped = false;
+    ug_ctx* c; ug_ctx::Span span; bool stopped = false, captured = false;
     ScopedTimer(const ScopedTimer&) = delete;
     ScopedTimer& operator=(const ScopedTimer&) = delete;
-    ~ScopedTimer() { if (!stopped) c->spans_free.push_back(span); }      // the timed section threw: the event pair goes back unused
+    ~ScopedTimer() {                                                      // the timed section threw: the event pair goes back unused
+        if (stopped) return;
+        if (captured) { hipEventDestroy(span.e0); hipEventDestroy(span.e1); }
+        else c->spans_free.push_back(span);
+    }
     ScopedTimer(ug_ctx* c_, double* acc_) : c(c_) {
+        if (c->recording) {                          // a pair of the graph's own, recorded by every launch of it
+            span = ug_ctx::Span{nullptr, nullptr, acc_};
+            UG_HIP(hipEventCreate(&span.e0));
+            if (hipEventCreate(&span.e1) != hipSuccess) { hipEventDestroy(span.e0); throw HipError("HIP error: hipEventCreate"); }
+            captured = true;
+            hipError_t e = hipEventRecordWithFlags(span.e0, c->stream, hipEventRecordExternal);
+            if (e != hipSuccess) { hipEventDestroy(span.e0); hipEventDestroy(span.e1); UG_HIP(e); }
+            return;
+        }
         if (c->spans_pending.size() >= 64) {        // a caller that never waits: account what has finished, without waiting
             std::vector<ug_ctx::Span> still;
             for (auto& sp : c->spans_pending) {
@@ -228,6 +264,12 @@ struct ScopedTimer {       // stream time between construction and stop() goes t
         c->spans_free.pop_back();
     }
     void stop() {
+        if (captured) {
+            UG_HIP(hipEventRecordWithFlags(span.e1, c->stream, hipEventRecordExternal));
+            c->recording->spans.push_back(ug_graph::Timed{span.e0, span.e1, span.acc});
+            stopped = true;
+            return;
+        }
         UG_HIP(hipEventRecord(span.e1, c->stream));
         c->spans_pending.push_back(span);
         stopped = true;
@@ -243,6 +285,17 @@ void resolve_spans(ug_ctx* c) {
     }
     c->spans_pending.clear();
     for (int k = 0; k < 4; k++) c->stats[k].collect();
+    // graphs launched on this stream have completed as well: one launch of each is accounted (their event pairs are re-recorded
+    // by every launch, so a graph is resolved before it is launched again: ug_graph_launch sees to that)
+    for (ug_graph* g : c->launched) {
+        for (const ug_graph::Timed& t : g->spans) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) *t.acc += ms; else (void)hipGetLastError();
+        }
+        for (int q = 0; q < 2; q++)
+            if (g->c[q]) for (int k = 0; k < 4; k++) g->c[q]->stats[k].account(g->cap[q][k]);
+    }
+    c->launched.clear();
 }
 void sync_and_resolve(ug_ctx* c) {
     UG_HIP(hipStreamSynchronize(c->stream));
@@ -450,6 +503,7 @@ int ug_bases_precompute(ug_bases* b, int c) {
         UG_HIP(hipMemcpyAsync(all, b->pts, (size_t)b->n * rec, hipMemcpyDeviceToDevice, ctx->stream));
         build_window_tables(b->g2, all, b->n, c, g.windows, ctx->stream);
         UG_HIP(hipStreamSynchronize(ctx->stream));
+        alloc_epoch_bump();                          // (captured launch sequences that read the old array are stale now)
         hipFree(b->pts);
         b->pts = all;
     }
@@ -467,6 +521,7 @@ int ug_bases_drop_tables(ug_bases* b) {
     u32* small = nullptr;
     UG_HIP(hipMalloc(&small, bytes ? bytes : 4));
     if (bytes) UG_HIP(hipMemcpy(small, b->pts, bytes, hipMemcpyDeviceToDevice));
+    alloc_epoch_bump();
     hipFree(b->pts);
     b->pts = small;
     b->table_c = 0;
@@ -504,6 +559,7 @@ int ug_ctx_mem_info(ug_ctx* c, uint64_t* free_bytes, uint64_t* total_bytes) {
 void ug_bases_destroy(ug_bases* b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);
+    alloc_epoch_bump();
     hipFree(b->pts);
     delete b;
 }
@@ -697,7 +753,7 @@ int ug_dvec_wrap(ug_ctx* c, void* device_ptr, uint64_t n, ug_dvec** out) {
 }
 void ug_dvec_destroy(ug_dvec* v) {
     if (!v) return;
-    if (v->owns) { hipSetDevice(v->ctx->device); hipFree(v->data); }
+    if (v->owns) { hipSetDevice(v->ctx->device); alloc_epoch_bump(); hipFree(v->data); }
     delete v;
 }
 
@@ -795,7 +851,7 @@ int ug_msm_g1(ug_ctx* c, const ug_bases* b, const ug_schedule* s, int64_t index_
     ScopedTimer tm(c, &c->msm_ms);
     int64_t delta = (int64_t)s->first - index_shift - (int64_t)b->global_first;
     if (!c->pending_msm.empty()) throw std::logic_error("collect the queued MSMs first (ug_ctx_collect)");
-    G1XYZZ r = msm_g1(s->sched, c->ws_g1, b->pts, b->empty ? 0 : b->n, delta, c->stream, &c->stats[0]);      // synchronises the stream
+    G1XYZZ r = msm_g1(s->sched, c->ws_g1, b->pts, b->empty ? 0 : b->n, delta, c->stream, c->stat(0));      // synchronises the stream
     tm.stop();
     sync_and_resolve(c);
     affine_out_g1((uint8_t*)out, r);
@@ -810,7 +866,7 @@ int ug_msm_g2(ug_ctx* c, const ug_bases* b, const ug_schedule* s, int64_t index_
     ScopedTimer tm(c, &c->msm_ms);
     int64_t delta = (int64_t)s->first - index_shift - (int64_t)b->global_first;
     if (!c->pending_msm.empty()) throw std::logic_error("collect the queued MSMs first (ug_ctx_collect)");
-    G2XYZZ r = msm_g2(s->sched, c->ws_g2, b->pts, b->empty ? 0 : b->n, delta, c->stream, &c->stats[1]);      // synchronises the stream
+    G2XYZZ r = msm_g2(s->sched, c->ws_g2, b->pts, b->empty ? 0 : b->n, delta, c->stream, c->stat(1));      // synchronises the stream
     tm.stop();
     sync_and_resolve(c);
     affine_out_g2((uint8_t*)out, r);
@@ -853,8 +909,8 @@ int ug_msm_batch_enqueue(ug_ctx* c, int count, const ug_bases* const* bases, con
                 delta[q] = (int64_t)s->first - (index_shifts ? index_shifts[idx[q]] : 0) - (int64_t)b->global_first;
                 host[q] = c->pinned_results + (first_slot + idx[q]) * MSM_PENDING_WORDS;
             }
-            if (g2) msm_enqueue_batch_g2(s->sched, c->ws_g2, n, pts, nb, delta, c->stream, &c->stats[1], host, pend);
-            else msm_enqueue_batch_g1(s->sched, c->ws_g1, n, pts, nb, delta, c->stream, &c->stats[0], host, pend);
+            if (g2) msm_enqueue_batch_g2(s->sched, c->ws_g2, n, pts, nb, delta, c->stream, c->stat(1), host, pend);
+            else msm_enqueue_batch_g1(s->sched, c->ws_g1, n, pts, nb, delta, c->stream, c->stat(0), host, pend);
             for (int q = 0; q < n; q++) c->pending_msm[first_slot + idx[q]].pend = pend[q];
             n = 0;
         };
@@ -891,7 +947,7 @@ int ug_msm_group_enqueue(ug_ctx* c, const ug_bases* group, const ug_schedule* s,
         u32* host[MSM_BATCH_MAX]; MsmPending pend[MSM_BATCH_MAX];
         for (int m = 0; m < K; m++) host[m] = c->pinned_results + (first_slot + m) * MSM_PENDING_WORDS;
         const int64_t delta = (int64_t)s->first - (int64_t)group->global_first;
-        msm_enqueue_group_g1(s->sched, c->ws_g1, K, group->pts, group->slots, delta, c->stream, &c->stats[3], host, pend);
+        msm_enqueue_group_g1(s->sched, c->ws_g1, K, group->pts, group->slots, delta, c->stream, c->stat(3), host, pend);
         for (int m = 0; m < K; m++) c->pending_msm[first_slot + m].pend = pend[m];
     } catch (...) { c->pending_msm.resize(first_slot); throw; }
     tm.stop();
@@ -918,6 +974,7 @@ int ug_ctx_collect(ug_ctx* c) {
 void ug_ctx_abandon(ug_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->recording) ug_graph_abort(c->recording->c[0]);      // a capture that failed half way: nothing of it was ever queued
     (void)hipStreamSynchronize(c->stream);
     (void)hipGetLastError();
     c->pending_msm.clear();
@@ -1002,29 +1059,29 @@ int ug_hpoly_run(ug_hpoly* hp, const ug_dvec* w, ug_dvec* h_out) {
         hp->ntt.passes(pa, hp->a, hp->a, true, false, true, hp->ntt.twist, nullptr, &wa);      // S8 ifft + twist :110-128
         hp->ntt.passes(pb, hp->b, hp->b, true, false, true, hp->ntt.twist, nullptr, &wb);
         const NttPass* inv3[3] = {pa, pb, pc};
-        for (int p = 0; p < np; p++) hp->ntt.launch(inv3, 3, p, st, &c->stats[2]);
+        for (int p = 0; p < np; p++) hp->ntt.launch(inv3, 3, p, st, c->stat(2));
         // S8 fft :130-140, in place on a and b; chain c's last pass also forms h = a o b - c (S9 :142-148) from the FINISHED
         // a and b, so it goes after theirs
         hp->ntt.passes(pa, hp->a, hp->a, false, false, false, nullptr, nullptr, nullptr);
         hp->ntt.passes(pb, hp->b, hp->b, false, false, false, nullptr, nullptr, nullptr);
         hp->ntt.passes(pc, h_out->data, hp->t2, false, false, false, nullptr, nullptr, &cfwd);
         const NttPass* fwd3[3] = {pa, pb, pc};
-        for (int p = 0; p + 1 < np; p++) hp->ntt.launch(fwd3, 3, p, st, &c->stats[2]);
-        hp->ntt.launch(fwd3, 2, np - 1, st, &c->stats[2]);
+        for (int p = 0; p + 1 < np; p++) hp->ntt.launch(fwd3, 3, p, st, c->stat(2));
+        hp->ntt.launch(fwd3, 2, np - 1, st, c->stat(2));
         const NttPass* last[1] = {pc};
-        hp->ntt.launch(last, 1, np - 1, st, &c->stats[2]);
+        hp->ntt.launch(last, 1, np - 1, st, c->stat(2));
     } else {
         // S7 + the inverse half of the third chain: c = a o b is formed inside the first pass of its ifft (:100-108), whose
         // passes run on hp->c so that a and b stay intact; the twisted coefficients wait in hp->t2
-        hp->ntt.transform(hp->t2, hp->a, /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, &c->stats[2], &cinv);
+        hp->ntt.transform(hp->t2, hp->a, /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, c->stat(2), &cinv);
         // S8: ifft, twist by omega_2n^i (with 1/n folded in), fft          :110-140
         u32* polys[2] = {hp->a, hp->b};
         for (int p = 0; p < 2; p++) {
-            hp->ntt.transform(hp->t, polys[p], /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, &c->stats[2]);
-            hp->ntt.transform(polys[p], hp->t, /*inverse*/ false, false, false, nullptr, nullptr, st, &c->stats[2]);
+            hp->ntt.transform(hp->t, polys[p], /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, c->stat(2));
+            hp->ntt.transform(polys[p], hp->t, /*inverse*/ false, false, false, nullptr, nullptr, st, c->stat(2));
         }
         // the forward half of the third chain, with S9 (h = a o b - c, to plain integers, :142-148) inside its last pass
-        hp->ntt.transform(h_out->data, hp->t2, /*inverse*/ false, false, false, nullptr, nullptr, st, &c->stats[2], &cfwd);
+        hp->ntt.transform(h_out->data, hp->t2, /*inverse*/ false, false, false, nullptr, nullptr, st, c->stat(2), &cfwd);
     }
     tm.stop();
     UG_CATCH
@@ -1052,13 +1109,13 @@ int ug_hpoly_chain(ug_hpoly* hp, const ug_dvec* w, int which, ug_dvec* out) {
     if (which == 2) {
         coef_matvec(hp->a, hp->b, hp->mat, w->data, 3, st);
         NttFusion cinv; cinv.in2 = hp->b; cinv.work = hp->c;             // c = a o b inside the first pass
-        hp->ntt.transform(hp->t, hp->a, /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, &c->stats[2], &cinv);
+        hp->ntt.transform(hp->t, hp->a, /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, c->stat(2), &cinv);
     } else {
         coef_matvec(hp->a, hp->b, hp->mat, w->data, 1 << which, st);
         u32* src = which ? hp->b : hp->a;
-        hp->ntt.transform(hp->t, src, /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, &c->stats[2]);
+        hp->ntt.transform(hp->t, src, /*inverse*/ true, false, /*scatter_bitrev*/ true, hp->ntt.twist, nullptr, st, c->stat(2));
     }
-    hp->ntt.transform(out->data, hp->t, /*inverse*/ false, false, false, nullptr, nullptr, st, &c->stats[2]);
+    hp->ntt.transform(out->data, hp->t, /*inverse*/ false, false, false, nullptr, nullptr, st, c->stat(2));
     tm.stop();
     sync_and_resolve(c);                         // the caller hands the buffer to other libraries (RCCL): complete on return
     UG_CATCH
@@ -1099,6 +1156,7 @@ int ug_hpoly_debug_abc(ug_hpoly* hp, void* ha, void* hb, void* hc) {
 void ug_hpoly_destroy(ug_hpoly* hp) {
     if (!hp) return;
     hipSetDevice(hp->ctx->device);
+    alloc_epoch_bump();
     hipFree(hp->a); hipFree(hp->b); hipFree(hp->c); hipFree(hp->t); hipFree(hp->t2);
     hp->mat.release(); hp->ntt.release();
     delete hp;
@@ -1163,6 +1221,124 @@ int ug_synth_points(ug_ctx* c, int g2, const void* generator_record, uint64_t se
     UG_CATCH
 }
 
+// ---- captured launch sequences ---------------------------------------------------------------------------------------------
+// A created prover's proof is one fixed sequence of 60-75 launches on two streams, none of which depends on a host read-back:
+// captured once per witness buffer, replayed with one hipGraphLaunch. ug_graph_begin puts the context's stream into capture
+// (relaxed mode: other host threads -- the witness staging lanes -- go on using the runtime) and forks ctx2's stream off it;
+// everything the library queues on either context until ug_graph_end becomes a node: kernels, memsets, the result copies into
+// pinned memory, and the timing events as EXTERNAL event records, so that the MSM | FFT split and the per-kernel statistics
+// keep working under replay. Nothing runs during the capture. ug_graph_end joins the streams, instantiates, and takes the
+// products that were queued (ug_msm_*_enqueue) out of the contexts; ug_graph_launch puts them back and launches: the caller
+// then collects as after the eager calls -- ug_ctx_collect on the FIRST context first (the graph runs on its stream).
+int ug_graph_begin(ug_ctx* c, ug_ctx* c2) {
+    UG_TRY
+    if (!c) throw std::invalid_argument("null argument");
+    if (c2 && c2->device != c->device) throw std::invalid_argument("contexts on different devices");
+    if (c->recording || (c2 && c2->recording)) throw std::logic_error("a capture is already in progress on this context");
+    if (!c->pending_msm.empty() || (c2 && !c2->pending_msm.empty())) throw std::logic_error("collect the queued MSMs first (ug_ctx_collect)");
+    c->use();
+    sync_and_resolve(c);                                   // pending spans and statistics of eager work: accounted before the switch
+    if (c2) sync_and_resolve(c2);
+    std::unique_ptr<ug_graph> g(new ug_graph());
+    g->c[0] = c; g->c[1] = c2;
+    UG_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+    g->capturing = true;
+    ug_graph* raw = g.release();
+    c->recording = raw;
+    for (int k = 0; k < 4; k++) c->stats[k].capture = &raw->cap[0][k];
+    if (c2) {
+        c2->recording = raw;
+        for (int k = 0; k < 4; k++) c2->stats[k].capture = &raw->cap[1][k];
+        hipError_t e = hipEventRecord(c->order_event, c->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c2->stream, c->order_event, 0);      // ctx2's stream joins the capture
+        if (e != hipSuccess) { ug_graph_abort(c); UG_HIP(e); }
+    }
+    UG_CATCH
+}
+static void graph_unhook(ug_graph* g) {
+    for (int q = 0; q < 2; q++) {
+        if (!g->c[q]) continue;
+        g->c[q]->recording = nullptr;
+        for (int k = 0; k < 4; k++) g->c[q]->stats[k].capture = nullptr;
+    }
+}
+void ug_graph_abort(ug_ctx* c) {
+    if (!c || !c->recording) return;
+    ug_graph* g = c->recording;
+    (void)hipSetDevice(c->device);
+    graph_unhook(g);
+    for (int q = 0; q < 2; q++) if (g->c[q]) g->c[q]->pending_msm.clear();
+    if (g->capturing) {
+        hipGraph_t broken = nullptr;
+        (void)hipStreamEndCapture(g->c[0]->stream, &broken);
+        if (broken) (void)hipGraphDestroy(broken);
+        (void)hipGetLastError();
+        g->capturing = false;
+    }
+    ug_graph_destroy(g);
+}
+int ug_graph_end(ug_ctx* c, ug_graph** out) {
+    UG_TRY
+    if (!c || !out) throw std::invalid_argument("null argument");
+    if (!c->recording || c->recording->c[0] != c) throw std::logic_error("no capture was begun on this context");
+    ug_graph* g = c->recording;
+    c->use();
+    try {
+        if (g->c[1]) {                                     // join: the first stream waits for everything queued on the second
+            UG_HIP(hipEventRecord(g->c[1]->order_event, g->c[1]->stream));
+            UG_HIP(hipStreamWaitEvent(c->stream, g->c[1]->order_event, 0));
+        }
+        hipError_t e = hipStreamEndCapture(c->stream, &g->graph);
+        g->capturing = false;
+        UG_HIP(e);
+        if (!g->graph) throw std::runtime_error("stream capture produced no graph");
+        UG_HIP(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
+        (void)hipGraphGetNodes(g->graph, nullptr, &g->nodes);
+    } catch (...) { ug_graph_abort(c); throw; }
+    graph_unhook(g);
+    for (int q = 0; q < 2; q++) if (g->c[q]) { g->pend[q].swap(g->c[q]->pending_msm); g->c[q]->pending_msm.clear(); }
+    g->epoch = alloc_epoch();
+    *out = g;
+    UG_CATCH
+}
+// 1 while every buffer the captured launches refer to is still where it was (no per-proof device buffer of this process has been
+// allocated or released since the capture ended)
+int ug_graph_valid(const ug_graph* g) { return g && g->exec && g->epoch == alloc_epoch() ? 1 : 0; }
+uint64_t ug_graph_nodes(const ug_graph* g) { return g ? g->nodes : 0; }
+int ug_graph_launch(ug_graph* g) {
+    UG_TRY
+    if (!g || !g->exec) throw std::invalid_argument("null argument");
+    if (!ug_graph_valid(g)) throw std::logic_error("the captured launch sequence is stale (device buffers were re-allocated since)");
+    ug_ctx* c = g->c[0];
+    c->use();
+    for (int q = 0; q < 2; q++)
+        if (g->c[q] && (!g->c[q]->pending_msm.empty() || g->c[q]->recording)) throw std::logic_error("collect the queued MSMs first (ug_ctx_collect)");
+    // a launch whose event pairs have not been read yet would be overwritten: account it first (a caller that collects after
+    // every launch never waits here)
+    for (ug_graph* l : c->launched) if (l == g) { sync_and_resolve(c); break; }
+    for (int q = 0; q < 2; q++) if (g->c[q]) g->c[q]->pending_msm = g->pend[q];
+    hipError_t e = hipGraphLaunch(g->exec, c->stream);
+    if (e != hipSuccess) { for (int q = 0; q < 2; q++) if (g->c[q]) g->c[q]->pending_msm.clear(); UG_HIP(e); }
+    c->launched.push_back(g);
+    UG_CATCH
+}
+void ug_graph_destroy(ug_graph* g) {
+    if (!g) return;
+    if (g->c[0]) {
+        (void)hipSetDevice(g->c[0]->device);
+        // a launch may still run, and the context may still want to read its event pairs
+        if (!g->capturing) (void)hipStreamSynchronize(g->c[0]->stream);
+        auto& l = g->c[0]->launched;
+        for (size_t i = 0; i < l.size();) { if (l[i] == g) l.erase(l.begin() + (long)i); else i++; }
+    }
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    for (auto& t : g->spans) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
+    for (int q = 0; q < 2; q++) for (int k = 0; k < 4; k++) for (auto& sp : g->cap[q][k]) { if (sp.e0) hipEventDestroy(sp.e0); if (sp.e1) hipEventDestroy(sp.e1); }
+    (void)hipGetLastError();
+    delete g;
+}
+
 int ug_ctx_timings(ug_ctx* c, double* msm_ms, double* fft_ms, int reset) {
     UG_TRY
     if (!c) throw std::invalid_argument("null argument");
@@ -1183,7 +1359,7 @@ int ug_ctx_kernel_stats(ug_ctx* c, int which, double* avg_ms, uint64_t* launches
     if (avg_ms) *avg_ms = st.launches ? st.accumulate_ms / (double)st.launches : 0.0;
     if (launches) *launches = st.launches;
     if (entries) *entries = st.entries;
-    if (reset) { st.accumulate_ms = 0; st.launches = 0; st.entries = 0; }
+    if (reset) { st.accumulate_ms = 0; st.launches = 0; st.entries = 0; c->kernel_stats_on = true; }
     UG_CATCH
 }
 
