@@ -256,7 +256,7 @@ int  ug_synth_points(ug_ctx* ctx, int g2, const void* generator_record, uint64_t
  * prove, src/groth16.cpp:48-203, is one fixed sequence of calls, and so is this library's: no launch depends on a host read-back).
  * ug_graph_begin puts ctx's stream into capture and forks ctx2's stream (may be NULL) off it; whatever the library queues on the
  * two contexts until ug_graph_end -- schedules, products, ug_hpoly_run, ug_ctx_wait edges -- is recorded instead of run, the timing
- * events included (as external event records: ug_ctx_timings / ug_ctx_kernel_stats keep working under replay). Calls that wait
+ * events included (as event-record nodes: ug_ctx_timings / ug_ctx_kernel_stats keep working under replay). Calls that wait
  * for the device (ug_ctx_sync, _collect, blocking products, uploads) must not be made on a capturing context. ug_graph_end
  * instantiates the graph and takes the queued products out of the contexts; ug_graph_launch puts them back and launches on ctx's
  * stream: collect as after the eager calls, ctx FIRST. ug_graph_valid: 0 once any per-proof device buffer of the process has

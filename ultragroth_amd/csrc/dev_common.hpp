@@ -22,6 +22,23 @@ struct HipError : public std::runtime_error {
 
 #define UG_KERNEL_CHECK() UG_HIP(hipGetLastError())
 
+// An event recorded INSIDE a stream capture so that every launch of the resulting graph records it again (timed spans of a
+// captured launch sequence): an explicit event-record node behind the stream's current capture dependencies, which then becomes
+// the stream's dependency. (hipEventRecordWithFlags(.., hipEventRecordExternal) is the same thing in one call on ROCm 7.2, but
+// the runtime a PyTorch wheel bundles -- ROCm 7.0, the one a Python process ends up with -- refuses it: tools/probe_graph_events.hip.)
+inline void record_in_capture(hipEvent_t ev, hipStream_t stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    hipGraph_t g = nullptr;
+    const hipGraphNode_t* deps = nullptr;
+    size_t n = 0;
+    UG_HIP(hipStreamGetCaptureInfo_v2(stream, &st, &id, &g, &deps, &n));
+    if (st != hipStreamCaptureStatusActive || !g) throw HipError("HIP error: the stream is not being captured (record_in_capture)");
+    hipGraphNode_t node = nullptr;
+    UG_HIP(hipGraphAddEventRecordNode(&node, g, deps, n, ev));
+    UG_HIP(hipStreamUpdateCaptureDependencies(stream, &node, 1, hipStreamSetCaptureDependencies));
+}
+
 // Environment switches come in two kinds (the table in include/ultragroth_hip.h lists both):
 //   tuning knobs        getenv(): every setting gives correct results, the default is the measured best
 //   measurement switches  measure_env(): A/B switches of finished experiments and settings that give WRONG results (folded

@@ -178,7 +178,7 @@ struct MsmWorkspace {
     ~MsmWorkspace() { release(); }
 };
 
-// An event pair recorded INSIDE a captured launch sequence (hipEventRecordWithFlags(.., hipEventRecordExternal): an event-record
+// An event pair recorded INSIDE a captured launch sequence (dev_common.hpp record_in_capture: an event-record
 // node of the graph, re-recorded by every launch of it), with what the elapsed time is accounted to once a launch has completed.
 struct CapturedSpan { hipEvent_t e0 = nullptr, e1 = nullptr; u64 units = 0; };
 

@@ -1198,7 +1198,7 @@ int MsmStats::begin(hipStream_t stream, u64 units) {
         UG_HIP(hipEventCreate(&sp.e0));
         if (hipEventCreate(&sp.e1) != hipSuccess) { hipEventDestroy(sp.e0); throw HipError("HIP error: hipEventCreate"); }
         capture->push_back(sp);
-        UG_HIP(hipEventRecordWithFlags(sp.e0, stream, hipEventRecordExternal));
+        record_in_capture(sp.e0, stream);
         return SLOTS + (int)capture->size() - 1;
     }
     if (pending == SLOTS) collect_ready();
@@ -1211,7 +1211,7 @@ int MsmStats::begin(hipStream_t stream, u64 units) {
 void MsmStats::end(int slot, hipStream_t stream) {
     if (slot >= SLOTS) {
         if (!capture || (size_t)(slot - SLOTS) >= capture->size()) throw std::logic_error("kernel statistics: captured slot without a capture");
-        UG_HIP(hipEventRecordWithFlags((*capture)[slot - SLOTS].e1, stream, hipEventRecordExternal));
+        record_in_capture((*capture)[slot - SLOTS].e1, stream);
         return;
     }
     if (slot >= 0) UG_HIP(hipEventRecord(ev1[slot], stream));

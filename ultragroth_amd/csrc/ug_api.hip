@@ -239,8 +239,8 @@ struct ScopedTimer {       // stream time between construction and stop() goes t
             UG_HIP(hipEventCreate(&span.e0));
             if (hipEventCreate(&span.e1) != hipSuccess) { hipEventDestroy(span.e0); throw HipError("HIP error: hipEventCreate"); }
             captured = true;
-            hipError_t e = hipEventRecordWithFlags(span.e0, c->stream, hipEventRecordExternal);
-            if (e != hipSuccess) { hipEventDestroy(span.e0); hipEventDestroy(span.e1); UG_HIP(e); }
+            try { record_in_capture(span.e0, c->stream); }
+            catch (...) { hipEventDestroy(span.e0); hipEventDestroy(span.e1); stopped = true; throw; }
             return;
         }
         if (c->spans_pending.size() >= 64) {        // a caller that never waits: account what has finished, without waiting
@@ -265,7 +265,7 @@ struct ScopedTimer {       // stream time between construction and stop() goes t
     }
     void stop() {
         if (captured) {
-            UG_HIP(hipEventRecordWithFlags(span.e1, c->stream, hipEventRecordExternal));
+            record_in_capture(span.e1, c->stream);
             c->recording->spans.push_back(ug_graph::Timed{span.e0, span.e1, span.acc});
             stopped = true;
             return;
@@ -1226,7 +1226,7 @@ int ug_synth_points(ug_ctx* c, int g2, const void* generator_record, uint64_t se
 // captured once per witness buffer, replayed with one hipGraphLaunch. ug_graph_begin puts the context's stream into capture
 // (relaxed mode: other host threads -- the witness staging lanes -- go on using the runtime) and forks ctx2's stream off it;
 // everything the library queues on either context until ug_graph_end becomes a node: kernels, memsets, the result copies into
-// pinned memory, and the timing events as EXTERNAL event records, so that the MSM | FFT split and the per-kernel statistics
+// pinned memory, and the timing events as event-record nodes (dev_common.hpp: record_in_capture), so that the MSM | FFT split and the per-kernel statistics
 // keep working under replay. Nothing runs during the capture. ug_graph_end joins the streams, instantiates, and takes the
 // products that were queued (ug_msm_*_enqueue) out of the contexts; ug_graph_launch puts them back and launches: the caller
 // then collects as after the eager calls -- ug_ctx_collect on the FIRST context first (the graph runs on its stream).
