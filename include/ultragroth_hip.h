@@ -112,6 +112,13 @@ int      ug_bases_precompute(ug_bases* b, int c);
 /* give the tables' memory back (the set keeps its n points; schedules must then be built without tables) */
 int      ug_bases_drop_tables(ug_bases* b);
 int      ug_bases_table_window(const ug_bases* b);          /* width of the tables held, 0 = none */
+/* BACKGROUND TABLE BUILDS (cold start of a created prover): after ug_ctx_background_tables(ctx, 1) the table
+ * kernels of sets made by ug_bases_create_tables_* / ug_bases_create_group_g1 on this context run on a lowest-priority stream of
+ * their own and NOTHING queued on the context waits for them: until ug_bases_tables_ready(set, 0) returns 1 the set is used as a
+ * plain set (schedules without tables read table 0 only, which the upload filled); from then on table schedules may be built
+ * (before, products over a table schedule fail). wait != 0 blocks until the build has ended. Returns -1 on an error. */
+int      ug_ctx_background_tables(ug_ctx* ctx, int on);
+int      ug_bases_tables_ready(ug_bases* b, int wait);
 int      ug_ctx_mem_info(ug_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 void ug_bases_destroy(ug_bases* b);
 

@@ -145,7 +145,25 @@ struct ug_ctx {
     u32* pinned_results = nullptr;         // MsmStats::SLOTS result blocks of queued MSMs (ug_msm_batch)
     std::vector<void*> deferred_free;      // staging memory of queued set-up work: hipFree waits for the whole device, so it is
                                            // freed the next time the stream is idle anyway (ug_ctx_sync, destroy)
-    void free_deferred() { for (void* p : deferred_free) hipFree(p); deferred_free.clear(); }
+    // BACKGROUND TABLE BUILDS (ug_ctx_background_tables): the window-table kernels of sets created on this context go to a stream
+    // of their own (lowest priority) and nothing queued on the context waits for them; a set's tables_ready event tells when its
+    // tables may be used. While one of them runs, nothing is hipFree'd on behalf of this context (hipFree waits for the device).
+    bool bg_tables = false;
+    hipStream_t build_stream = nullptr;
+    std::vector<hipEvent_t> bg_events;     // ready events of the sets created so (owned by the sets; dropped here once they have fired)
+    bool builds_running() {
+        for (size_t i = 0; i < bg_events.size();) {
+            if (hipEventQuery(bg_events[i]) == hipSuccess) bg_events.erase(bg_events.begin() + (long)i); else i++;
+        }
+        (void)hipGetLastError();
+        return !bg_events.empty();
+    }
+    void forget_build(hipEvent_t ev) { for (size_t i = 0; i < bg_events.size(); i++) if (bg_events[i] == ev) { bg_events.erase(bg_events.begin() + (long)i); return; } }
+    void free_deferred() {
+        if (deferred_free.empty() || builds_running()) return;
+        for (void* p : deferred_free) hipFree(p);
+        deferred_free.clear();
+    }
     void use() const { UG_HIP(hipSetDevice(device)); }
 };
 struct ug_bases {
@@ -155,6 +173,17 @@ struct ug_bases {
     u64 slots = 0;            //      scalar global_first + slot (ug_bases_create_group_g1)
     bool empty = false;       // every record is the point at infinity (e.g. the B2 section of a circuit without B-side wires): its
                               // products are the point at infinity and no kernel is launched for them
+    hipEvent_t tables_ready = nullptr;      // set: the tables are (were) built in the background; fired = they may be used
+    // 1 once the tables may be read (always for a set built on its context's stream); wait: block until then
+    bool ready(bool wait) {
+        if (!tables_ready) return true;
+        if (wait) { UG_HIP(hipEventSynchronize(tables_ready)); }
+        else if (hipEventQuery(tables_ready) != hipSuccess) { (void)hipGetLastError(); return false; }
+        ctx->forget_build(tables_ready);
+        hipEventDestroy(tables_ready);
+        tables_ready = nullptr;
+        return true;
+    }
 };
 struct ug_dvec {
     ug_ctx* ctx; u64 n; u32* data; bool owns;
@@ -343,6 +372,8 @@ void ug_ctx_destroy(ug_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    if (c->build_stream) { hipStreamSynchronize(c->build_stream); hipStreamDestroy(c->build_stream); c->build_stream = nullptr; }
+    c->bg_events.clear();
     c->free_deferred();
     c->ws_g1.release(); c->ws_g2.release(); c->raw_ntt.release(); c->uploader.release();
     if (c->lookup_last) hipFree(c->lookup_last);
@@ -386,6 +417,20 @@ static bool host_all_zero(const void* p, size_t bytes) {
     for (; i < bytes; i++) if (b[i]) return false;
     return true;
 }
+// the table kernel of a freshly uploaded set: on the context's stream, or -- background builds -- on the build stream with the
+// set's ready event behind it
+static void queue_table_build(ug_ctx* c, ug_bases* b, u32* pts, u64 n, int table_c, int windows) {
+    if (!c->bg_tables) { build_window_tables(b->g2, pts, n, table_c, windows, c->stream); return; }
+    if (!c->build_stream) {
+        int least = 0, greatest = 0;
+        UG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        UG_HIP(hipStreamCreateWithPriority(&c->build_stream, hipStreamNonBlocking, least));
+    }
+    build_window_tables(b->g2, pts, n, table_c, windows, c->build_stream);
+    UG_HIP(hipEventCreateWithFlags(&b->tables_ready, hipEventDisableTiming));
+    UG_HIP(hipEventRecord(b->tables_ready, c->build_stream));
+    c->bg_events.push_back(b->tables_ready);
+}
 static int bases_create(ug_ctx* c, const void* host, u64 n, u64 global_first, bool g2, int table_c, ug_bases** out) {
     UG_TRY
     if (!c || !out || (!host && n)) throw std::invalid_argument("null argument");
@@ -411,8 +456,8 @@ static int bases_create(ug_ctx* c, const void* host, u64 n, u64 global_first, bo
                 u32* p = pts + off / 4;
                 if (g2) convert_points_g2(p, len / rec, st); else convert_points_g1(p, len / rec, st);
             }, /*fresh*/ true);
-            if (table_c) build_window_tables(g2, pts, n, table_c, windows, c->stream);
-        } catch (...) { hipFree(b->pts); delete b; throw; }
+            if (table_c) queue_table_build(c, b, pts, n, table_c, windows);
+        } catch (...) { if (b->tables_ready) { hipStreamSynchronize(c->build_stream); c->forget_build(b->tables_ready); hipEventDestroy(b->tables_ready); } hipFree(b->pts); delete b; throw; }
     }
     b->table_c = table_c;
     *out = b;
@@ -468,8 +513,8 @@ int ug_bases_create_group_g1(ug_ctx* c, int members, const void* const* host, co
                 interleave_points_g1(pts, stage + off / 4, len / 64, members, m, slot0 + off / 64, st);
             }, /*fresh*/ true);
         }
-        if (table_c && b->n) build_window_tables(false, pts, b->n, table_c, windows, c->stream);
-    } catch (...) { hipFree(stage); hipFree(b->pts); delete b; throw; }
+        if (table_c && b->n) queue_table_build(c, b, pts, b->n, table_c, windows);
+    } catch (...) { if (b->tables_ready) { hipStreamSynchronize(c->build_stream); c->forget_build(b->tables_ready); hipEventDestroy(b->tables_ready); } hipFree(stage); hipFree(b->pts); delete b; throw; }
     c->deferred_free.push_back(stage);      // (not hipFree here: it would wait for the table build just queued, and the caller's next
                                             // section could no longer be uploaded beside it)
     b->table_c = table_c;
@@ -489,6 +534,7 @@ int ug_bases_precompute(ug_bases* b, int c) {
     UG_TRY
     if (!b) throw std::invalid_argument("null argument");
     if (b->table_c) throw std::invalid_argument("bases already hold window tables");
+    b->ready(true);
     MsmGeometry g = MsmGeometry::choose_tables(b->n, c);             // validates c
     if ((b->members > 1 ? b->slots : b->n) > ((u64)1 << TABLE_INDEX_BITS)) throw std::invalid_argument("window tables need at most 2^27 points per set");
     ug_ctx* ctx = b->ctx;
@@ -516,6 +562,7 @@ int ug_bases_drop_tables(ug_bases* b) {
     if (!b->table_c) return UG_OK;
     ug_ctx* ctx = b->ctx;
     ctx->use();
+    b->ready(true);                                  // (a background build of them ends first)
     UG_HIP(hipStreamSynchronize(ctx->stream));
     size_t bytes = (size_t)b->n * (b->g2 ? 128 : 64);
     u32* small = nullptr;
@@ -528,6 +575,20 @@ int ug_bases_drop_tables(ug_bases* b) {
     UG_CATCH
 }
 int ug_bases_table_window(const ug_bases* b) { return b ? b->table_c : 0; }
+int ug_ctx_background_tables(ug_ctx* c, int on) {
+    UG_TRY
+    if (!c) throw std::invalid_argument("null argument");
+    c->bg_tables = on != 0;
+    UG_CATCH
+}
+// 1: the set's window tables may be used (also for a set without a background build); 0: still being built; -1: error
+int ug_bases_tables_ready(ug_bases* b, int wait) {
+    if (!b) { g_last_error = "null argument"; return -1; }
+    try {
+        b->ctx->use();
+        return b->ready(wait != 0) ? 1 : 0;
+    } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
+}
 int ug_schedule_trim(ug_schedule* s) {
     UG_TRY
     if (!s) throw std::invalid_argument("null argument");
@@ -559,6 +620,7 @@ int ug_ctx_mem_info(ug_ctx* c, uint64_t* free_bytes, uint64_t* total_bytes) {
 void ug_bases_destroy(ug_bases* b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);
+    try { b->ready(true); } catch (...) {}
     alloc_epoch_bump();
     hipFree(b->pts);
     delete b;
@@ -837,6 +899,8 @@ static void affine_out_g2(uint8_t* out, const G2XYZZ& p) {
 
 // a schedule built for window tables needs bases that hold tables of the same width (a classic schedule reads table 0 only)
 static void check_tables(const ug_bases* b, const ug_schedule* s) {
+    if (s->sched.geo.tables && b->tables_ready && !const_cast<ug_bases*>(b)->ready(false))
+        throw std::logic_error("the window tables of this base set are still being built (ug_bases_tables_ready)");
     if (s->sched.geo.tables && s->sched.geo.c != b->table_c)
         throw std::invalid_argument("schedule built for window tables of width " + std::to_string(s->sched.geo.c) +
                                     " but the bases hold " + (b->table_c ? "tables of width " + std::to_string(b->table_c) : std::string("no tables")));
