@@ -569,6 +569,14 @@ def main():
         t0 = time.perf_counter()
         prover = ug.Groth16Prover(zkey)          # groth16_prover_create: the reference's own entry point
         create_s = time.perf_counter() - t0
+        # cold start: create does not wait for the window tables; the first proof (the reference's call, .wtns in host memory)
+        # goes at once, on the classic windows beside the table kernels; the timed region below runs on the finished tables
+        first_proof_s = tables_s = None
+        if not args.bare:
+            prover.prove(wtns)
+            first_proof_s = time.perf_counter() - t0
+        prover.tables_ready(wait=True)
+        tables_s = time.perf_counter() - t0
         if not args.check and args.no_cpu_baseline:
             del zkey
             zkey = None
@@ -1036,6 +1044,10 @@ def main():
             "pipelined_proofs_per_s": (args.steps / pipelined_s) if pipelined_s else None,
             "pipelined_host_threads": host_threads if pipelined_s else None,
             "create_s": create_s, "zkey_bytes": zkey_bytes, "zkey_ingest_gbs": zkey_bytes / create_s / 1e9,
+            "time_to_first_proof_s": first_proof_s if single else None, "tables_in_use_after_s": tables_s if single else None,
+            "cold_start": ("groth16_prover_create returns once the zkey is resident (create_s); time_to_first_proof_s = create + one "
+                           "groth16_prover_prove at once (classic windows, beside the window-table kernels, which run on a stream of their own); "
+                           "tables_in_use_after_s = when the tables were finished and adopted; the timed region runs on them") if single else None,
             "host_peak_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 2),
             "roofline": roofline,
         }

@@ -96,15 +96,32 @@ def test_closed_form_equals_the_oracle_prover(device):
         assert got == (exp[0], exp[1])
 
 
-def test_whole_proof_at_configs2_size_uniform(full_zkey, full_prover):
+def test_whole_proof_at_configs2_size_uniform(full_zkey, request):
     """BASELINE.json configs[2]: 2^24 constraints, uniform scalars, created prover with window tables -- the bench's
     default workload (a second witness on the same prover object follows in the circom-like test below; two different
-    witnesses through one prover are also compared at 2^20, test_created_prover_at_2_20_bit_exact)"""
+    witnesses through one prover are also compared at 2^20, test_created_prover_at_2_20_bit_exact).
+    COLD START at the full size (round 5): groth16_prover_create returns once the zkey is resident; the first proof runs at
+    once -- on the classic windows, BESIDE the table kernels -- and the one after the tables are finished on the tables: both
+    byte for byte the expected proof."""
     from ultragroth_amd import synth
     zkey, info = full_zkey
     wtns = synth.build_witness(FULL_LOG, "U")
-    _progress("2^%d U: proving" % FULL_LOG)
-    assert _prove(full_prover, wtns) == _expected(zkey, wtns, FULL_LOG, "U")
+    exp = _expected(zkey, wtns, FULL_LOG, "U")                  # (first: the oracle's H polynomial takes longer than the table build)
+    t0 = time.perf_counter()
+    full_prover = request.getfixturevalue("full_prover")        # groth16_prover_create
+    created = time.perf_counter() - t0
+    ready_at_create = full_prover.tables_ready()
+    _progress("2^%d U: proving at once (create %.2f s, tables ready at create: %s)" % (FULL_LOG, created, ready_at_create))
+    first = _prove(full_prover, wtns)
+    t_first = time.perf_counter() - t0
+    assert first == exp
+    full_prover.tables_ready(wait=True)
+    t_tables = time.perf_counter() - t0
+    _progress("2^%d U: first proof %.2f s after the start of create, tables in use after %.2f s; proving on the tables" % (FULL_LOG, t_first, t_tables))
+    assert full_prover.tables_ready()
+    assert _prove(full_prover, wtns) == exp
+    if os.environ.get("ULTRAGROTH_TABLES_BG", "1") != "0" and FULL_LOG >= 22:
+        assert not ready_at_create                              # (the build takes seconds at this size: create did not wait for it)
 
 
 def test_whole_proof_at_configs2_size_circom_like(full_zkey, full_prover):

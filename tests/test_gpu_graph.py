@@ -117,3 +117,42 @@ def test_two_host_threads_on_one_prover_with_graphs(device, monkeypatch):
             assert not bad, bad
     finally:
         ug.set_test_blinding(b"")
+
+
+def test_cold_start_proofs_during_and_after_the_table_build(device, monkeypatch):
+    """groth16_prover_create no longer waits for the window tables (ug_prover_tables_ready): proofs that arrive while they are
+    built use the classic windows beside the table kernels, the first one that finds them built switches over; every proof is
+    the oracle's, the two scalar mixes alternate, and ULTRAGROTH_TABLES_BG=0 keeps the old blocking create"""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    from oracle import closed_form
+    zkey, wtns, info = synth.build_circuit(device, 20, mix="U")
+    wtns2 = synth.build_witness(20, "C")
+    r, s = fixed_rs()
+    ri, si = int.from_bytes(r, "little"), int.from_bytes(s, "little")
+    exp = [closed_form.groth16_expected(zkey, w, synth.SEEDS, synth.g1_generator_record(), synth.g2_generator_record(), ri, si) for w in (wtns, wtns2)]
+    with ug.Groth16Prover(zkey) as p:
+        during = 0
+        k = 0
+        while True:
+            ready = p.tables_ready()
+            assert _fixed(ug, r + s, lambda: p.prove((wtns, wtns2)[k % 2])) == exp[k % 2], (k, ready)
+            k += 1
+            during += 0 if ready else 1
+            if ready and k >= 4:
+                break
+            assert k < 400
+        assert p.tables_ready()
+        for k in range(4):                                           # ... and on the tables
+            assert _fixed(ug, r + s, lambda: p.prove((wtns, wtns2)[k % 2])) == exp[k % 2]
+        assert during >= 1                                           # (the build takes ~0.15 s at this size, a classic proof ~15 ms)
+    monkeypatch.setenv("ULTRAGROTH_TABLES_BG", "0")
+    with ug.Groth16Prover(zkey) as p:
+        assert p.tables_ready()                                      # create waited
+        assert _fixed(ug, r + s, lambda: p.prove(wtns)) == exp[0]
+    # a prover that is destroyed while its tables are still being built
+    monkeypatch.delenv("ULTRAGROTH_TABLES_BG")
+    ug.Groth16Prover(zkey).close()
+    with ug.Groth16Prover(zkey) as p:
+        p.tables_ready(wait=True)
+        assert _fixed(ug, r + s, lambda: p.prove(wtns2)) == exp[1]

@@ -212,6 +212,14 @@ class _ProverBase:
         load().ug_prover_last_upload_ms(self._h, C.byref(a))
         return a.value
 
+    def tables_ready(self, wait=False):
+        """ug_prover_tables_ready: True once the fixed-base window tables (built in the background after create) are in use;
+        wait=True blocks until they are"""
+        rc = load().ug_prover_tables_ready(self._h, 1 if wait else 0)
+        if rc < 0:
+            raise ProverError(PROVER_ERROR, "ug_prover_tables_ready failed")
+        return rc == 1
+
     def close(self):
         if getattr(self, "_h", None):
             getattr(load(), self._destroy)(self._h)

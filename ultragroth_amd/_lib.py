@@ -25,7 +25,7 @@ INNER_SYMBOLS = [
     "ug_fr_ntt", "ug_field_op", "ug_synth_points", "ug_ctx_timings", "ug_ctx_kernel_stats", "ug_ctx_abandon", "ug_test_inject_fault",
     "ug_bases_create_group_g1", "ug_bases_members", "ug_points_all_infinity", "ug_msm_group_enqueue", "ug_dvec_device_ptr", "ug_dvec_copy", "ug_sort_plan",
     "ug_bases_drop_tables", "ug_bases_table_window", "ug_schedule_trim", "ug_ctx_trim",
-    "ug_ctx_background_tables", "ug_bases_tables_ready",
+    "ug_ctx_defer_tables", "ug_bases_tables_step", "ug_bases_tables_ready",
     "ug_graph_begin", "ug_graph_end", "ug_graph_abort", "ug_graph_valid", "ug_graph_nodes", "ug_graph_launch", "ug_graph_destroy",
 ]
 VERIFIER_SYMBOLS = ["groth16_verify", "ultra_groth_verify"]        # include/verifier.h
@@ -41,7 +41,7 @@ OUTER_SYMBOLS = [
     "groth16_prover_zkey_file", "ultra_groth_prover_zkey_file",
     "ug_registry_create", "ug_registry_load", "ug_registry_load_file", "ug_registry_prove", "ug_registry_evict", "ug_registry_info",
     "ug_registry_destroy",
-    "ug_test_set_blinding", "ug_prover_last_timings", "ug_prover_kernel_stats", "ug_prover_last_upload_ms",
+    "ug_test_set_blinding", "ug_prover_last_timings", "ug_prover_kernel_stats", "ug_prover_last_upload_ms", "ug_prover_tables_ready",
     "ug_groth16_prover_create_sharded", "ug_groth16_prover_create_sharded_range", "ug_groth16_prover_create_sharded_slices",
     "ug_groth16_shard_ranges", "ug_groth16_balanced_witness_range", "ug_groth16_prover_load_witness_part",
     "ug_groth16_shard_layout", "ug_groth16_prover_create_sharded_layout",
@@ -190,6 +190,7 @@ def load():
     L.ug_prover_last_timings.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ug_prover_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_double), pull, pull, C.c_int]
     L.ug_prover_last_upload_ms.argtypes = [vp, C.POINTER(C.c_double)]
+    L.ug_prover_tables_ready.argtypes = [vp, C.c_int]
     L.ug_registry_create.argtypes = [pp, C.c_int, ull, vp, ull]
     L.ug_registry_load.argtypes = [vp, C.c_char_p, vp, ull, vp, ull]
     L.ug_registry_load_file.argtypes = [vp, C.c_char_p, vp, ull]

@@ -244,7 +244,8 @@ void convert_points_g1(u32* pts, u64 n, hipStream_t stream);
 void convert_points_g2(u32* pts, u64 n, hipStream_t stream);
 
 // pts = `tables` tables of n records, table 0 filled: table j = 2^(c j) * table 0 (fixed-base window tables)
-void build_window_tables(bool g2, u32* pts, u64 n, int c, int tables, hipStream_t stream);
+// (first, count: only the tables of the points [first, first + count) -- one piece of a deferred build; default: all of them)
+void build_window_tables(bool g2, u32* pts, u64 n, int c, int tables, hipStream_t stream, u64 first = 0, u64 count = ~(u64)0);
 
 // bench / test tooling: out[i] = (seed + i) * G as zkey-format records (device buffer); G given as a host record
 void synth_points(bool g2, u32* out_dev, const u32* gen_record_host, u64 seed, u64 n, hipStream_t stream);

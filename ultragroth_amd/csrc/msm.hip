@@ -680,10 +680,12 @@ __global__ void interleave_records_kernel(u32* __restrict__ dst, const u32* __re
 // pts holds `tables` tables of n affine records; table 0 is given, table j = 2^(c j) * table 0. A lane carries K
 // consecutive points through c doublings per table and shares one field inversion among them for the conversion
 // back to affine (Montgomery's trick); infinity stays (0,0) in every table.
+// (the launch covers the points [first, end) of the n: a whole set at once, or one piece of a deferred build)
 template <class Cfg, int K>
-__global__ __launch_bounds__(128) void window_tables_kernel(u32* pts, u64 n, int c, int tables) {
+__global__ __launch_bounds__(128) void window_tables_kernel(u32* pts, u64 n_all, int c, int tables, u64 first, u64 end) {
     typedef typename Cfg::F F;
-    const u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * K;
+    const u64 i0 = first + ((u64)blockIdx.x * blockDim.x + threadIdx.x) * K;
+    const u64 n = end;                     // lanes stop at the piece's end; the tables' stride is n_all
     if (i0 >= n) return;
     F x[K], y[K];
     bool live[K];
@@ -702,7 +704,7 @@ __global__ __launch_bounds__(128) void window_tables_kernel(u32* pts, u64 n, int
         F irun = inv(run);                                               // 1 / prod zzz_k
         StaticFor<0, K>::down([&](auto k) {
             if (i0 + k >= n) return;
-            u32* o = pts + ((u64)j * n + i0 + k) * Cfg::AFF_WORDS;
+            u32* o = pts + ((u64)j * n_all + i0 + k) * Cfg::AFF_WORDS;
             if (live[k]) {
                 F izzz = mulk<8>(irun, pre[k]);                          // 1 / zzz_k
                 irun = mulk<8>(irun, p[k].zzz);
@@ -1302,12 +1304,15 @@ void synth_points(bool g2, u32* out_dev, const u32* gen_record_host, u64 seed, u
     else synth_points_run<G1Cfg>(out_dev, gen_record_host, seed, n, stream);
 }
 
-void build_window_tables(bool g2, u32* pts, u64 n, int c, int tables, hipStream_t stream) {
+void build_window_tables(bool g2, u32* pts, u64 n, int c, int tables, hipStream_t stream, u64 first, u64 count) {
     if (!n || tables < 2) return;
+    if (first > n) first = n;
+    const u64 end = count > n - first ? n : first + count, m = end - first;
+    if (!m) return;
     if (g2) {
-        hipLaunchKernelGGL((window_tables_kernel<G2Cfg, 2>), dim3((unsigned)(((n + 1) / 2 + 127) / 128)), dim3(128), 0, stream, pts, n, c, tables);
+        hipLaunchKernelGGL((window_tables_kernel<G2Cfg, 2>), dim3((unsigned)(((m + 1) / 2 + 127) / 128)), dim3(128), 0, stream, pts, n, c, tables, first, end);
     } else {
-        hipLaunchKernelGGL((window_tables_kernel<G1Cfg, 4>), dim3((unsigned)(((n + 3) / 4 + 127) / 128)), dim3(128), 0, stream, pts, n, c, tables);
+        hipLaunchKernelGGL((window_tables_kernel<G1Cfg, 4>), dim3((unsigned)(((m + 3) / 4 + 127) / 128)), dim3(128), 0, stream, pts, n, c, tables, first, end);
     }
     UG_KERNEL_CHECK();
 }

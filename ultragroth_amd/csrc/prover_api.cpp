@@ -348,6 +348,9 @@ thread_local bool g_oneShotProver = false;      // create + one prove + destroy 
 
 thread_local bool g_registryCreate = false;     // the resident multi-circuit prover decides about tables itself, after create
 
+thread_local bool g_deferTables = false;        // set around groth16_prover_create's constructor call: the one prover that may hand out
+                                                // proofs before its window tables exist (every caller of it goes through proveTurn)
+
 // what the tables of all groups would take (0: no group qualifies) and the schedule workspace they imply
 uint64_t tablesNeed(const std::vector<TableGroup>& groups, std::vector<int>& width, uint64_t* workspaceOut) {
     uint64_t need = 0, workspace = (uint64_t)2 << 30;
@@ -475,6 +478,7 @@ struct ProverBase {        // what the extern "C" layer stores behind the opaque
     uint64_t tableBytes = 0;
     virtual std::vector<TableGroup> tableGroups() = 0;
     uint64_t tablesWouldTake() { std::vector<TableGroup> g = tableGroups(); std::vector<int> w; return tablesNeed(g, w, nullptr); }
+    virtual bool tablesReady(bool /*wait*/) { return true; }       // (provers that build their tables in the background override)
     bool buildTables(uint64_t limit) {
         if (tableBytes) return true;
         std::lock_guard<std::mutex> turn(proveMutex);
@@ -483,6 +487,7 @@ struct ProverBase {        // what the extern "C" layer stores behind the opaque
         return tableBytes != 0;
     }
     void dropTables() {
+        tablesReady(true);
         std::lock_guard<std::mutex> turn(proveMutex);
         std::vector<TableGroup> g = tableGroups();
         for (auto& grp : g) {
@@ -650,6 +655,16 @@ private:
         }
 
         ugCheck(ug_ctx_create(&d_.ctx, device));
+        // COLD START: the prover groth16_prover_create makes does not wait for its window tables. Create returns
+        // after the 0.25 s of uploads; a thread of the prover (tableBuilder) then builds the tables in pieces of ~10 ms of device
+        // time, each under the prover's turn, and steps back whenever a caller wants the turn: proofs that arrive meanwhile use
+        // the classic windows on table 0 (which the upload filled) and wait for one piece at most; when the last piece is done
+        // the widths become the prover's (under the turn: a proof boundary). ULTRAGROTH_TABLES_BG=0 builds them inside create as
+        // rounds 1-4 did; sharded ranks and phase callers always get that form (they hold no turn the builder could share).
+        {
+            const char* bg = getenv("ULTRAGROTH_TABLES_BG");
+            bgTables_ = g_deferTables && count == 1 && !haveLayout_ && !src.sliced && !(bg && bg[0] == '0');
+        }
         // the H branch (coefficient mat-vec, NTT chains, h schedule, H MSM) gets its own stream. ULTRAGROTH_H_PRIORITY = h | n | l
         // gives it a stream priority class (ug_ctx_create_priority). Measured on MI355X / ROCm 7.2 (tools/run_r3_order.sh, rank 0 of
         // an 8-way shard at 2^24): the class changes NOTHING -- a chain queued beside the witness products takes 17.4 ms with the
@@ -678,6 +693,10 @@ private:
         groupG1_ = fusedGroups() && !anyEmpty;
         std::vector<int> ahead = planTableWidthsAhead(d_.ctx, tableGroups(), otherBytes);
         bool withTables = true;
+        if (bgTables_ && (ahead[0] || ahead[1])) {
+            ugCheck(ug_ctx_defer_tables(d_.ctx, 1));
+            ugCheck(ug_ctx_defer_tables(d_.ctx2, 1));
+        } else bgTables_ = false;
         auto create = [&](ug_ctx* ctx, bool g2, const uint8_t* pts, uint64_t n, uint64_t first, int width, ug_bases** out) {
             if (width && withTables) {
                 int rc = g2 ? ug_bases_create_tables_g2(ctx, pts, n, first, width, out) : ug_bases_create_tables_g1(ctx, pts, n, first, width, out);
@@ -686,6 +705,7 @@ private:
             }
             ugCheck(g2 ? ug_bases_create_g2(ctx, pts, n, first, out) : ug_bases_create_g1(ctx, pts, n, first, out));
         };
+        traceStep("create: contexts made, coefficient matrix resident (background tables), point sets next");
         if (groupG1_) {
             // A, B1 and C (with its index shift folded into the slot numbers) as one interleaved group
             const void* hosts[3] = {pA, pB1, pC};
@@ -700,10 +720,13 @@ private:
             create(d_.ctx, false, pA, nw, wr_.lo, ahead[0], &d_.A);
             create(d_.ctx, false, pB1, nw, wr_.lo, ahead[0], &d_.B1);
         }
+        traceStep("create: G1 sets of the witness uploaded");
         create(d_.ctx, true, pB2, nw, wr_.lo, ahead[0], &d_.B2);
+        traceStep("create: B2 uploaded");
         if (!d_.G) create(d_.ctx, false, pC, cHi - cLo, cLo, ahead[0], &d_.C);
         const bool group0 = withTables && ahead[0];
         create(d_.ctx2, false, pH, nh, hr_.lo, ahead[1], &d_.H);
+        traceStep("create: H uploaded");
         const bool group1 = withTables && ahead[1];
         if (ahead[0] && !group0) {
             for (ug_bases* b : {d_.G, d_.A, d_.B1, d_.B2, d_.C}) if (b) ug_bases_drop_tables(b);
@@ -713,7 +736,8 @@ private:
         if (group0) tableBytes += (d_.G ? ug_bases_tables_bytes(3 * nw, 0, tableW_) : ug_bases_tables_bytes(nw, 0, tableW_) * 2 + ug_bases_tables_bytes(cHi - cLo, 0, tableW_)) +
                                   ug_bases_tables_bytes(nw, 1, tableW_);
         if (group1) tableBytes += ug_bases_tables_bytes(nh, 0, tableH_);
-        if (haveHpoly_) ugCheck(ug_hpoly_create(d_.ctx2, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
+        if (bgTables_) { pendingW_.store(tableW_); pendingH_.store(tableH_); tableW_ = tableH_ = 0; }     // classic windows until tableBuilder() has finished them
+        if (haveHpoly_ && !d_.hp) ugCheck(ug_hpoly_create(d_.ctx2, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
         ugCheck(ug_dvec_create(d_.ctx, M, &d_.w));
         wCur_ = d_.w;
         witness_.attach(d_.ctx, M, &d_.w, &d_.w2);
@@ -728,11 +752,63 @@ private:
             if (layout_.sp.lo > layout_.sp.hi || layout_.sp.hi > M) throw std::invalid_argument("special-bucket range outside [0, nVars]");
             ugCheck(ug_schedule_set_classes(d_.sw, layout_.qLog, layout_.r0, layout_.cnt, SHARD_SPECIALS, layout_.sp.lo, layout_.sp.hi - layout_.sp.lo));
         }
-        ugCheck(ug_ctx_sync(d_.ctx));                // the table builds queued above end here: create returns a finished prover
-        ugCheck(ug_ctx_sync(d_.ctx2));
+        traceStep("create: vectors and schedules made");
+        ugCheck(ug_ctx_sync(d_.ctx));                // table builds queued by the creates above end here: a finished prover (deferred
+        ugCheck(ug_ctx_sync(d_.ctx2));               // builds have queued nothing: their thread starts now)
+        if (bgTables_) builder_ = std::thread([this] { tableBuilder(); });
+        traceStep("create: done");
     }
 
 public:
+    // ---- deferred window tables: built by this thread in pieces between the proofs (init) ----
+    // A caller that wants the turn says so (TurnRequest) and the builder stays away from the mutex meanwhile: a plain mutex
+    // would let the builder take turn after turn.
+    struct TurnRequest {
+        std::atomic<int>& n;
+        explicit TurnRequest(std::atomic<int>& n_) : n(n_) { n.fetch_add(1); }
+        ~TurnRequest() { n.fetch_sub(1); }
+    };
+    void tableBuilder() {
+        // pieces of about 10 ms: the G1 table kernel makes ~60 k points per ms, the G2 one ~20 k (2^24: 840 ms for 50 M points of
+        // the A | B1 | C group, 836 ms for 16.7 M points of B2)
+        const uint64_t pieceG1 = (uint64_t)1 << 19, pieceG2 = (uint64_t)3 << 16;
+        try {
+            for (int group = 0; group < 2; group++) {
+                ug_bases* sets[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+                if (group == 0) { if (!pendingW_.load()) continue; sets[0] = d_.G; sets[1] = d_.A; sets[2] = d_.B1; sets[3] = d_.C; sets[4] = d_.B2; }
+                else { if (!pendingH_.load()) continue; sets[0] = d_.H; }
+                for (ug_bases* b : sets) {
+                    if (!b) continue;
+                    for (;;) {
+                        while (wantTurn_.load() > 0 && !stopBuilder_.load()) std::this_thread::sleep_for(std::chrono::microseconds(50));
+                        if (stopBuilder_.load()) return;
+                        std::lock_guard<std::mutex> turn(proveMutex);
+                        uint64_t left = 0;
+                        ugCheck(ug_bases_tables_step(b, b == d_.B2 ? pieceG2 : pieceG1, &left));
+                        if (!left) break;
+                    }
+                }
+                std::lock_guard<std::mutex> turn(proveMutex);             // a proof boundary: the next proof uses the tables
+                if (group == 0) { tableW_ = pendingW_.load(); pendingW_.store(0); } else { tableH_ = pendingH_.load(); pendingH_.store(0); }
+                dropGraphs();
+                traceStep(group == 0 ? "window tables of the witness sets in use" : "window tables of H in use");
+            }
+        } catch (const std::exception& e) {
+            builderError_ = e.what();                                     // the prover stays on the classic windows
+        }
+        builderDone_.store(true);
+    }
+    void stopTableBuilder() {
+        stopBuilder_.store(true);
+        if (builder_.joinable()) builder_.join();
+    }
+    bool tablesReady(bool wait) override {
+        if (!bgTables_) return true;
+        while (wait && !builderDone_.load() && !stopBuilder_.load()) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        // (no turn taken: a query must not wait for the builder's pieces; the error string is complete once builderDone_ is set)
+        if (wait && builderDone_.load() && !builderError_.empty()) throw std::runtime_error("window tables: " + builderError_);
+        return !pendingW_.load() && !pendingH_.load();
+    }
     std::vector<TableGroup> tableGroups() override {
         std::vector<TableGroup> groups(2);
         if (d_.G || (!d_.A && groupG1_)) { groups[0].g1 = {d_.G}; groups[0].n1 = {3 * (wr_.hi - wr_.lo)}; }      // (also before the sets exist)
@@ -746,6 +822,7 @@ public:
         return groups;
     }
     void trimWorkspaces() override {
+        TurnRequest mine(wantTurn_);
         std::lock_guard<std::mutex> turn(proveMutex);
         dropGraphs();                                   // (they hold pointers into what goes now)
         ug_schedule_trim(d_.sw); ug_schedule_trim(d_.sh);
@@ -769,7 +846,8 @@ public:
         if (witnessQueued_ == 1) throw std::invalid_argument("the queued witness products still read the witness (ug_groth16_prover_witness_msm_end)");
         WitnessLease lease(witness_);
         stage(*lease, wtns, wtnsSize);
-        std::lock_guard<std::mutex> turn(proveMutex);
+        std::unique_lock<std::mutex> turn;
+        { TurnRequest mine(wantTurn_); turn = std::unique_lock<std::mutex>(proveMutex); }
         adopt(*lease);
     }
     // staging: parse the .wtns and copy the witness into the leased buffer; needs no turn on the device, only the
@@ -809,7 +887,8 @@ public:
         traceStep("witness staged");
         std::unique_lock<std::mutex> card;
         if (device) card = std::unique_lock<std::mutex>(*device);
-        std::unique_lock<std::mutex> turn(proveMutex);
+        std::unique_lock<std::mutex> turn;
+        { TurnRequest mine(wantTurn_); turn = std::unique_lock<std::mutex>(proveMutex); }
         traceStep("turn on the device");
         AroundGuard bracket(around);
         bracket.begin();
@@ -1073,6 +1152,7 @@ public:
         double a1 = 0, a2 = 0;
         uint64_t l1 = 0, l2 = 0, e1 = 0, e2 = 0;
         if (reset && !statsOn_) {                   // the statistics start here: sequences recorded without their event pairs are recorded again
+            TurnRequest mine(wantTurn_);
             std::lock_guard<std::mutex> turn(proveMutex);
             dropGraphs(/*keepWarm*/ true);
             statsOn_ = true;
@@ -1111,7 +1191,8 @@ public:
     // one whole proof (S1-S13) of the witness that is already resident (loadWitness): what prove does after its staging --
     // r and s drawn first, the multiples that need only them formed on host threads beside the device work
     void proveResident(std::string& proof, std::string& pub) override {
-        std::lock_guard<std::mutex> turn(proveMutex);
+        std::unique_lock<std::mutex> turn;
+        { TurnRequest mine(wantTurn_); turn = std::unique_lock<std::mutex>(proveMutex); }
         if (!witnessLoaded_ || !witnessComplete_) throw std::invalid_argument("no witness loaded");
         proveLoaded(proof, pub);
     }
@@ -1146,6 +1227,12 @@ private:
     static constexpr uint64_t MAX_RANGE = (uint64_t)1 << 26;       // 2^26 scalars * <= 16 windows < 2^31 entries
     uint64_t maxRange_ = MAX_RANGE;    // ULTRAGROTH_MAX_RANGE lowers it (tests: the piecewise path without a 2^27 circuit)
     int tableW_ = 0, tableH_ = 0;      // window widths of the fixed-base tables (0: classic windows), planWindowTables
+    std::atomic<int> pendingW_{0}, pendingH_{0};      // ... of tables that are still being built (tableBuilder)
+    bool bgTables_ = false;
+    std::thread builder_;
+    std::atomic<bool> stopBuilder_{false}, builderDone_{false};
+    std::atomic<int> wantTurn_{0};
+    std::string builderError_;
     int rank_, count_;
     ShardLayout layout_;               // this rank's part of a many-device layout (haveLayout_), else unused
     bool haveLayout_ = false;
@@ -1169,7 +1256,7 @@ private:
     std::vector<std::pair<const ug_dvec*, int>> warm_;
     bool statsOn_ = false;
 public:
-    ~Groth16Prover() override { dropGraphs(); }             // (before d_ goes: the graphs refer to its contexts)
+    ~Groth16Prover() override { stopTableBuilder(); dropGraphs(); }      // (before d_ goes: both refer to its contexts)
 };
 
 // =================================================================================================================
@@ -1289,7 +1376,7 @@ private:
         ugCheck(ug_bases_create_g1(d_.ctx, pFinalC, c2.hi - c2.lo, 0, &d_.C));
         ugCheck(ug_bases_create_g1(d_.ctx, pRoundC, c1.hi - c1.lo, 0, &d_.roundC));
         ugCheck(ug_bases_create_g1(d_.ctx2, pH, hr_.hi - hr_.lo, hr_.lo, &d_.H));
-        if (haveHpoly_) ugCheck(ug_hpoly_create(d_.ctx2, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
+        if (haveHpoly_ && !d_.hp) ugCheck(ug_hpoly_create(d_.ctx2, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
         ugCheck(ug_dvec_create(d_.ctx, M, &d_.w));
         wCur_ = d_.w;
         witness_.attach(d_.ctx, M, &d_.w, &d_.w2);
@@ -2099,6 +2186,7 @@ ProverBase* newUltraGrothProver(const void* zkey, unsigned long long size) {
 ProverBase* newGroth16Prover(const void* zkey, unsigned long long size) {
     const std::vector<int> devices = devicesFromEnv();
     if (devices.size() > 1) return new MultiGroth16Prover(zkey, size, devices);
+    struct Flag { Flag() { g_deferTables = true; } ~Flag() { g_deferTables = false; } } deferred;
     return new Groth16Prover(zkey, size, devices.size() == 1 ? devices[0] : deviceFromEnv(), 0, 1);
 }
 
@@ -2551,6 +2639,11 @@ int ug_prover_kernel_stats(void* prover_object, int which, double* launch_ms_avg
     if (!prover_object) return PROVER_ERROR;
     int rc = static_cast<ProverBase*>(prover_object)->kernelStats(which, launch_ms_avg, launches, units, reset);
     return rc == UG_OK ? PROVER_OK : PROVER_ERROR;
+}
+int ug_prover_tables_ready(void* prover_object, int wait) {
+    if (!prover_object) return -1;
+    try { return static_cast<ProverBase*>(prover_object)->tablesReady(wait != 0) ? 1 : 0; }
+    catch (...) { return -1; }
 }
 int ug_prover_last_upload_ms(void* prover_object, double* upload_ms) {
     if (!prover_object || !upload_ms) return PROVER_ERROR;

@@ -127,6 +127,8 @@ struct ug_ctx {
     struct QueuedMsm { MsmPending pend; void* out; bool g2; };
     std::vector<QueuedMsm> pending_msm;
     hipEvent_t order_event = nullptr;      // ug_ctx_wait
+    bool defer_tables = false;             // ug_ctx_defer_tables: sets are created with room for their window tables, which are
+                                           // then built piece by piece (ug_bases_tables_step)
     ug_graph* recording = nullptr;         // the stream is being captured into this graph (ug_graph_begin .. ug_graph_end)
     std::vector<ug_graph*> launched;       // graphs launched on this stream whose event pairs are not accounted yet (resolve_spans)
     NttPlan raw_ntt;                       // cache for ug_fr_ntt
@@ -145,25 +147,7 @@ struct ug_ctx {
     u32* pinned_results = nullptr;         // MsmStats::SLOTS result blocks of queued MSMs (ug_msm_batch)
     std::vector<void*> deferred_free;      // staging memory of queued set-up work: hipFree waits for the whole device, so it is
                                            // freed the next time the stream is idle anyway (ug_ctx_sync, destroy)
-    // BACKGROUND TABLE BUILDS (ug_ctx_background_tables): the window-table kernels of sets created on this context go to a stream
-    // of their own (lowest priority) and nothing queued on the context waits for them; a set's tables_ready event tells when its
-    // tables may be used. While one of them runs, nothing is hipFree'd on behalf of this context (hipFree waits for the device).
-    bool bg_tables = false;
-    hipStream_t build_stream = nullptr;
-    std::vector<hipEvent_t> bg_events;     // ready events of the sets created so (owned by the sets; dropped here once they have fired)
-    bool builds_running() {
-        for (size_t i = 0; i < bg_events.size();) {
-            if (hipEventQuery(bg_events[i]) == hipSuccess) bg_events.erase(bg_events.begin() + (long)i); else i++;
-        }
-        (void)hipGetLastError();
-        return !bg_events.empty();
-    }
-    void forget_build(hipEvent_t ev) { for (size_t i = 0; i < bg_events.size(); i++) if (bg_events[i] == ev) { bg_events.erase(bg_events.begin() + (long)i); return; } }
-    void free_deferred() {
-        if (deferred_free.empty() || builds_running()) return;
-        for (void* p : deferred_free) hipFree(p);
-        deferred_free.clear();
-    }
+    void free_deferred() { for (void* p : deferred_free) hipFree(p); deferred_free.clear(); }
     void use() const { UG_HIP(hipSetDevice(device)); }
 };
 struct ug_bases {
@@ -173,17 +157,8 @@ struct ug_bases {
     u64 slots = 0;            //      scalar global_first + slot (ug_bases_create_group_g1)
     bool empty = false;       // every record is the point at infinity (e.g. the B2 section of a circuit without B-side wires): its
                               // products are the point at infinity and no kernel is launched for them
-    hipEvent_t tables_ready = nullptr;      // set: the tables are (were) built in the background; fired = they may be used
-    // 1 once the tables may be read (always for a set built on its context's stream); wait: block until then
-    bool ready(bool wait) {
-        if (!tables_ready) return true;
-        if (wait) { UG_HIP(hipEventSynchronize(tables_ready)); }
-        else if (hipEventQuery(tables_ready) != hipSuccess) { (void)hipGetLastError(); return false; }
-        ctx->forget_build(tables_ready);
-        hipEventDestroy(tables_ready);
-        tables_ready = nullptr;
-        return true;
-    }
+    u64 tables_built = ~(u64)0;   // deferred build (ug_ctx_defer_tables): points [0, tables_built) have their tables; >= n: all of them
+    bool tables_usable() const { return !table_c || tables_built >= n; }
 };
 struct ug_dvec {
     ug_ctx* ctx; u64 n; u32* data; bool owns;
@@ -372,8 +347,6 @@ void ug_ctx_destroy(ug_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    if (c->build_stream) { hipStreamSynchronize(c->build_stream); hipStreamDestroy(c->build_stream); c->build_stream = nullptr; }
-    c->bg_events.clear();
     c->free_deferred();
     c->ws_g1.release(); c->ws_g2.release(); c->raw_ntt.release(); c->uploader.release();
     if (c->lookup_last) hipFree(c->lookup_last);
@@ -417,20 +390,6 @@ static bool host_all_zero(const void* p, size_t bytes) {
     for (; i < bytes; i++) if (b[i]) return false;
     return true;
 }
-// the table kernel of a freshly uploaded set: on the context's stream, or -- background builds -- on the build stream with the
-// set's ready event behind it
-static void queue_table_build(ug_ctx* c, ug_bases* b, u32* pts, u64 n, int table_c, int windows) {
-    if (!c->bg_tables) { build_window_tables(b->g2, pts, n, table_c, windows, c->stream); return; }
-    if (!c->build_stream) {
-        int least = 0, greatest = 0;
-        UG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        UG_HIP(hipStreamCreateWithPriority(&c->build_stream, hipStreamNonBlocking, least));
-    }
-    build_window_tables(b->g2, pts, n, table_c, windows, c->build_stream);
-    UG_HIP(hipEventCreateWithFlags(&b->tables_ready, hipEventDisableTiming));
-    UG_HIP(hipEventRecord(b->tables_ready, c->build_stream));
-    c->bg_events.push_back(b->tables_ready);
-}
 static int bases_create(ug_ctx* c, const void* host, u64 n, u64 global_first, bool g2, int table_c, ug_bases** out) {
     UG_TRY
     if (!c || !out || (!host && n)) throw std::invalid_argument("null argument");
@@ -456,8 +415,9 @@ static int bases_create(ug_ctx* c, const void* host, u64 n, u64 global_first, bo
                 u32* p = pts + off / 4;
                 if (g2) convert_points_g2(p, len / rec, st); else convert_points_g1(p, len / rec, st);
             }, /*fresh*/ true);
-            if (table_c) queue_table_build(c, b, pts, n, table_c, windows);
-        } catch (...) { if (b->tables_ready) { hipStreamSynchronize(c->build_stream); c->forget_build(b->tables_ready); hipEventDestroy(b->tables_ready); } hipFree(b->pts); delete b; throw; }
+            if (table_c && c->defer_tables) b->tables_built = 0;                  // (built later, in pieces: ug_bases_tables_step)
+            else if (table_c) build_window_tables(g2, pts, n, table_c, windows, c->stream);
+        } catch (...) { hipFree(b->pts); delete b; throw; }
     }
     b->table_c = table_c;
     *out = b;
@@ -513,8 +473,9 @@ int ug_bases_create_group_g1(ug_ctx* c, int members, const void* const* host, co
                 interleave_points_g1(pts, stage + off / 4, len / 64, members, m, slot0 + off / 64, st);
             }, /*fresh*/ true);
         }
-        if (table_c && b->n) queue_table_build(c, b, pts, b->n, table_c, windows);
-    } catch (...) { if (b->tables_ready) { hipStreamSynchronize(c->build_stream); c->forget_build(b->tables_ready); hipEventDestroy(b->tables_ready); } hipFree(stage); hipFree(b->pts); delete b; throw; }
+        if (table_c && b->n && c->defer_tables) b->tables_built = 0;
+        else if (table_c && b->n) build_window_tables(false, pts, b->n, table_c, windows, c->stream);
+    } catch (...) { hipFree(stage); hipFree(b->pts); delete b; throw; }
     c->deferred_free.push_back(stage);      // (not hipFree here: it would wait for the table build just queued, and the caller's next
                                             // section could no longer be uploaded beside it)
     b->table_c = table_c;
@@ -534,7 +495,6 @@ int ug_bases_precompute(ug_bases* b, int c) {
     UG_TRY
     if (!b) throw std::invalid_argument("null argument");
     if (b->table_c) throw std::invalid_argument("bases already hold window tables");
-    b->ready(true);
     MsmGeometry g = MsmGeometry::choose_tables(b->n, c);             // validates c
     if ((b->members > 1 ? b->slots : b->n) > ((u64)1 << TABLE_INDEX_BITS)) throw std::invalid_argument("window tables need at most 2^27 points per set");
     ug_ctx* ctx = b->ctx;
@@ -562,7 +522,6 @@ int ug_bases_drop_tables(ug_bases* b) {
     if (!b->table_c) return UG_OK;
     ug_ctx* ctx = b->ctx;
     ctx->use();
-    b->ready(true);                                  // (a background build of them ends first)
     UG_HIP(hipStreamSynchronize(ctx->stream));
     size_t bytes = (size_t)b->n * (b->g2 ? 128 : 64);
     u32* small = nullptr;
@@ -575,20 +534,36 @@ int ug_bases_drop_tables(ug_bases* b) {
     UG_CATCH
 }
 int ug_bases_table_window(const ug_bases* b) { return b ? b->table_c : 0; }
-int ug_ctx_background_tables(ug_ctx* c, int on) {
+// DEFERRED TABLE BUILDS (cold start of a created prover). After ug_ctx_defer_tables(ctx, 1) the sets made on the context with a
+// table width get the room for their tables and table 0, nothing else: ug_bases_tables_step builds the tables of the next
+// `max_points` points on the context's stream and WAITS for them (a bounded piece of device time: the caller interleaves the
+// pieces with proofs, which use the classic windows on table 0 until *remaining reaches 0).
+int ug_ctx_defer_tables(ug_ctx* c, int on) {
     UG_TRY
     if (!c) throw std::invalid_argument("null argument");
-    c->bg_tables = on != 0;
+    c->defer_tables = on != 0;
     UG_CATCH
 }
-// 1: the set's window tables may be used (also for a set without a background build); 0: still being built; -1: error
-int ug_bases_tables_ready(ug_bases* b, int wait) {
-    if (!b) { g_last_error = "null argument"; return -1; }
-    try {
-        b->ctx->use();
-        return b->ready(wait != 0) ? 1 : 0;
-    } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
+int ug_bases_tables_step(ug_bases* b, uint64_t max_points, uint64_t* remaining) {
+    UG_TRY
+    if (!b) throw std::invalid_argument("null argument");
+    if (b->table_c && b->tables_built < b->n) {
+        ug_ctx* c = b->ctx;
+        c->use();
+        const u64 first = b->tables_built, count = max_points < b->n - first ? max_points : b->n - first;
+        const int windows = MsmGeometry::choose_tables(b->n, b->table_c).windows;
+        // (a group is one array of n = slots * members records; a lane of the table kernel carries 4 (G1) / 2 (G2) consecutive
+        // points, so pieces start at multiples of 4)
+        const u64 take = count >= b->n - first ? b->n - first : (count + 3) / 4 * 4;
+        build_window_tables(b->g2, b->pts, b->n, b->table_c, windows, c->stream, first, take);
+        UG_HIP(hipStreamSynchronize(c->stream));
+        b->tables_built = first + take >= b->n ? ~(u64)0 : first + take;
+    }
+    if (remaining) *remaining = (b->table_c && b->tables_built < b->n) ? b->n - b->tables_built : 0;
+    UG_CATCH
 }
+// 1: a schedule with window tables may use this set (it has none to wait for, or they are complete); 0: a deferred build is not finished
+int ug_bases_tables_ready(const ug_bases* b) { return b && b->tables_usable() ? 1 : 0; }
 int ug_schedule_trim(ug_schedule* s) {
     UG_TRY
     if (!s) throw std::invalid_argument("null argument");
@@ -620,7 +595,6 @@ int ug_ctx_mem_info(ug_ctx* c, uint64_t* free_bytes, uint64_t* total_bytes) {
 void ug_bases_destroy(ug_bases* b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);
-    try { b->ready(true); } catch (...) {}
     alloc_epoch_bump();
     hipFree(b->pts);
     delete b;
@@ -899,8 +873,8 @@ static void affine_out_g2(uint8_t* out, const G2XYZZ& p) {
 
 // a schedule built for window tables needs bases that hold tables of the same width (a classic schedule reads table 0 only)
 static void check_tables(const ug_bases* b, const ug_schedule* s) {
-    if (s->sched.geo.tables && b->tables_ready && !const_cast<ug_bases*>(b)->ready(false))
-        throw std::logic_error("the window tables of this base set are still being built (ug_bases_tables_ready)");
+    if (s->sched.geo.tables && !b->tables_usable())
+        throw std::logic_error("the window tables of this base set are not complete yet (ug_bases_tables_step)");
     if (s->sched.geo.tables && s->sched.geo.c != b->table_c)
         throw std::invalid_argument("schedule built for window tables of width " + std::to_string(s->sched.geo.c) +
                                     " but the bases hold " + (b->table_c ? "tables of width " + std::to_string(b->table_c) : std::string("no tables")));
