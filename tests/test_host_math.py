@@ -163,6 +163,30 @@ def test_curve_formulas_and_exceptional_cases(hm, zkey):
         assert out2.raw == O.g2_mul(p2, k), hex(k)
 
 
+def test_shoup_product_of_the_ntt(hm):
+    """ff.hpp mul_shoup / shoup_quotient: x * w mod r for a table constant w with w' = floor(w 2^261 / r) -- the product the NTT
+    butterflies make since round 5 -- on un-normalised limb sums (four addends, limbs up to 2^31) and edge constants; the raw
+    result stays below 3r (the bound the kernel's subtraction tables and contraction rely on)"""
+    hm.ugt_fr_mul_shoup.argtypes = [C.c_void_p] * 6
+    rng = random.Random(2029)
+    R = O.R_MOD
+    out = C.create_string_buffer(32)
+    ws = [1, 2, R - 1, R - 2, (R - 1) // 2, pow(5, (R - 1) >> 20, R), pow(5, (R - 1) >> 28, R)] + [rng.randrange(1, R) for _ in range(40)]
+    for w in ws:
+        for trial in range(6):
+            if trial == 0:
+                xs = [(1 << 256) - 1] * 4                           # the largest limbs the unpacked form can hold, four times
+            elif trial == 1:
+                xs = [0, 0, 0, 0]
+            elif trial == 2:
+                xs = [R - 1, R - 1, 2 * R - 1, (1 << 256) - 1]
+            else:
+                xs = [rng.randrange(1 << 256) for _ in range(4)]
+            ok = hm.ugt_fr_mul_shoup(out, *[O.to_le(x) for x in xs], O.to_le(w))
+            assert int.from_bytes(out.raw, "little") == sum(xs) * w % R, (hex(w), trial)
+            assert ok == 1, (hex(w), trial)
+
+
 def test_segment_map_invariants(hm):
     """csrc/segmap.hpp: the cut of an MSM schedule's sorted entries into long segments and, for the last eighth, short
     ones. Every kernel of msm.hip derives positions from this map (on the device, from the number of valid entries), so

@@ -155,6 +155,82 @@ template <class P> UG_HD Fp<P> mul_add(const Fp<P>& a, const Fp<P>& b, const Fp<
     return redc<P>(c);
 }
 
+// ---- Shoup products: one operand is a TABLE constant (twiddles) --------------------------------------
+// x * w mod q for a constant w < q kept beside wq = floor(w * 2^261 / q):
+//     quot = floor(x * wq / 2^261)  (from the columns >= 7 of the product: 53 multiply-adds),
+//     r    = (x * w + quot * (2^261 - q)) mod 2^261  (low columns only: 90 multiply-adds)
+// -- 143 multiply-adds against the Montgomery product's 162 + 9 mul_lo, and the data keep whatever form they have (a value
+// x R' times a PLAIN constant w is x w R': Montgomery-form data stay Montgomery-form).
+// x: limbs below 2^31 + 2^30 (un-normalised sums are fine), value below 2^261 (~170 q). w, wq: strict limbs.
+// quot never exceeds floor(x w / q) and falls short of it by at most 2 (wq is a floor: < 1; the dropped columns 0..6 of x * wq
+// are worth < 2^-23; the floor: < 1), so the result is x w - quot q in [0, 3q), strict limbs.
+template <class P> UG_HD Fp<P> mul_shoup(const u32* x, const u32* w, const u32* wq) {
+    u64 h[NL + 1];                                   // columns 7 .. 16 of x * wq
+#pragma unroll
+    for (int k = 0; k <= NL; k++) h[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+#pragma unroll
+        for (int j = 0; j < NL; j++)
+            if (i + j >= 7) h[i + j - 7] += (u64)x[i] * wq[j];
+    }
+    u32 qt[NL];
+    u64 carry = ((h[0] >> LB) + h[1]) >> LB;
+#pragma unroll
+    for (int k = 0; k < NL - 1; k++) {
+        const u64 v = h[2 + k] + carry;
+        qt[k] = (u32)v & MASK29;
+        carry = v >> LB;
+    }
+    qt[NL - 1] = (u32)carry;
+    u64 c[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+#pragma unroll
+        for (int j = 0; j < NL; j++)
+            if (i + j < NL) c[i + j] += (u64)x[i] * w[j] + (u64)qt[i] * P::qc[j];
+    }
+    Fp<P> r;
+#pragma unroll
+    for (int k = 0; k < NL - 1; k++) {
+        r.l[k] = (u32)c[k] & MASK29;
+        c[k + 1] += c[k] >> LB;
+    }
+    r.l[NL - 1] = (u32)c[NL - 1] & MASK29;           // (modulo 2^261: the true value is below 3q < 2^256)
+    return r;
+}
+// wq = floor(w * 2^261 / q) from cm = w * 2^261 mod q (canonical: the Montgomery form of w) -- w 2^261 = wq q + cm, so
+// wq = -cm * q^-1 modulo 2^261, and wq < 2^261 makes that the value itself. cm != 0.
+template <class P> UG_HD Fp<P> shoup_quotient(const Fp<P>& cm) {
+    u32 n[NL];                                       // 2^261 - cm
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const u32 v = (0u - cm.l[i] - borrow) & MASK29;
+        borrow = (cm.l[i] + borrow) ? 1u : 0u;
+        n[i] = v;
+    }
+    u64 c[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+#pragma unroll
+        for (int j = 0; j < NL; j++)
+            if (i + j < NL) c[i + j] += (u64)n[i] * P::qinv[j];
+    }
+    Fp<P> r;
+#pragma unroll
+    for (int k = 0; k < NL - 1; k++) {
+        r.l[k] = (u32)c[k] & MASK29;
+        c[k + 1] += c[k] >> LB;
+    }
+    r.l[NL - 1] = (u32)c[NL - 1] & MASK29;
+    return r;
+}
+
 // ---- carry handling ----------------------------------------------------------------------------
 // One parallel carry pass: inputs with limbs < 2^32 (non-negative), output weak.
 template <class P> UG_HD Fp<P> norm_weak(const u32* x) {

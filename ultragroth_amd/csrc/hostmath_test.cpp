@@ -168,6 +168,30 @@ void ugt_g2_mul(uint8_t out[128], const uint8_t base[128], const uint8_t scalar[
     g2_store(out, xyzz_mul_scalar(xyzz_from_affine(x, y), k, 256));
 }
 
+// Shoup product of the NTT's twiddle multiplications (ff.hpp: mul_shoup, shoup_quotient): out = canonical((xa + xb + xc + xd) * w),
+// everything plain 32-byte integers; the four addends are summed limb-wise WITHOUT a carry pass, the un-normalised form the
+// radix-4 butterfly feeds into its second product. Also returns 1 when the raw result was below 3q, as the kernel's bounds assume.
+int ugt_fr_mul_shoup(uint8_t out[32], const uint8_t xa[32], const uint8_t xb[32], const uint8_t xc[32], const uint8_t xd[32], const uint8_t w[32]) {
+    u32 a[8], b[8], c[8], d[8], ww[8];
+    memcpy(a, xa, 32); memcpy(b, xb, 32); memcpy(c, xc, 32); memcpy(d, xd, 32); memcpy(ww, w, 32);
+    const Fr fa = unpack256<FrParams>(a), fb = unpack256<FrParams>(b), fc = unpack256<FrParams>(c), fd = unpack256<FrParams>(d);
+    u32 x[NL];
+    for (int i = 0; i < NL; i++) x[i] = fa.l[i] + fb.l[i] + fc.l[i] + fd.l[i];          // limbs up to 2^31
+    const Fr wp = unpack256<FrParams>(ww);                                             // plain, < q
+    const Fr wq = shoup_quotient(cond_sub_q(from_normal<FrParams>(ww)));
+    const Fr r = mul_shoup<FrParams>(x, wp.l, wq.l);
+    int below3q = 1;
+    {   // r < 3q ?  compare strict limbs from the top with 3q
+        u64 t[NL], carry = 0;
+        for (int i = 0; i < NL; i++) { u64 v = (u64)FrParams::q[i] * 3 + carry; t[i] = i < NL - 1 ? (v & MASK29) : v; carry = i < NL - 1 ? (v >> LB) : 0; }
+        for (int i = NL - 1; i >= 0; i--) { if (r.l[i] < t[i]) break; if (r.l[i] > t[i]) { below3q = 0; break; } if (i == 0) below3q = 0; }
+    }
+    u32 o[8];
+    pack256(o, canon(r));
+    memcpy(out, o, 32);
+    return below3q;
+}
+
 // the windowed form the provers' host parts use (ec.hpp: xyzz_mul_scalar_w4)
 void ugt_g1_mul_w4(uint8_t out[64], const uint8_t base[64], const uint8_t scalar[32]) {
     Fq x, y; u32 k[8]; memcpy(k, scalar, 32);
