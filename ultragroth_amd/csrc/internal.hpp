@@ -28,11 +28,12 @@ constexpr int NTT_MAX_PASSES = 8;
 
 struct NttPlan {
     int logn = -1;
-    u32* tw_fwd = nullptr;    // omega_n^i,   i < n/2
+    u32* tw_fwd = nullptr;    // stage-major twiddles omega_{2^(s+1)}^j (ntt.hip: 12-word Montgomery or 20-word Shoup entries)
     u32* tw_inv = nullptr;    // omega_n^-i,  i < n/2
     u32* twist = nullptr;     // n^-1 * omega_{2n}^i at place bitrev(i), i < n   (coset twist with the ifft scale folded in; in the
                               // order of the scattering pass that applies it)
     u32* ninv = nullptr;      // n^-1 (one element)
+    bool shoup = true;        // twiddle tables hold (w, floor(w 2^261 / q)) pairs and the butterflies make Shoup products (ntt.hip)
     void init(int logn, hipStream_t stream);
     void release();
     // DIT transform; see ntt.hip for the buffer rules. post / post_const are optional multipliers

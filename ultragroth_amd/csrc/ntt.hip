@@ -41,6 +41,34 @@ __device__ __forceinline__ Fr ld_twiddle(const u32* tw, size_t entry) {
     return r;
 }
 
+__device__ __forceinline__ Fr as_fr(const u32* x) { return fp_from<FrParams>(x); }
+// Shoup form of a twiddle (UG_NTT_SHOUP, the default since round 5): the PLAIN constant w beside wq = floor(w 2^261 / q), 20 words
+// (80 bytes: five aligned 16-byte loads): [w0..w7 | wq0..wq7 | w8 wq8 0 0]. x * w mod q then costs 143 multiply-adds instead of
+// the Montgomery product's 162 + 9 (ff.hpp: mul_shoup) and the data keep their Montgomery form.
+constexpr int TWS_WORDS = 20;
+struct ShoupTw { u32 w[NL], wq[NL]; };
+__device__ __forceinline__ ShoupTw ld_twiddle_shoup(const u32* tw, size_t entry) {
+    const uint4* q = reinterpret_cast<const uint4*>(tw + entry * TWS_WORDS);
+    const uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+    ShoupTw r;
+    r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w; r.w[4] = b.x; r.w[5] = b.y; r.w[6] = b.z; r.w[7] = b.w;
+    r.wq[0] = c.x; r.wq[1] = c.y; r.wq[2] = c.z; r.wq[3] = c.w; r.wq[4] = d.x; r.wq[5] = d.y; r.wq[6] = d.z; r.wq[7] = d.w;
+    r.w[8] = e.x; r.wq[8] = e.y;
+    return r;
+}
+// the twiddle product of a butterfly in either form: result strict, < 2q (Montgomery) / < 3q (Shoup)
+template <bool SHOUP> struct Twiddle;
+template <> struct Twiddle<false> {
+    Fr w;
+    __device__ __forceinline__ static Twiddle load(const u32* tw, size_t entry) { Twiddle t; t.w = ld_twiddle(tw, entry); return t; }
+    __device__ __forceinline__ Fr times(const u32* x) const { return mul(as_fr(x), w); }
+};
+template <> struct Twiddle<true> {
+    ShoupTw t;
+    __device__ __forceinline__ static Twiddle load(const u32* tw, size_t entry) { Twiddle r; r.t = ld_twiddle_shoup(tw, entry); return r; }
+    __device__ __forceinline__ Fr times(const u32* x) const { return mul_shoup<FrParams>(x, t.w, t.wq); }
+};
+
 struct PassArgs {
     const u32* in;
     u32* out;
@@ -73,19 +101,27 @@ __device__ __forceinline__ void raw_sub2q(u32* r, const u32* a, const Fr& b) {
 #pragma unroll
     for (int i = 0; i < NL; i++) r[i] = a[i] + kq[i] - b.l[i];
 }
-__device__ __forceinline__ Fr as_fr(const u32* x) { return fp_from<FrParams>(x); }
+// a + Kq - b for a product b below K q (K = 2 for Montgomery products, 3 for Shoup products)
+template <int K> __device__ __forceinline__ void raw_subkq(u32* r, const u32* a, const Fr& b) {
+    const u32* kq = kq_padded<FrParams, K>();
+#pragma unroll
+    for (int i = 0; i < NL; i++) r[i] = a[i] + kq[i] - b.l[i];
+}
 
 // One pass = k consecutive DIT stages on a tile staged in LDS (9 limb planes, conflict-free 4-byte accesses). Stages are
 // taken two at a time as radix-4 steps held in registers: 4 elements and 3 twiddles in, 4 products, 4 elements out per
 // lane -- half the LDS round trips and address arithmetic of radix-2 steps, and only ONE carry pass per element per two
 // stages: the first stage's sums stay un-normalised (limbs < 2^31 + 16, which the column sums of a product with a strict
 // twiddle still hold: 9 * 2^60 + 9 * 2^58 < 2^64). An odd k starts with one radix-2 step. Bounds in units of q: every
-// stage adds a product (< 2q) or its negation (+ 2q), so a pass of 12 stages takes a packed input (< 2^256 < 5.3 q) to
-// below 30 q; the last loop contracts to < 2.01 q for packing.
+// stage adds a product or its negation + K q -- Montgomery products are below 2q (K = 2), Shoup products below 3q (K = 3) --
+// so a pass of 10 stages takes a packed input (< 2^256 < 5.3 q) to below 36 q (Shoup; 26 q Montgomery): under the 64 q the
+// contraction of the last loop takes (to < 2.01 q for packing) and the 170 q a Shoup product's operand may have.
 // up to three transforms of the same size in one launch (blockIdx.y picks one): the three chains of the H-polynomial block
 struct PassBatch { PassArgs a[3]; };
 
+template <bool SHOUP>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassBatch batch) {
+    constexpr int KQ = SHOUP ? 3 : 2;             // the twiddle products are below KQ q
     extern __shared__ u32 lds[];
     const PassArgs& a = batch.a[blockIdx.y];
     const int E = 1 << (a.k + a.j);               // elements per workgroup
@@ -137,10 +173,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassBatch batch) 
             const u32 pos0 = lpos(e0, t), pos1 = lpos(e0 + 1, t);
             u32 x0[NL], x1[NL], y[NL];
             ld(x0, pos0); ld(x1, pos1);
-            Fr w = ld_twiddle(a.tw, twidx(0, 0, t));
-            Fr tt = mul(as_fr(x1), w);
+            const Twiddle<SHOUP> w = Twiddle<SHOUP>::load(a.tw, twidx(0, 0, t));
+            Fr tt = w.times(x1);
             raw_add(y, x0, tt); st(pos0, norm_weak<FrParams>(y));
-            raw_sub2q(y, x0, tt); st(pos1, norm_weak<FrParams>(y));
+            raw_subkq<KQ>(y, x0, tt); st(pos1, norm_weak<FrParams>(y));
         }
         __syncthreads();
         d = 1;
@@ -151,7 +187,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassBatch batch) 
     // are not: the results are WRONG) -- i.e. the instruction stream of four stages with half the LDS loads, stores, address
     // arithmetic and barriers and the same products, carry passes and twiddle loads: an upper bound of what ANY higher radix
     // can save (a real radix-16 step would also need 16 elements per lane in registers).
-    if (a.fuse_steps) {
+    if (!SHOUP && a.fuse_steps) {
         for (; d + 3 < k; d += 4) {
             for (u32 bf = tid; bf < (u32)(E >> 2); bf += nth) {
                 u32 t, p;
@@ -199,25 +235,25 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassBatch batch) 
             const u32 e0 = ((p >> d) << (d + 2)) | elow;
             const u32 p0 = lpos(e0, t), p1 = lpos(e0 + D, t), p2 = lpos(e0 + 2 * D, t), p3 = lpos(e0 + 3 * D, t);
             // twiddles first: their latency (L2 / HBM) hides behind the LDS reads
-            Fr wa = ld_twiddle(a.tw, twidx(d, elow, t));
-            Fr wb0 = ld_twiddle(a.tw, twidx(d + 1, elow, t));
-            Fr wb1 = ld_twiddle(a.tw, twidx(d + 1, elow + D, t));
+            const Twiddle<SHOUP> wa = Twiddle<SHOUP>::load(a.tw, twidx(d, elow, t));
+            const Twiddle<SHOUP> wb0 = Twiddle<SHOUP>::load(a.tw, twidx(d + 1, elow, t));
+            const Twiddle<SHOUP> wb1 = Twiddle<SHOUP>::load(a.tw, twidx(d + 1, elow + D, t));
             u32 x0[NL], x1[NL], x2[NL], x3[NL];
             ld(x0, p0); ld(x1, p1); ld(x2, p2); ld(x3, p3);
             // stage d: (x0, x1) and (x2, x3), both with wa; sums left raw
-            Fr t1 = mul(as_fr(x1), wa);
-            Fr t3 = mul(as_fr(x3), wa);
+            Fr t1 = wa.times(x1);
+            Fr t3 = wa.times(x3);
             u32 a0[NL], a1[NL], a2[NL], a3[NL];
-            raw_add(a0, x0, t1); raw_sub2q(a1, x0, t1);
-            raw_add(a2, x2, t3); raw_sub2q(a3, x2, t3);
+            raw_add(a0, x0, t1); raw_subkq<KQ>(a1, x0, t1);
+            raw_add(a2, x2, t3); raw_subkq<KQ>(a3, x2, t3);
             // stage d + 1: (a0, a2) with wb0, (a1, a3) with wb1 = wb0 * omega_4
-            Fr u2 = mul(as_fr(a2), wb0);
-            Fr u3 = mul(as_fr(a3), wb1);
+            Fr u2 = wb0.times(a2);
+            Fr u3 = wb1.times(a3);
             u32 y[NL];
             raw_add(y, a0, u2); st(p0, norm_weak<FrParams>(y));
-            raw_sub2q(y, a0, u2); st(p2, norm_weak<FrParams>(y));
+            raw_subkq<KQ>(y, a0, u2); st(p2, norm_weak<FrParams>(y));
             raw_add(y, a1, u3); st(p1, norm_weak<FrParams>(y));
-            raw_sub2q(y, a1, u3); st(p3, norm_weak<FrParams>(y));
+            raw_subkq<KQ>(y, a1, u3); st(p3, norm_weak<FrParams>(y));
         }
         __syncthreads();
     }
@@ -274,7 +310,17 @@ __global__ void power_table_kernel(u32* table, const u32* base_packed, const u32
     }
     for (int i = 0; i < POW_RUN && start + i < count; i++) {
         const Fr c = cond_sub_q(acc);
-        if (unpacked) {
+        if (unpacked == 2) {
+            // Shoup entry: the plain constant and its quotient (ld_twiddle_shoup's layout)
+            Fr lone = fp_zero<FrParams>();
+            lone.l[0] = 1;
+            const Fr wp = cond_sub_q(mul(c, lone));                    // c / 2^261: the plain value
+            const Fr wq = shoup_quotient(c);
+            u32* o = table + (start + i) * TWS_WORDS;
+#pragma unroll
+            for (int l = 0; l < 8; l++) { o[l] = wp.l[l]; o[8 + l] = wq.l[l]; }
+            o[16] = wp.l[8]; o[17] = wq.l[8]; o[18] = 0; o[19] = 0;
+        } else if (unpacked) {
             u32* o = table + (start + i) * TW_WORDS;
 #pragma unroll
             for (int l = 0; l < NL; l++) o[l] = c.l[l];
@@ -308,15 +354,23 @@ void NttPlan::init(int logn_, hipStream_t stream) {
     release();
     logn = logn_;
     // per device, and idempotent: set whenever a plan is made on the current device
-    UG_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    UG_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (1 << NTT_MAX_LOG_TILE) * NL * 4));
+    UG_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (1 << NTT_MAX_LOG_TILE) * NL * 4));
+    // twiddle products in Shoup form (tuning knob UG_NTT_SHOUP=0: the Montgomery form of rounds 1-4; both are exact)
+    {
+        const char* e = getenv("UG_NTT_SHOUP");
+        shoup = !(e && e[0] == '0');
+    }
+    const size_t tw_words = shoup ? TWS_WORDS : TW_WORDS;
     u64 n = (u64)1 << logn;
     // Stage-major twiddle tables: stage s (butterfly span 2^s) reads omega_{2^(s+1)}^j at consecutive j, so the
     // lanes of a wave touch consecutive 32-byte entries at every stage (a single table of omega_n^i indexed with a
     // stage-dependent stride makes the late stages hit one L2 channel with 64 KiB strides).
     u64 entries = n > 1 ? n - 1 : 1;
-    UG_HIP(hipMalloc(&tw_fwd, entries * TW_WORDS * 4));
-    UG_HIP(hipMalloc(&tw_inv, entries * TW_WORDS * 4));
+    UG_HIP(hipMalloc(&tw_fwd, entries * tw_words * 4));
+    UG_HIP(hipMalloc(&tw_inv, entries * tw_words * 4));
     UG_HIP(hipMalloc(&twist, n * 32));
     UG_HIP(hipMalloc(&ninv, 32));
     Fr w2n = fr_root_of_unity(logn + 1);
@@ -340,8 +394,8 @@ void NttPlan::init(int logn_, hipStream_t stream) {
     };
     for (int st = 0; st < logn; st++) {
         u64 off = ((u64)1 << st) - 1;
-        launch(tw_fwd + off * TW_WORDS, 3 + 2 * st, 2, (u64)1 << st, 1);
-        launch(tw_inv + off * TW_WORDS, 4 + 2 * st, 2, (u64)1 << st, 1);
+        launch(tw_fwd + off * tw_words, 3 + 2 * st, 2, (u64)1 << st, shoup ? 2 : 1);
+        launch(tw_inv + off * tw_words, 4 + 2 * st, 2, (u64)1 << st, shoup ? 2 : 1);
     }
     // n^-1 * omega_{2n}^i (packed: one product per element, in the last pass of the inverse transform), stored at bitrev(i):
     // that pass scatters element i to place bitrev(i) and multiplies there
@@ -433,7 +487,8 @@ void NttPlan::launch(const NttPass* const* lists, int count, int p, hipStream_t 
     int threads = E / 4 > NTT_THREADS ? NTT_THREADS : (E / 4 < 64 ? 64 : E / 4);
     size_t lds = (size_t)E * NL * 4;
     int slot = stats ? stats->begin(stream, ((u64)1 << logn) * (u64)count) : -1;
-    hipLaunchKernelGGL(ntt_pass_kernel, dim3(blocks, (unsigned)count), dim3(threads), lds, stream, b);
+    if (shoup) hipLaunchKernelGGL(ntt_pass_kernel<true>, dim3(blocks, (unsigned)count), dim3(threads), lds, stream, b);
+    else hipLaunchKernelGGL(ntt_pass_kernel<false>, dim3(blocks, (unsigned)count), dim3(threads), lds, stream, b);
     UG_KERNEL_CHECK();
     if (stats) stats->end(slot, stream);
 }
