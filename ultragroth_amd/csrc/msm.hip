@@ -748,8 +748,12 @@ __global__ __launch_bounds__(128) void synth_points_kernel(const u32* table, u64
 // chunks, i.e. half the per-chunk scalar multiples -- which are half of this kernel's work -- of a single product)
 int reduce_chunk(const MsmGeometry& g, int sets = 1, bool g2 = false) {
     static const int g2_log = getenv("UG_REDUCE_G2_LOG") ? atoi(getenv("UG_REDUCE_G2_LOG")) : 16;      // tuning knobs
-    static const int g1_log = getenv("UG_REDUCE_G1_LOG") ? atoi(getenv("UG_REDUCE_G1_LOG")) : 17;
-    const u64 lanes = (u64)1 << (g2 ? g2_log : g1_log);
+    static const int g1_log = getenv("UG_REDUCE_G1_LOG") ? atoi(getenv("UG_REDUCE_G1_LOG")) : 0;
+    // G1: 2^17 lanes, but 2^16 when the whole batch has fewer than 2^21 buckets -- a rank of an eight-way shard (three products
+    // over 2^19 buckets): there the chunks would fall to 8 buckets, and a chunk's scalar multiple is half of its work (round 5,
+    // one rank of eight at 2^24: 22.8 -> 22.3-22.5 ms per step; full-size problems keep 2^17)
+    const int g1_auto = (u64)sets * g.bucket_windows() * g.buckets < ((u64)1 << 21) ? 16 : 17;
+    const u64 lanes = (u64)1 << (g2 ? g2_log : (g1_log ? g1_log : g1_auto));
     int chunk = g.buckets < (u32)CHUNK ? (int)g.buckets : CHUNK;
     while (chunk > 8 && (u64)sets * g.bucket_windows() * (g.buckets / chunk) < lanes) chunk >>= 1;
     return chunk;
