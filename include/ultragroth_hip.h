@@ -34,6 +34,10 @@
  *                      ULTRAGROTH_DEVICES=a,b,..  one proof sharded over the listed devices behind the reference's API
  *                      ULTRAGROTH_TABLES=0|1|2    fixed-base window tables: never | created provers (default) | one-shot calls too
  *                      ULTRAGROTH_OVERLAP=0|1|2   H branch behind (default) / beside the witness products on one device
+ *                      ULTRAGROTH_TABLES_BG=0     groth16_prover_create waits for its window tables (default: returns once the zkey is
+ *                                                 resident; the tables are built in pieces between proofs, include/prover.h)
+ *                      ULTRAGROTH_GRAPH=1         the device part of a created prover's proof recorded once per witness buffer and
+ *                                                 replayed as a hipGraph (exact; measured a wash on this runtime, so off by default)
  *                      ULTRAGROTH_FUSED=0         A, B1, C as separate base sets instead of one interleaved group
  *                      ULTRAGROTH_SHARD=PxB       many-device layout: P base-point ranges x B bucket classes
  *                      ULTRAGROTH_MAX_RANGE=n     scalars per schedule (tests: the piecewise path without a 2^27 circuit)
@@ -42,6 +46,7 @@
  *                      UG_SEG_LANES_LOG, UG_SEG_TAPER   segment length of the accumulation (default 2^20 lanes, tapered end)
  *                      UG_REDUCE_G1_LOG, UG_REDUCE_G2_LOG   lanes the bucket reduction keeps busy (default 17, 16)
  *                      UG_UPLOAD_PRIORITY=l|n|h   stream class of the witness staging lanes (default l)
+ *                      UG_NTT_SHOUP=0             Montgomery-form twiddle products in the NTT passes (default: Shoup form, ff.hpp mul_shoup)
  *   test hooks         ULTRAGROTH_TEST_HOOKS=1 enables ug_test_set_blinding / ULTRAGROTH_TEST_BLINDING and ug_test_inject_fault;
  *                      without it those calls fail and the variables are ignored
  *   measurement        NOT in this library: UG_SORT=cub (library sort, links hipcub), UG_GROUP_FOLD_LOG (gathers folded into
