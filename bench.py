@@ -261,6 +261,8 @@ def measure_traffic(args, log_domain):
                 return None, "rocprofv3 --pmc %s child failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode(errors="replace")[-200:])
             dirs[counter] = d
         summary = pmc_summary.summarize(dirs["FETCH_SIZE"], dirs["WRITE_SIZE"], log_domain, how="child runs of this bench.py run, one counter each")
+        if os.environ.get("UG_BENCH_PMC_DUMP"):         # (evidence for profiles/: the summary this line's traffic figures come from)
+            json.dump(summary, open(os.environ["UG_BENCH_PMC_DUMP"], "w"), indent=1)
         return summary, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of bench.py --bare on the same workload "
                          "(%.0f s), per launch, corrected as the microarch guide says (tools/pmc_summary.py)" % (time.perf_counter() - t0))
     except Exception as e:                            # noqa: BLE001 -- the committed summary is the fallback

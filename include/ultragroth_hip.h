@@ -169,6 +169,8 @@ uint64_t ug_dvec_size(const ug_dvec* v);
 void* ug_dvec_device_ptr(const ug_dvec* v);
 /* dst[dst_first .. + count) = src[src_first .. + count) between vectors of ANY two devices of the node (blocking) */
 int  ug_dvec_copy(ug_dvec* dst, uint64_t dst_first, const ug_dvec* src, uint64_t src_first, uint64_t count);
+/* the same with the copy queued on `via`'s stream (a context of dst's device; NULL = dst's own) */
+int  ug_dvec_copy_via(ug_dvec* dst, uint64_t dst_first, const ug_dvec* src, uint64_t src_first, uint64_t count, ug_ctx* via);
 void ug_dvec_destroy(ug_dvec* v);
 
 /* Decompose scalars [first, first + count) of `scalars` (plain 32-byte integers) into signed window

@@ -738,6 +738,20 @@ def test_cli_and_api_on_several_devices(device, tmp_path, devices):
                 assert p.prove(wtns) == exp
             finally:
                 ug.set_test_blinding(b"")
+            # (round 5) the witness on a node: by default a chain rank collects the other ranks' slices from their HBM (peer copies);
+            # ULTRAGROTH_WITNESS_GATHER=0 keeps the older form, every chain rank uploading the rest itself -- read per proof
+            os.environ["ULTRAGROTH_WITNESS_GATHER"] = "0"
+            ug.set_test_blinding(r + s)
+            try:
+                assert p.prove(wtns) == exp
+            finally:
+                ug.set_test_blinding(b"")
+                del os.environ["ULTRAGROTH_WITNESS_GATHER"]
+            ug.set_test_blinding(r + s)
+            try:
+                assert p.prove(wtns) == exp
+            finally:
+                ug.set_test_blinding(b"")
         os.environ["ULTRAGROTH_DEVICES"] = "0,x"
         with pytest.raises(ug.ProverError, match="ULTRAGROTH_DEVICES"):
             ug.Groth16Prover(zkey)

@@ -1222,6 +1222,14 @@ public:
     }
     ug_ctx* ctx() override { return d_.ctx; }
     ug_ctx* ctx2() { return d_.ctx2; }              // the H branch's context (its stream orders hpolyChain / hpolyCombine / runHMsm)
+    // a many-device prover collects a chain rank's witness from its peers: the vector the device part reads, this rank's range of
+    // it, and the word that the rest has arrived (on the H branch's stream, as loadWitnessPart(.., 1) leaves it)
+    ug_dvec* witnessVec() { return wCur_; }
+    Range witnessRange() const { return wr_; }
+    void witnessGathered() {
+        if (!witnessLoaded_) throw std::invalid_argument("the rank's own part of the witness comes first");
+        witnessComplete_ = true;
+    }
 
 private:
     static constexpr uint64_t MAX_RANGE = (uint64_t)1 << 26;       // 2^26 scalars * <= 16 windows < 2^31 entries
@@ -1920,7 +1928,7 @@ public:
         BinFile f(zkey, zkeySize, "zkey", 1);
         ZkeyHeader h = loadZkeyHeader(f, false);
         if (!h.rIsBn254) throw std::invalid_argument("zkey curve not supported");
-        nPublic_ = h.nPublic; domain_ = h.domainSize;
+        nPublic_ = h.nPublic; domain_ = h.domainSize; nVars_ = h.nVars;
         // the layout (shardLayouts): base-point ranges, unless ULTRAGROTH_SHARD asks for bucket classes (PxB, or auto: when the
         // tables of a group's range fit the devices, asked from the first one); if a class rank then cannot build its tables after
         // all, everything is created once more with base-point ranges
@@ -1991,21 +1999,54 @@ public:
         std::promise<void> chainDone[3];
         std::shared_future<void> chainReady[3];
         for (int c = 0; c < 3; c++) chainReady[c] = chainDone[c].get_future().share();
+        // THE WITNESS ON A NODE: every rank copies its own slice of the scalars over its own PCIe link (all links at once); a
+        // chain rank, whose mat-vec reads the WHOLE witness, then collects the other slices from its peers' HBM over xGMI
+        // (ug_dvec_copy_via: hipMemcpyPeerAsync) instead of pulling all of it through its one link -- 512 MiB at 2^24: 9.4 ms by
+        // PCIe, ~1.3 ms for seven 64 MiB pieces over seven links. The ranks' ranges tile the witness in rank order (base-point
+        // layouts), or repeat inside a group (bucket classes): pieces already covered are skipped. ULTRAGROTH_WITNESS_GATHER=0
+        // keeps the round-4 form (a chain rank uploads the rest itself).
+        const char* wg = getenv("ULTRAGROTH_WITNESS_GATHER");
+        const bool gather = R > 1 && !(wg && wg[0] == '0');
+        std::vector<std::promise<void>> sliceUp(R);
+        std::vector<std::shared_future<void>> sliceReady(R);
+        for (int k = 0; k < R; k++) sliceReady[k] = sliceUp[k].get_future().share();
         {
             std::vector<std::thread> th;
             for (int k = 0; k < R; k++)
                 th.emplace_back([&, k] {
                     Groth16Prover& p = *ranks_[k];
                     bool told[3] = {false, false, false};
+                    bool toldSlice = false;
                     try {
                         p.loadWitnessPart(wtns, wtnsSize, 0);
+                        toldSlice = true;
+                        sliceUp[k].set_value();
                         // with many ranks most of them wait for the chains: a chain rank then runs its chain first, alone (a
                         // chain beside the products gets ~40 % of the chip whatever the stream priorities say, 17 ms instead of
                         // 7 at 2^24 / 8 ranks); with few ranks it runs beside the products (bench.py: UG_BENCH_CHAIN_ORDER)
                         const bool chainFirst = R >= 5;
                         if (!chainFirst) p.witnessMsmBegin();
                         if (k < 3) {                                       // chains k, k + R, ... of the three
-                            p.loadWitnessPart(wtns, wtnsSize, 1);
+                            if (gather) {
+                                uint64_t covered = 0;                      // [0, covered) of the witness is on this rank or on its way
+                                const Range mine = p.witnessRange();
+                                for (int q = 0; q < R; q++) {
+                                    const Range w = q == k ? mine : ranks_[q]->witnessRange();
+                                    const uint64_t lo = std::max(w.lo, covered);
+                                    if (w.hi <= lo) continue;
+                                    if (q != k && !(lo >= mine.lo && w.hi <= mine.hi)) {
+                                        sliceReady[q].get();               // (a peer's failed upload is rethrown here)
+                                        // the part of it this rank does not hold itself
+                                        const uint64_t a = lo, b = w.hi;
+                                        const uint64_t a1 = std::min(b, std::max(a, mine.lo)), b1 = std::max(a, std::min(b, mine.hi));
+                                        if (a1 > a) ugCheck(ug_dvec_copy_via(p.witnessVec(), a, ranks_[q]->witnessVec(), a, a1 - a, p.ctx2()));
+                                        if (b > b1) ugCheck(ug_dvec_copy_via(p.witnessVec(), std::max(b1, a), ranks_[q]->witnessVec(), std::max(b1, a), b - std::max(b1, a), p.ctx2()));
+                                    }
+                                    covered = std::max(covered, w.hi);
+                                }
+                                if (covered < nVars_) throw std::logic_error("the ranks' witness ranges do not cover the witness");
+                                p.witnessGathered();
+                            } else p.loadWitnessPart(wtns, wtnsSize, 1);
                             for (int c = k; c < 3; c += R) {
                                 p.hpolyChain(c, ug_dvec_device_ptr(full_[c]));
                                 told[c] = true;
@@ -2024,7 +2065,8 @@ public:
                         memcpy(parts[k].data() + 320, hpart + 320, 64);
                     } catch (...) {
                         errs[k] = std::current_exception();
-                        for (int c = k; c < 3; c += R)                     // nobody may wait for a chain that will not come
+                        if (!toldSlice) sliceUp[k].set_exception(errs[k]);  // nobody may wait for a slice or a chain that will not come
+                        for (int c = k; c < 3; c += R)
                             if (k < 3 && !told[c]) chainDone[c].set_exception(errs[k]);
                         p.witnessMsmAbandon();
                     }
@@ -2061,6 +2103,7 @@ private:
     ug_dvec* full_[3] = {nullptr, nullptr, nullptr};
     std::vector<Slices> slices_;
     uint32_t nPublic_ = 0, domain_ = 0;
+    uint64_t nVars_ = 0;
     double msm_ = 0, fft_ = 0, total_ = 0;
 };
 

@@ -2,6 +2,8 @@
 // Owns device memory, the stream and the reusable workspaces; translates between the reference's byte
 // formats and the device forms; catches every exception at the boundary.
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -228,6 +230,13 @@ void fault_point(int site) {
     g_fault_site.store(0);
     throw std::runtime_error("injected fault (test hook) at site " + std::to_string(site));
 }
+// ULTRAGROTH_TRACE=1: where the host time of the set-up calls goes (stderr, ms of a process-wide clock)
+void trace_step(const char* what) {
+    static const bool on = getenv("ULTRAGROTH_TRACE") && atoi(getenv("ULTRAGROTH_TRACE")) != 0;
+    if (!on) return;
+    static const auto origin = std::chrono::steady_clock::now();
+    fprintf(stderr, "[ug_api] %9.3f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - origin).count(), what);
+}
 struct ScopedTimer {       // stream time between construction and stop() goes to *acc -- later: see ug_ctx::Span
     ug_ctx* c; ug_ctx::Span span; bool stopped = false, captured = false;
     ScopedTimer(const ScopedTimer&) = delete;
@@ -452,6 +461,7 @@ int ug_bases_create_group_g1(ug_ctx* c, int members, const void* const* host, co
     u64 most = 0;
     for (int m = 0; m < members; m++) most = n[m] > most ? n[m] : most;
     u32* stage = nullptr;
+    trace_step("group: allocating");
     if (hipMalloc(&b->pts, bytes ? bytes * (size_t)windows : 4) != hipSuccess || hipMalloc(&stage, most ? (size_t)most * 64 : 4) != hipSuccess) {
         (void)hipGetLastError();
         if (b->pts) hipFree(b->pts);
@@ -459,12 +469,15 @@ int ug_bases_create_group_g1(ug_ctx* c, int members, const void* const* host, co
         throw std::runtime_error(table_c ? "not enough device memory for the window tables" : "not enough device memory for the base points");
     }
     try {
+        trace_step("group: allocated");
         if (bytes) {
             UG_HIP(hipMemsetAsync(b->pts, 0, bytes, c->stream));            // slots without a point: infinity
             UG_HIP(hipStreamSynchronize(c->stream));
         }
+        trace_step("group: table 0 cleared");
         u32* pts = b->pts;
         for (int m = 0; m < members; m++) {
+            trace_step("group: member upload");
             // chunks of whole records: converted to the device form and moved to their slots behind their own DMA
             if (!n[m]) continue;
             const u64 slot0 = first[m] - group_first;
@@ -756,11 +769,17 @@ void* ug_dvec_device_ptr(const ug_dvec* v) { return v ? v->data : nullptr; }
 // xGMI, or through the host when peer access is not there: hipMemcpyPeer decides). Blocking; both vectors' earlier work must be
 // complete (the phase calls that produce them are).
 int ug_dvec_copy(ug_dvec* dst, uint64_t dst_first, const ug_dvec* src, uint64_t src_first, uint64_t count) {
+    return ug_dvec_copy_via(dst, dst_first, src, src_first, count, nullptr);
+}
+// the same with the copy queued on `via`'s stream (a context of dst's device; NULL = dst's own): the witness of a chain rank is
+// collected from its peers on the H branch's stream while its witness products are queued on the other
+int ug_dvec_copy_via(ug_dvec* dst, uint64_t dst_first, const ug_dvec* src, uint64_t src_first, uint64_t count, ug_ctx* via) {
     UG_TRY
     if (!dst || !src) throw std::invalid_argument("null argument");
     if (dst_first + count > dst->n || src_first + count > src->n) throw std::invalid_argument("copy outside the vectors");
     if (!count) return UG_OK;
-    ug_ctx* c = dst->ctx;
+    ug_ctx* c = via ? via : dst->ctx;
+    if (c->device != dst->ctx->device) throw std::invalid_argument("copy context on another device than the destination");
     c->use();
     const size_t bytes = (size_t)count * 32;
     if (src->ctx->device == c->device)
