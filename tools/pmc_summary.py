@@ -40,6 +40,7 @@ def summarize(fetch_dir, write_dir, log, how="separate passes, tools/run_r4_prof
         if fetch.get(k, 0) + write.get(k, 0) < 1024:          # below 1 MB per launch
             continue
         name = k.replace("<false, 4>", "<false>").replace("<true, 4>", "<true>")
+        name = name.replace("ntt_pass_kernel<true>", "ntt_pass_kernel").replace("ntt_pass_kernel<false>", "ntt_pass_kernel")    # (Shoup / Montgomery form)
         dbl = any(name.startswith(p) or p in name for p in DOUBLED)
         out[log][name] = {"fetch": int(fetch.get(k, 0) * 1024 * (2 if dbl else 1)), "write": int(write.get(k, 0) * 1024),
                           "fetch_raw_kb": fetch.get(k, 0), "write_raw_kb": write.get(k, 0), **({"fetch_doubled": True} if dbl else {})}
