@@ -336,6 +336,26 @@ def bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_r
             msm_ms += m
             fft_ms += f
         elapsed = time.perf_counter() - t0                 # THE timed region: K whole calls, one after the other
+        # the region ran in the library's default configuration (the H branch of the final round beside its witness products:
+        # stream times of the two parts stretch and overlap); the MSM | FFT split of the metric comes from K more calls with the
+        # branch behind the products
+        unoverlapped_ms = None
+        if os.environ.get("ULTRAGROTH_OVERLAP", "1") != "0":
+            keep = os.environ.get("ULTRAGROTH_OVERLAP")
+            os.environ["ULTRAGROTH_OVERLAP"] = "0"
+            prover.prove(uwtns)
+            msm_ms = fft_ms = 0.0
+            tc = time.perf_counter()
+            for _ in range(args.steps):
+                prover.prove(uwtns)
+                m, f, _ = prover.last_timings()
+                msm_ms += m
+                fft_ms += f
+            unoverlapped_ms = 1e3 * (time.perf_counter() - tc) / args.steps
+            if keep is None:
+                del os.environ["ULTRAGROTH_OVERLAP"]
+            else:
+                os.environ["ULTRAGROTH_OVERLAP"] = keep
         pipelined_s = None
         if args.host_threads > 1:
             # an extra figure, as on the Groth16 line: the K calls from several host threads on the one prover object (the .uwtns
@@ -373,7 +393,11 @@ def bench_ultra(args, dev, ug, synth, torch, dist, backend, rank, world, local_r
             ok = got == expected()
             workload += " [check: %s]" % ("bit-exact" if ok else "MISMATCH")
         line(elapsed, msm_ms, fft_ms, create_s, "one GPU", pipelined_proofs_per_s=(args.steps / pipelined_s) if pipelined_s else None,
-             pipelined_host_threads=max(1, args.host_threads) if pipelined_s else None)
+             pipelined_host_threads=max(1, args.host_threads) if pipelined_s else None, unoverlapped_ms_per_step=unoverlapped_ms,
+             split_region=("device time of the MSM and FFT parts of K more calls with the H branch behind the witness products (ULTRAGROTH_OVERLAP=0)"
+                           if unoverlapped_ms else "device time of the MSM and FFT parts of the K timed calls"),
+             value_definition="K / wall time of K ultra_groth_prover_prove calls (src/prover.h), .uwtns in host memory, one after the other; "
+                              "library switches: ULTRAGROTH_OVERLAP=%s" % os.environ.get("ULTRAGROTH_OVERLAP", "1 (default)"))
         if not ok:
             sys.exit(3)
         return

@@ -33,7 +33,8 @@
  *   deployment         ULTRAGROTH_DEVICE=n        device of a prover made by the reference's create calls (default 0)
  *                      ULTRAGROTH_DEVICES=a,b,..  one proof sharded over the listed devices behind the reference's API
  *                      ULTRAGROTH_TABLES=0|1|2    fixed-base window tables: never | created provers (default) | one-shot calls too
- *                      ULTRAGROTH_OVERLAP=0|1|2   H branch behind (default) / beside the witness products on one device
+ *                      ULTRAGROTH_OVERLAP=0|1|2   H branch behind / beside (default since round 5) the witness products on one device
+ *                                                 (0: one kernel on the chip at a time, for clean per-kernel times)
  *                      ULTRAGROTH_TABLES_BG=0     groth16_prover_create waits for its window tables (default: returns once the zkey is
  *                                                 resident; the tables are built in pieces between proofs, include/prover.h)
  *                      ULTRAGROTH_GRAPH=1         the device part of a created prover's proof recorded once per witness buffer and

@@ -1077,11 +1077,12 @@ public:
             collectTimings(3);
             return;
         }
-        // ULTRAGROTH_OVERLAP: 0 (default) the second stream waits for the first; 1 no edge at all; 2 the G2 product goes
-        // first and the H branch's mat-vec, NTT passes and schedule run beside it, its MSM after the witness branch -- so
-        // that no two G1 accumulation launches share the chip
+        // ULTRAGROTH_OVERLAP: 1 (default since round 5: -2 % at 2^24, -9 % at 2^20) no edge between the streams: the H branch runs
+        // beside the witness products; 0 the second stream waits for the first (one kernel on the chip at a time: what a caller
+        // that wants clean per-kernel times sets, bench.py for its roofline steps); 2 the G2 product goes first and the H
+        // branch's mat-vec, NTT passes and schedule run beside it, its MSM after the witness branch
         const char* ov = getenv("ULTRAGROTH_OVERLAP");
-        const int overlap = ov ? atoi(ov) : 0;
+        const int overlap = ov ? atoi(ov) : 1;
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
         memset(runParts_, 0, sizeof runParts_);
         QueueGuard inFlight(d_.ctx, d_.ctx2);                   // from here to the collects below work is queued on both streams
@@ -1670,7 +1671,7 @@ public:
             memset(sums, 0, sizeof sums);
             queueFinalRoundProducts(sums);
             const char* ov = getenv("ULTRAGROTH_OVERLAP");
-            if (!(ov && atoi(ov) != 0)) ugCheck(ug_ctx_wait(d_.ctx2, d_.ctx));
+            if (ov && atoi(ov) == 0) ugCheck(ug_ctx_wait(d_.ctx2, d_.ctx));      // (default: beside, as for Groth16)
             ugCheck(ug_hpoly_run(d_.hp, wCur_, d_.h));
             buildSchedule(d_.sh, d_.h, hr_.lo, hr_.hi - hr_.lo, tableH_);
             const ug_bases* setH[1] = {d_.H};
