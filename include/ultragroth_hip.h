@@ -230,6 +230,12 @@ int  ug_bases_members(const ug_bases* bases);
  * base group. Stops at the first other record, i.e. at once for any real section. */
 int  ug_points_all_infinity(const void* host_points, uint64_t n, uint64_t record_bytes);
 int  ug_msm_group_enqueue(ug_ctx* ctx, const ug_bases* group, const ug_schedule* schedule, void* const* outs);
+/* The witness products of a proof in one call -- the K products of a base group and ONE G2 set over the same schedule (S1-S4,
+ * src/groth16.cpp:55-64): both accumulations back to back, then the G1 and the G2 tails (cut buckets, bucket reduction, tree sums,
+ * result copies: chains of dependent EC additions) side by side on two streams. Results as after ug_msm_group_enqueue +
+ * ug_msm_batch_enqueue: outs_group[m] (64 bytes each) and out_g2 (128 bytes) after ug_ctx_collect. */
+int  ug_msm_witness_enqueue(ug_ctx* ctx, const ug_bases* group, const ug_bases* g2set, const ug_schedule* schedule,
+                            void* const* outs_group, void* out_g2);
 int  ug_ctx_collect(ug_ctx* ctx);
 int  ug_ctx_wait(ug_ctx* waiter, ug_ctx* signal);
 /* For a caller that queued work and then failed before ug_ctx_collect: waits for what is still running on the context (the

@@ -223,12 +223,15 @@ MsmPending msm_enqueue_g2(const MsmSchedule& s, MsmWorkspace& ws, const u32* bas
 constexpr int MSM_BATCH_MAX = 4;
 void msm_enqueue_batch_g1(const MsmSchedule& s, MsmWorkspace& ws, int count, const u32* const* bases, const u64* n_bases, const int64_t* delta,
                           hipStream_t stream, MsmStats* stats, u32* const* pinned_host, MsmPending* pend);
+// phase (msm_enqueue_batch_g2, msm_enqueue_group_g1): the whole call, or its two halves made one after the other with the same
+// arguments -- the accumulation launches, and everything behind them (on a stream that is ordered behind the accumulation)
+constexpr int MSM_PHASE_ALL = 0, MSM_PHASE_ACCUMULATE = 1, MSM_PHASE_TAIL = 2;
 void msm_enqueue_batch_g2(const MsmSchedule& s, MsmWorkspace& ws, int count, const u32* const* bases, const u64* n_bases, const int64_t* delta,
-                          hipStream_t stream, MsmStats* stats, u32* const* pinned_host, MsmPending* pend);
+                          hipStream_t stream, MsmStats* stats, u32* const* pinned_host, MsmPending* pend, int phase = MSM_PHASE_ALL);
 // `members` (2 or 3) products over ONE interleaved array of members-point records (n_slots records per window table); pinned_host /
 // pend: one per member
 void msm_enqueue_group_g1(const MsmSchedule& s, MsmWorkspace& ws, int members, const u32* bases, u64 n_slots, int64_t delta, hipStream_t stream,
-                          MsmStats* stats, u32* const* pinned_host, MsmPending* pend);
+                          MsmStats* stats, u32* const* pinned_host, MsmPending* pend, int phase = MSM_PHASE_ALL);
 // 64-byte records of one member set -> record (slot0 + i) * members + member of a group array
 void interleave_points_g1(u32* dst, const u32* src, u64 n, int members, int member, u64 slot0, hipStream_t stream);
 G1XYZZ msm_collect_g1(const MsmPending& p);

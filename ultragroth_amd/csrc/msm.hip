@@ -991,9 +991,13 @@ namespace {
 constexpr int MSM_MAX_BATCH = 4;
 // group: 0 = `count` separate base arrays; K = bases[0] is ONE interleaved array of K-member records (n_bases[0] slots; count
 // == K): a single launch of segment_accumulate_group_kernel accumulates all K products
+// phase: MSM_PHASE_ALL, or the two halves of the same call made one after the other with the same arguments -- MSM_PHASE_ACCUMULATE
+// (the accumulation launches) and MSM_PHASE_TAIL (everything behind them, possibly on another stream that has been ordered behind
+// the accumulation): ug_msm_witness_enqueue runs the G1 and the G2 tails of a proof side by side
 template <class Cfg>
 void msm_enqueue_multi(const MsmSchedule& s, MsmWorkspace& ws, int count, const u32* const* bases, const u64* n_bases, const int64_t* delta,
-                       hipStream_t stream, MsmStats* stats, u32* const* pinned_host, MsmPending* pend, int group = 0) {
+                       hipStream_t stream, MsmStats* stats, u32* const* pinned_host, MsmPending* pend, int group = 0, int phase = MSM_PHASE_ALL) {
+    const bool do_acc = phase != MSM_PHASE_TAIL, do_tail = phase != MSM_PHASE_ACCUMULATE;
     typedef typename Cfg::F F;
     const MsmGeometry& g = s.geo;
     if (count < 1 || count > MSM_MAX_BATCH) throw std::logic_error("msm: batch size");
@@ -1017,12 +1021,12 @@ void msm_enqueue_multi(const MsmSchedule& s, MsmWorkspace& ws, int count, const 
     const u32 heavy_max = (u32)std::min<u64>(s.heavy_cap, nseg / MEDIUM_MAX + 1);
     const u32 tasks_max = (u32)((nseg + heavy_max) / HEAVY_TASK + heavy_max + 1);
     const u32 medium_max = (u32)std::min<u64>(s.heavy_cap, nseg / (FIX_MAX - 1) + 1);
-    ws.reserve(g, Cfg::PT_WORDS == G2Cfg::PT_WORDS, nseg, tasks_max, k);
+    if (do_acc) ws.reserve(g, Cfg::PT_WORDS == G2Cfg::PT_WORDS, nseg, tasks_max, k);      // (the tail half finds what the first half reserved)
     // word strides between the arrays of consecutive products
     const size_t bucket_stride = (size_t)g.total_buckets() * Cfg::PT_WORDS, slot_stride = (size_t)nseg * 2 * Cfg::PT_WORDS,
                  task_stride = (size_t)tasks_max * Cfg::PT_WORDS;
     if constexpr (Cfg::PT_WORDS == G1Cfg::PT_WORDS) {
-        if (group) {                                 // (all K products are live, or none: they share the slot count)
+        if (group && do_acc) {                       // (all K products are live, or none: they share the slot count)
 #ifdef UG_MEASURE
             const char* fold = getenv("UG_GROUP_FOLD_LOG");                   // measurement knob (WRONG sums): see the kernel
             const u32 fold_mask = fold && *fold ? ((1u << atoi(fold)) - 1) : ~0u;
@@ -1046,7 +1050,7 @@ void msm_enqueue_multi(const MsmSchedule& s, MsmWorkspace& ws, int count, const 
             if (stats) stats->end(slot, stream);
         }
     } else if (group) throw std::logic_error("msm: groups are G1 only");
-    for (int q = 0; q < (group ? 0 : k); q++) {
+    for (int q = 0; q < (group || !do_acc ? 0 : k); q++) {
         const int j = live[q];
         int slot = stats ? stats->begin(stream, g.n * g.windows) : -1;
         if (nseg) {
@@ -1057,6 +1061,7 @@ void msm_enqueue_multi(const MsmSchedule& s, MsmWorkspace& ws, int count, const 
         }
         if (stats) stats->end(slot, stream);
     }
+    if (!do_tail) return;
     if (nseg > 1) {
         const u64 small_max = std::min<u64>(g.total_buckets(), nseg);       // a listed bucket crosses a segment boundary of its own
         hipLaunchKernelGGL(bucket_fixup_kernel<Cfg>, dim3((unsigned)((small_max + 127) / 128), k), dim3(128), 0, stream,
@@ -1248,16 +1253,16 @@ void msm_enqueue_batch_g1(const MsmSchedule& s, MsmWorkspace& ws, int count, con
     msm_enqueue_multi<G1Cfg>(s, ws, count, bases, n_bases, delta, stream, stats, pinned_host, pend);
 }
 void msm_enqueue_batch_g2(const MsmSchedule& s, MsmWorkspace& ws, int count, const u32* const* bases, const u64* n_bases, const int64_t* delta,
-                          hipStream_t stream, MsmStats* stats, u32* const* pinned_host, MsmPending* pend) {
-    msm_enqueue_multi<G2Cfg>(s, ws, count, bases, n_bases, delta, stream, stats, pinned_host, pend);
+                          hipStream_t stream, MsmStats* stats, u32* const* pinned_host, MsmPending* pend, int phase) {
+    msm_enqueue_multi<G2Cfg>(s, ws, count, bases, n_bases, delta, stream, stats, pinned_host, pend, 0, phase);
 }
 void msm_enqueue_group_g1(const MsmSchedule& s, MsmWorkspace& ws, int members, const u32* bases, u64 n_slots, int64_t delta, hipStream_t stream,
-                          MsmStats* stats, u32* const* pinned_host, MsmPending* pend) {
+                          MsmStats* stats, u32* const* pinned_host, MsmPending* pend, int phase) {
     if (members < 2 || members > 3) throw std::invalid_argument("msm: a base group has 2 or 3 members");
     const u32* b[MSM_MAX_BATCH] = {bases, bases, bases, bases};
     const u64 n[MSM_MAX_BATCH] = {n_slots, n_slots, n_slots, n_slots};
     const int64_t d[MSM_MAX_BATCH] = {delta, delta, delta, delta};
-    msm_enqueue_multi<G1Cfg>(s, ws, members, b, n, d, stream, stats, pinned_host, pend, members);
+    msm_enqueue_multi<G1Cfg>(s, ws, members, b, n, d, stream, stats, pinned_host, pend, members, phase);
 }
 G1XYZZ msm_collect_g1(const MsmPending& p) { return msm_collect<G1Cfg>(p); }
 G2XYZZ msm_collect_g2(const MsmPending& p) { return msm_collect<G2Cfg>(p); }

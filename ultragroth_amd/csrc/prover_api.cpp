@@ -430,6 +430,16 @@ void enqueueWitnessProducts(DeviceProver& d, ug_ctx* ctx, const ug_schedule* sw,
         void* outs[1] = {outB2};
         ugCheck(ug_msm_batch_enqueue(ctx, 1, sets, sw, nullptr, outs));
     };
+    // ULTRAGROTH_TAILS=split: a group and a G2 set in one call that runs their tails side by side on two streams
+    // (ug_msm_witness_enqueue). Built, exact and measured in round 5 -- a wash (one rank of eight at 2^24: 22.06-22.16 ms against
+    // 21.96-22.10; 2^24: 130.96-131.37 against 130.90-131.97): the tails keep the chip's issue slots busy, they are not waiting. The
+    // default stays one product after the other.
+    static const bool splitTails = [] { const char* e = getenv("ULTRAGROTH_TAILS"); return e && !strcmp(e, "split"); }();
+    if (splitTails && !g2First && d.G && d.B2) {
+        void* outs[3] = {outA, outB1, outC};
+        ugCheck(ug_msm_witness_enqueue(ctx, d.G, d.B2, sw, outs, outB2));
+        return;
+    }
     if (g2First) g2();
     if (d.G) {
         void* outs[3] = {outA, outB1, outC};

@@ -129,6 +129,8 @@ struct ug_ctx {
     struct QueuedMsm { MsmPending pend; void* out; bool g2; };
     std::vector<QueuedMsm> pending_msm;
     hipEvent_t order_event = nullptr;      // ug_ctx_wait
+    hipStream_t side_stream = nullptr;     // ug_msm_witness_enqueue: the G2 tail runs here beside the G1 tail
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
     bool defer_tables = false;             // ug_ctx_defer_tables: sets are created with room for their window tables, which are
                                            // then built piece by piece (ug_bases_tables_step)
     ug_graph* recording = nullptr;         // the stream is being captured into this graph (ug_graph_begin .. ug_graph_end)
@@ -363,6 +365,9 @@ void ug_ctx_destroy(ug_ctx* c) {
     for (auto& sp : c->spans_free) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
     for (auto& sp : c->spans_pending) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
     if (c->order_event) hipEventDestroy(c->order_event);
+    if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
+    if (c->side_fork) hipEventDestroy(c->side_fork);
+    if (c->side_join) hipEventDestroy(c->side_join);
     for (int k = 0; k < 4; k++) c->stats[k].destroy();
     if (c->pinned_results) hipHostFree(c->pinned_results);
     hipStreamDestroy(c->stream);
@@ -1007,6 +1012,62 @@ int ug_msm_group_enqueue(ug_ctx* c, const ug_bases* group, const ug_schedule* s,
         msm_enqueue_group_g1(s->sched, c->ws_g1, K, group->pts, group->slots, delta, c->stream, c->stat(3), host, pend);
         for (int m = 0; m < K; m++) c->pending_msm[first_slot + m].pend = pend[m];
     } catch (...) { c->pending_msm.resize(first_slot); throw; }
+    tm.stop();
+    UG_CATCH
+}
+// The witness products of a proof -- the K products of a base group (A | B1 | C, or A | B1) and the G2 product B2 over ONE schedule
+// (src/groth16.cpp:55-64) -- queued so that their latency-bound ends overlap: both accumulations back to back on the context's
+// stream, then the G1 tail (fix-up of cut buckets, bucket reduction, tree sums, result copy) on that stream and the G2 tail on a
+// side stream beside it. The two tails are chains of dependent EC additions in kernels of a few thousand waves: one after the other
+// they leave most of the chip idle, most of all on a rank of a many-device prover (round 5: one rank of eight at 2^24 22.4 -> see
+// profiles/r05_variants_ab.txt item 10). Results as after ug_msm_group_enqueue + ug_msm_batch_enqueue (ug_ctx_collect).
+int ug_msm_witness_enqueue(ug_ctx* c, const ug_bases* group, const ug_bases* g2set, const ug_schedule* s, void* const* outs_group, void* out_g2) {
+    UG_TRY
+    if (!c || !group || !g2set || !s || !outs_group || !out_g2) throw std::invalid_argument("null argument");
+    if (group->members < 2 || !g2set->g2 || g2set->members > 1) throw std::invalid_argument("a base group and a G2 set are expected");
+    const int K = group->members;
+    if (c->pending_msm.size() + (size_t)K + 1 > (size_t)MsmStats::MAX_BATCH) throw std::invalid_argument("at most 8 products may be queued before ug_ctx_collect");
+    for (int m = 0; m < K; m++) if (!outs_group[m]) throw std::invalid_argument("null argument");
+    check_tables(group, s); check_tables(g2set, s);
+    c->use();
+    if (!c->side_stream) {
+        UG_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+        UG_HIP(hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming));
+        UG_HIP(hipEventCreateWithFlags(&c->side_join, hipEventDisableTiming));
+    }
+    ScopedTimer tm(c, &c->msm_ms);
+    const size_t first_slot = c->pending_msm.size();
+    for (int m = 0; m <= K; m++) {
+        ug_ctx::QueuedMsm q;
+        q.g2 = m == K; q.out = m == K ? out_g2 : outs_group[m];
+        c->pending_msm.push_back(q);
+    }
+    try {
+        u32* host[MSM_BATCH_MAX]; MsmPending pend[MSM_BATCH_MAX];
+        for (int m = 0; m < K; m++) host[m] = c->pinned_results + (first_slot + m) * MSM_PENDING_WORDS;
+        u32* host2[1] = {c->pinned_results + (first_slot + K) * MSM_PENDING_WORDS};
+        MsmPending pend2[1];
+        const int64_t delta = (int64_t)s->first - (int64_t)group->global_first;
+        const u32* pts2[1] = {g2set->pts};
+        const u64 nb2[1] = {g2set->empty ? 0 : g2set->n};
+        const int64_t delta2[1] = {(int64_t)s->first - (int64_t)g2set->global_first};
+        // both accumulations, back to back
+        msm_enqueue_group_g1(s->sched, c->ws_g1, K, group->pts, group->slots, delta, c->stream, c->stat(3), host, pend, MSM_PHASE_ACCUMULATE);
+        msm_enqueue_batch_g2(s->sched, c->ws_g2, 1, pts2, nb2, delta2, c->stream, c->stat(1), host2, pend2, MSM_PHASE_ACCUMULATE);
+        // the G2 tail on the side stream, the G1 tail on the context's, then the context's stream waits for the side
+        UG_HIP(hipEventRecord(c->side_fork, c->stream));
+        UG_HIP(hipStreamWaitEvent(c->side_stream, c->side_fork, 0));
+        msm_enqueue_batch_g2(s->sched, c->ws_g2, 1, pts2, nb2, delta2, c->side_stream, nullptr, host2, pend2, MSM_PHASE_TAIL);
+        msm_enqueue_group_g1(s->sched, c->ws_g1, K, group->pts, group->slots, delta, c->stream, nullptr, host, pend, MSM_PHASE_TAIL);
+        UG_HIP(hipEventRecord(c->side_join, c->side_stream));
+        UG_HIP(hipStreamWaitEvent(c->stream, c->side_join, 0));
+        for (int m = 0; m < K; m++) c->pending_msm[first_slot + m].pend = pend[m];
+        c->pending_msm[first_slot + K].pend = pend2[0];
+    } catch (...) {
+        c->pending_msm.resize(first_slot);
+        if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
+        throw;
+    }
     tm.stop();
     UG_CATCH
 }
