@@ -41,6 +41,7 @@
  *                                                 replayed as a hipGraph (exact; measured a wash on this runtime, so off by default)
  *                      ULTRAGROTH_WITNESS_GATHER=0  ULTRAGROTH_DEVICES: a chain rank uploads the whole witness over its own PCIe link
  *                                                 (default: it collects the other ranks' slices from their HBM, peer copies)
+ *                      ULTRAGROTH_TAILS=split     the G1 and G2 tails of the witness products side by side on two streams (exact; a wash)
  *                      ULTRAGROTH_FUSED=0         A, B1, C as separate base sets instead of one interleaved group
  *                      ULTRAGROTH_SHARD=PxB       many-device layout: P base-point ranges x B bucket classes
  *                      ULTRAGROTH_MAX_RANGE=n     scalars per schedule (tests: the piecewise path without a 2^27 circuit)

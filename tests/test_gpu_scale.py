@@ -772,10 +772,12 @@ def test_ultragroth_api_on_several_devices(device, devices):
     os.environ["ULTRAGROTH_DEVICES"] = devices
     try:
         with ug.UltraGrothProver(zkey) as p:
-            for k in range(3):
+            for k in range(4):
                 if k == 1:
                     with pytest.raises(ug.ProverError):
                         p.prove(uwtns[:-40])
+                if k == 3:      # (round 5) every rank uploads the whole witness itself instead of collecting its peers' slices
+                    os.environ["ULTRAGROTH_WITNESS_GATHER"] = "0"
                 ug.set_test_blinding(rk + r + s)
                 try:
                     assert p.prove(uwtns) == exp
@@ -783,6 +785,7 @@ def test_ultragroth_api_on_several_devices(device, devices):
                     ug.set_test_blinding(b"")
     finally:
         del os.environ["ULTRAGROTH_DEVICES"]
+        os.environ.pop("ULTRAGROTH_WITNESS_GATHER", None)
 
 
 @pytest.mark.parametrize("log_domain,n_public", [(2, 1), (3, 0), (5, 3), (7, 1), (10, 0)])

@@ -1457,6 +1457,38 @@ public:
         ugCheck(ug_dvec_upload_idle(sl.buf, signals0, M));
         sl.uploadMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tLoad0).count();
     }
+    // A rank of a many-device prover (MultiUltraGrothProver): the .uwtns parsed as stage() does, but only the signals
+    // [lo, hi) copied over this rank's PCIe link, into the current buffer -- the rest arrives from the peers' HBM
+    // (witnessVec / ug_dvec_copy_via), after which witnessGathered() makes the witness the prover's. One thread, no turn.
+    void loadWitnessSlice(const void* wtns, unsigned long long wtnsSize, uint64_t lo, uint64_t hi) {
+        if (witnessQueued_ == 1) throw std::invalid_argument("the queued witness products still read the witness (ug_groth16_prover_witness_msm_end)");
+        auto tLoad0 = std::chrono::steady_clock::now();
+        BinFile f(wtns, wtnsSize, "wtns", 2);
+        WtnsHeader wh = loadWtnsHeader(f);
+        if (hdr_.nVars != wh.nVars)
+            throw InvalidWitnessLengthException("Invalid witness length. Circuit: " + std::to_string(hdr_.nVars) +
+                                                ", witness: " + std::to_string(wh.nVars));
+        if (!wh.primeIsBn254) throw std::invalid_argument("different wtns curve");
+        const uint64_t M = hdr_.nVars;
+        if (lo > hi || hi > M) throw std::invalid_argument("witness slice outside [0, nVars]");
+        const uint8_t* signals0 = checkedSection(f, 2, M * 32);
+        auto u32Section = [&](uint32_t id) {
+            std::vector<uint32_t> v(f.sectionSize(id) >> 2);
+            memcpy(v.data(), f.sectionData(id), v.size() * 4);
+            return v;
+        };
+        StagedWitness sl;
+        sl.buf = wCur_;
+        sl.chunks = u32Section(3); sl.freq = u32Section(4); sl.wIdx = u32Section(5); sl.pIdx = u32Section(6);
+        if (sl.wIdx.size() != sl.pIdx.size()) throw std::range_error("uwtns: wtns_indxs and push_indxs differ in length");
+        sl.publicPart.assign(signals0, signals0 + ((size_t)hdr_.nPublic + 1) * 32);
+        if (hi > lo) ugCheck(ug_dvec_upload_range(wCur_, signals0 + lo * 32, lo, hi - lo, nullptr));
+        sl.uploadMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tLoad0).count();
+        adopt(sl);
+        witnessLoaded_ = false;                      // (until the peers' slices are here: witnessGathered)
+    }
+    ug_dvec* witnessVec() { return wCur_; }
+    void witnessGathered() { witnessLoaded_ = true; }
     // the staged witness becomes the prover's (proveMutex held)
     void adopt(StagedWitness& sl) {
         wCur_ = sl.buf;
@@ -2130,7 +2162,7 @@ public:
         BinFile f(zkey, zkeySize, "zkey", 1);
         ZkeyHeader h = loadZkeyHeader(f, true);
         if (!h.rIsBn254) throw std::invalid_argument("zkey curve not supported");
-        nPublic_ = h.nPublic; domain_ = h.domainSize;
+        nPublic_ = h.nPublic; domain_ = h.domainSize; nVars_ = h.nVars;
         ranks_.resize(R);
         const bool oneShot = g_oneShotProver;
         std::vector<std::future<void>> jobs;
@@ -2164,9 +2196,27 @@ public:
             for (auto& t : th) t.join();
             for (auto& e : errs) if (e) std::rethrow_exception(e);
         };
-        // round 1: the commitment to the round witnesses, part by part
+        // round 1: the commitment to the round witnesses, part by part. Every rank needs the whole witness (the lookup completion
+        // rewrites signals anywhere in it): each copies ITS R-th over its own PCIe link, then collects the others from its peers'
+        // HBM (peer copies over xGMI; 128 MiB at 2^22: 3.1 ms per rank through one link, ~0.9 ms this way).
+        // ULTRAGROTH_WITNESS_GATHER=0: every rank uploads all of it, as round 4 did.
         std::vector<std::array<uint8_t, 64>> cparts(R);
-        everyRank([&](int k) { ranks_[k]->loadWitness(wtns, wtnsSize); ranks_[k]->roundCommit(cparts[k].data()); });
+        const char* wg = getenv("ULTRAGROTH_WITNESS_GATHER");
+        if (R > 1 && !(wg && wg[0] == '0')) {
+            const uint64_t M = nVars_;
+            auto slice = [&](int k) { return Range{M * (uint64_t)k / (uint64_t)R, M * (uint64_t)(k + 1) / (uint64_t)R}; };
+            everyRank([&](int k) { const Range w = slice(k); ranks_[k]->loadWitnessSlice(wtns, wtnsSize, w.lo, w.hi); });
+            everyRank([&](int k) {
+                for (int q = 0; q < R; q++) {
+                    const Range w = slice(q);
+                    if (q != k && w.hi > w.lo) ugCheck(ug_dvec_copy(ranks_[k]->witnessVec(), w.lo, ranks_[q]->witnessVec(), w.lo, w.hi - w.lo));
+                }
+                ranks_[k]->witnessGathered();
+                ranks_[k]->roundCommit(cparts[k].data());
+            });
+        } else {
+            everyRank([&](int k) { ranks_[k]->loadWitness(wtns, wtnsSize); ranks_[k]->roundCommit(cparts[k].data()); });
+        }
         for (int k = 1; k < R; k++) if (ug_g1_record_add(cparts[0].data(), cparts[k].data()) != PROVER_OK) throw std::runtime_error("partial sum failed");
         uint8_t commit[64];
         ranks_[0]->roundFinish(cparts[0].data(), commit);
@@ -2229,6 +2279,7 @@ private:
     ug_dvec* full_[3] = {nullptr, nullptr, nullptr};
     std::vector<Slices> slices_;
     uint32_t nPublic_ = 0, domain_ = 0;
+    uint64_t nVars_ = 0;
     double msm_ = 0, fft_ = 0, total_ = 0;
 };
 
