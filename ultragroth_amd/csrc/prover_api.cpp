@@ -778,6 +778,10 @@ public:
         explicit TurnRequest(std::atomic<int>& n_) : n(n_) { n.fetch_add(1); }
         ~TurnRequest() { n.fetch_sub(1); }
     };
+    // ... and they alternate: under a steady stream of callers the builder still gets one piece between two of their turns (a
+    // proof then waits ~10 ms; the tables arrive after ~190 proofs at 2^24 instead of never), and never two in a row while
+    // somebody waits
+    void callerHasTheTurn() { builderHadLast_.store(false); }
     void tableBuilder() {
         // pieces of about 10 ms: the G1 table kernel makes ~60 k points per ms, the G2 one ~20 k (2^24: 840 ms for 50 M points of
         // the A | B1 | C group, 836 ms for 16.7 M points of B2)
@@ -790,11 +794,17 @@ public:
                 for (ug_bases* b : sets) {
                     if (!b) continue;
                     for (;;) {
-                        while (wantTurn_.load() > 0 && !stopBuilder_.load()) std::this_thread::sleep_for(std::chrono::microseconds(50));
+                        while (wantTurn_.load() > 0 && builderHadLast_.load() && !stopBuilder_.load()) std::this_thread::sleep_for(std::chrono::microseconds(50));
                         if (stopBuilder_.load()) return;
                         std::lock_guard<std::mutex> turn(proveMutex);
-                        uint64_t left = 0;
-                        ugCheck(ug_bases_tables_step(b, b == d_.B2 ? pieceG2 : pieceG1, &left));
+                        // one piece per turn while the prover is idle (a caller that arrives waits ~5 ms on average); four in the
+                        // turn that follows a caller's proof or when callers queue -- under a steady load the tables are then in
+                        // use after ~50 proofs (~9 s at 2^24, a proof up to 40 ms later meanwhile) instead of ~140 (one piece in
+                        // the gap between two calls): a proof on the tables is 20 ms faster, so finishing the build pays
+                        const int pieces = (wantTurn_.load() > 0 || !builderHadLast_.load()) ? 4 : 1;
+                        uint64_t left = 1;
+                        for (int i = 0; i < pieces && left; i++) ugCheck(ug_bases_tables_step(b, b == d_.B2 ? pieceG2 : pieceG1, &left));
+                        builderHadLast_.store(true);
                         if (!left) break;
                     }
                 }
@@ -899,6 +909,7 @@ public:
         if (device) card = std::unique_lock<std::mutex>(*device);
         std::unique_lock<std::mutex> turn;
         { TurnRequest mine(wantTurn_); turn = std::unique_lock<std::mutex>(proveMutex); }
+        callerHasTheTurn();
         traceStep("turn on the device");
         AroundGuard bracket(around);
         bracket.begin();
@@ -1204,6 +1215,7 @@ public:
     void proveResident(std::string& proof, std::string& pub) override {
         std::unique_lock<std::mutex> turn;
         { TurnRequest mine(wantTurn_); turn = std::unique_lock<std::mutex>(proveMutex); }
+        callerHasTheTurn();
         if (!witnessLoaded_ || !witnessComplete_) throw std::invalid_argument("no witness loaded");
         proveLoaded(proof, pub);
     }
@@ -1251,6 +1263,7 @@ private:
     std::thread builder_;
     std::atomic<bool> stopBuilder_{false}, builderDone_{false};
     std::atomic<int> wantTurn_{0};
+    std::atomic<bool> builderHadLast_{true};       // (the first turns, before any caller: one piece each)
     std::string builderError_;
     int rank_, count_;
     ShardLayout layout_;               // this rank's part of a many-device layout (haveLayout_), else unused
