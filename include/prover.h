@@ -128,10 +128,11 @@ int ug_prover_kernel_stats(void *prover_object, int which, double *launch_ms_avg
 /* host wall-clock milliseconds the last prove spent bringing the witness into HBM (parse + host-to-device copy) */
 int ug_prover_last_upload_ms(void *prover_object, double *upload_ms);
 /* COLD START: groth16_prover_create (src/prover.h:127-138 of the reference; an unsharded prover here) returns once the zkey is
- * resident -- 0.25 s at 2^24 -- and does not wait for its fixed-base window tables (1.9 s of kernels): they are built on a
- * stream of their own while the prover already answers, on the classic windows, and the first proof that finds them finished
- * switches over. 1 = the tables are in use (or the prover has none to wait for), 0 = still being built; wait != 0 blocks until
- * they are and switches; -1 = error. ULTRAGROTH_TABLES_BG=0 makes create wait as it did before. */
+ * resident -- 0.25 s at 2^24 -- and does not wait for its fixed-base window tables (1.9 s of kernels): a thread of the prover
+ * builds them in pieces of ~10 ms of device time between the proofs, which meanwhile run on the classic windows (one piece per
+ * turn while the prover is idle, four after a caller's proof under load), and the first proof after the last piece uses them.
+ * 1 = the tables are in use (or the prover has none to wait for), 0 = still being built; wait != 0 blocks until they are;
+ * -1 = error. ULTRAGROTH_TABLES_BG=0 makes create wait as it did before. */
 int ug_prover_tables_ready(void *prover_object, int wait);
 
 /* ---- resident multi-circuit prover ---------------------------------------------------------------------
