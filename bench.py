@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--check", action="store_true", help="one more proof with fixed blinding, compared byte for byte with the expected proof "
                                                          "(oracle H polynomial + MSMs in the exponent; any size); exit code 3 on a mismatch")
     ap.add_argument("--g1-only", action="store_true", help="BASELINE.json configs[1]: G1 MSM + NTT only (B1/B2/C sets at infinity)")
+    ap.add_argument("--b-zero", type=float, default=0.0, help="(N = 1) fraction of the signals without a B-side point (B1 / B2 at infinity), as in "
+                                                                "real circuits; 0 = the dense benchmark circuits of BASELINE.json")
     ap.add_argument("--overlap", type=int, default=None, choices=[0, 1, 2], nargs="?", const=1,
                     help="ULTRAGROTH_OVERLAP of the K timed steps at N = 1: 0 = the H branch behind the witness products, 1 / 2 = beside them on "
                          "the second stream (the library's deployment switch; the fastest honest form and the default here: 1). The per-kernel "
@@ -255,7 +257,7 @@ def measure_traffic(args, log_domain):
             d = os.path.join(base, counter)
             cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
                    sys.executable, os.path.join(ROOT, "bench.py"), "--bare", "--steps", "2", "--warmup", "1", "--overlap", "0",
-                   "--log-domain", str(log_domain), "--mix", args.mix, "--host-threads", "1"] + (["--g1-only"] if args.g1_only else [])
+                   "--log-domain", str(log_domain), "--mix", args.mix, "--host-threads", "1", "--b-zero", str(args.b_zero)] + (["--g1-only"] if args.g1_only else [])
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
             if r.returncode != 0:
                 return None, "rocprofv3 --pmc %s child failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode(errors="replace")[-200:])
@@ -590,7 +592,7 @@ def main():
     single = dist is None                       # the one-GPU form: the reference's calls on one prover object
     timed_overlap = (1 if args.overlap is None else args.overlap) if single else 0
     if single:
-        zkey, wtns, info = synth.build_circuit(dev, log_domain, mix=args.mix, g1_only=args.g1_only)
+        zkey, wtns, info = synth.build_circuit(dev, log_domain, mix=args.mix, g1_only=args.g1_only, b_zero=args.b_zero)
         zkey_bytes = len(zkey)
         t0 = time.perf_counter()
         prover = ug.Groth16Prover(zkey)          # groth16_prover_create: the reference's own entry point
@@ -1048,7 +1050,7 @@ def main():
                                    "one proof after the other from one host thread"
                                    % (log_domain, log_domain, "G1 MSMs A and H only" if args.g1_only else "full G1+G2 MSM", args.mix,
                                       1 if args.g1_only else 2),
-                       "log_domain": log_domain, "mix": args.mix, "overlap": timed_overlap,
+                       "log_domain": log_domain, "mix": args.mix, "b_zero": args.b_zero if single else 0.0, "overlap": timed_overlap,
                        "graph": os.environ.get("ULTRAGROTH_GRAPH", "0") not in ("", "0"),
                        "fused_g1_group": os.environ.get("ULTRAGROTH_FUSED", "1") != "0",
                        "parallelism": "one GPU" if single else "%s x%d%s" % (
@@ -1090,7 +1092,8 @@ def main():
                 zkey = synth.build_circuit(dev, log_domain, mix=args.mix, g1_only=args.g1_only)[0]
             exp = closed_form.groth16_expected(zkey, wtns, synth.SEEDS, synth.g1_generator_record(), synth.g2_generator_record(),
                                                int.from_bytes(bytes(range(1, 32)), "little"), int.from_bytes(bytes(range(31, 62)), "little"),
-                                               g1_only=args.g1_only)
+                                               g1_only=args.g1_only,
+                                               b_zero_mask=synth.b_zero_mask(info["nVars"], args.b_zero) if (single and args.b_zero) else None)
             ok = (chk[0], chk[1]) == exp
             res["check"] = "bit-exact" if ok else "MISMATCH"
             rc = 0 if ok else 3

@@ -41,6 +41,9 @@
  *                                                 replayed as a hipGraph (exact; measured a wash on this runtime, so off by default)
  *                      ULTRAGROTH_WITNESS_GATHER=0  ULTRAGROTH_DEVICES: a chain rank uploads the whole witness over its own PCIe link
  *                                                 (default: it collects the other ranks' slices from their HBM, peer copies)
+ *                      ULTRAGROTH_SPARSE_B=0      keep B1 / B2 dense (default: when at most 3/4 of a circuit's B points are real, the prover
+ *                                                 keeps only those, with a schedule of its own over their scalars: -15 % per proof at
+ *                                                 2^24 with half of the B points at infinity, -26 % with three quarters)
  *                      ULTRAGROTH_TAILS=split     the G1 and G2 tails of the witness products side by side on two streams (exact; a wash)
  *                      ULTRAGROTH_FUSED=0         A, B1, C as separate base sets instead of one interleaved group
  *                      ULTRAGROTH_SHARD=PxB       many-device layout: P base-point ranges x B bucket classes

@@ -28,10 +28,11 @@ def _dot_walk(ptr, n, seed):
     return from_le(out.raw)
 
 
-def groth16_expected(zkey, wtns, seeds, g1_generator, g2_generator, r, s, g1_only=False, progress=None):
+def groth16_expected(zkey, wtns, seeds, g1_generator, g2_generator, r, s, g1_only=False, progress=None, b_zero_mask=None):
     """(proof_json, public_json) the prover must produce for (zkey, wtns) with blinding scalars r, s (ints < 2^248).
 
-    seeds: {"A","B1","B2","C","H"} -> walk seed of each section; g1_only: B1, B2, C sections are all-infinity."""
+    seeds: {"A","B1","B2","C","H"} -> walk seed of each section; g1_only: B1, B2, C sections are all-infinity;
+    b_zero_mask (numpy bool per signal): the signals whose B1 and B2 points are the point at infinity (their scalars drop out)."""
     say = progress or (lambda msg: None)
     info = zkey_info(zkey)
     nv, npub, dom, ncoefs = info["nVars"], info["nPublic"], info["domainSize"], info["nCoefs"]
@@ -51,8 +52,15 @@ def groth16_expected(zkey, wtns, seeds, g1_generator, g2_generator, r, s, g1_onl
     if g1_only:
         sum_b1, sum_b2, sum_c = zero1, zero2, zero1
     else:
-        kb1 = _dot_walk(w_ptr, nv, seeds["B1"])
-        kb2 = _dot_walk(w_ptr, nv, seeds["B2"])
+        wb_ptr, keep = w_ptr, None
+        if b_zero_mask is not None:
+            import numpy as np
+            keep = np.frombuffer(C.string_at(w_ptr, nv * 32), dtype=np.uint8).reshape(nv, 32).copy()
+            keep[np.asarray(b_zero_mask, dtype=bool)] = 0
+            wb_ptr = keep.ctypes.data
+        kb1 = _dot_walk(wb_ptr, nv, seeds["B1"])
+        kb2 = _dot_walk(wb_ptr, nv, seeds["B2"])
+        del keep
         kc = _dot_walk(w_ptr + (npub + 1) * 32, nv - npub - 1, seeds["C"])
         sum_b1 = g1_mul(g1_generator, kb1) if kb1 else zero1
         sum_b2 = g2_mul(g2_generator, kb2) if kb2 else zero2

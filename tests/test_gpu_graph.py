@@ -156,3 +156,38 @@ def test_cold_start_proofs_during_and_after_the_table_build(device, monkeypatch)
     with ug.Groth16Prover(zkey) as p:
         p.tables_ready(wait=True)
         assert _fixed(ug, r + s, lambda: p.prove(wtns2)) == exp[1]
+
+
+@pytest.mark.parametrize("b_zero", [0.5, 0.97, 0.3])
+def test_sparse_b_circuits(device, monkeypatch, b_zero):
+    """Real circuits leave many signals off the B side of every constraint: B1 and B2 hold points at infinity for them. From a quarter
+    of such points on the prover keeps B1 / B2 compacted over the signals that have a real point, with a schedule of its own over the
+    gathered scalars, and [A | C] as the G1 group (DeviceProver: sparse B); below that, and with ULTRAGROTH_SPARSE_B=0, the dense
+    form. Every form proves the oracle's proof: eager and recorded, on the classic windows and on the tables, two witnesses."""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, wtns, info = synth.build_circuit(device, 15, mix="U", seed=0x5EED0B00, b_zero=b_zero)
+    wtns2 = synth.build_witness(15, "C", seed=0x5EED0B01)
+    r, s = fixed_rs()
+    exp = [O.groth16_prove(zkey, w, int.from_bytes(r, "little"), int.from_bytes(s, "little"))[:2] for w in (wtns, wtns2)]
+    from oracle import closed_form
+    mask = synth.b_zero_mask(info["nVars"], b_zero, 0x5EED0B00)
+    assert closed_form.groth16_expected(zkey, wtns, synth.SEEDS, synth.g1_generator_record(), synth.g2_generator_record(),
+                                        int.from_bytes(r, "little"), int.from_bytes(s, "little"), b_zero_mask=mask) == exp[0]
+    for sparse, graph in (("1", "0"), ("1", "1"), ("0", "0")):
+        monkeypatch.setenv("ULTRAGROTH_SPARSE_B", sparse)
+        monkeypatch.setenv("ULTRAGROTH_GRAPH", graph)
+        with ug.Groth16Prover(zkey) as p:
+            for k in range(4):                                       # (classic windows first, the tables arrive meanwhile)
+                assert _fixed(ug, r + s, lambda: p.prove((wtns, wtns2)[k % 2])) == exp[k % 2], (sparse, graph, k)
+            p.tables_ready(wait=True)
+            for k in range(4):
+                assert _fixed(ug, r + s, lambda: p.prove((wtns, wtns2)[k % 2])) == exp[k % 2], (sparse, graph, k)
+    # the one-shot call (no tables) and the phase calls of an unsharded prover take the same path
+    monkeypatch.setenv("ULTRAGROTH_SPARSE_B", "1")
+    monkeypatch.setenv("ULTRAGROTH_GRAPH", "0")
+    ug.set_test_blinding(r + s)
+    try:
+        assert ug.groth16_prover(zkey, wtns) == exp[0]
+    finally:
+        ug.set_test_blinding(b"")

@@ -246,6 +246,15 @@ struct DeviceProver {
     ug_bases* G = nullptr;       // the G1 sets that share the witness scalars as ONE interleaved group ([A | B1 | C] for Groth16,
                                  // [A | B1] for UltraGroth; A, B1 (and C) are then null): one gather and one accumulation
                                  // launch for all of them (ug_bases_create_group_g1). ULTRAGROTH_FUSED=0 keeps separate sets.
+    // SPARSE B (Groth16, one device): in real circuits many signals never appear on the B side of a constraint, so B1 / B2 hold
+    // points at infinity for them. When at most three quarters of the B points are real, the prover keeps only those (Bc1, Bc2:
+    // compacted sets), the list of their signal numbers (bIdx) and a schedule of its own over the gathered scalars (wB, sB);
+    // the G1 group is then [A | C]. The dense form (B1 in the group, B2 over the witness schedule) stays for everything else.
+    ug_bases *Bc1 = nullptr, *Bc2 = nullptr;
+    ug_index* bIdx = nullptr;
+    ug_dvec* wB = nullptr;
+    ug_schedule* sB = nullptr;
+    int tableB = 0;              // window width of the compacted sets' tables (0: classic windows)
     ug_hpoly* hp = nullptr;
     ug_dvec *w = nullptr, *h = nullptr, *aux = nullptr;
     ug_dvec* w2 = nullptr;       // second witness buffer (Groth16): the next proof's witness is staged here while a proof runs
@@ -253,9 +262,10 @@ struct DeviceProver {
     ug_schedule *sw = nullptr, *sh = nullptr, *saux = nullptr;
     ug_index *roundIdx = nullptr, *finalIdx = nullptr;      // UltraGroth: zkey sections 10 and 11, resident
     ~DeviceProver() {
-        ug_index_destroy(roundIdx); ug_index_destroy(finalIdx);
-        ug_schedule_destroy(sw); ug_schedule_destroy(sh); ug_schedule_destroy(saux);
-        ug_dvec_destroy(w); ug_dvec_destroy(w2); ug_dvec_destroy(h); ug_dvec_destroy(aux);
+        ug_index_destroy(roundIdx); ug_index_destroy(finalIdx); ug_index_destroy(bIdx);
+        ug_schedule_destroy(sw); ug_schedule_destroy(sh); ug_schedule_destroy(saux); ug_schedule_destroy(sB);
+        ug_dvec_destroy(w); ug_dvec_destroy(w2); ug_dvec_destroy(h); ug_dvec_destroy(aux); ug_dvec_destroy(wB);
+        ug_bases_destroy(Bc1); ug_bases_destroy(Bc2);
         ug_hpoly_destroy(hp);
         ug_bases_destroy(A); ug_bases_destroy(B1); ug_bases_destroy(B2); ug_bases_destroy(C); ug_bases_destroy(H);
         ug_bases_destroy(roundC); ug_bases_destroy(G);
@@ -423,8 +433,22 @@ bool fusedGroups() {
 // The witness products of one schedule, queued on ctx (results after ug_ctx_collect): the G1 sets -- as the interleaved group
 // d.G when the prover holds one (outC null: a two-member group), else d.A, d.B1 and, with outC, d.C shifted by shiftC --
 // and the G2 set d.B2; g2First queues the G2 product ahead of the G1 ones.
+void buildSchedule(ug_schedule* s, const ug_dvec* scalars, uint64_t first, uint64_t count, int tableC);
 void enqueueWitnessProducts(DeviceProver& d, ug_ctx* ctx, const ug_schedule* sw, uint8_t* outA, uint8_t* outB1, uint8_t* outB2, uint8_t* outC,
-                            int64_t shiftC, bool g2First) {
+                            int64_t shiftC, bool g2First, const ug_dvec* witness = nullptr) {
+    if (d.Bc2) {
+        // sparse B: [A | C] over the witness schedule; the B scalars gathered by signal number, a schedule over them, B1 and B2
+        // over that one (src/groth16.cpp:58,61 with the points at infinity left out: the sums are the same)
+        if (!witness) throw std::logic_error("sparse B: the witness vector is needed");
+        void* outsG[2] = {outA, outC};
+        ugCheck(ug_msm_group_enqueue(ctx, d.G, sw, outsG));
+        ugCheck(ug_dvec_gather_index(d.wB, witness, d.bIdx));
+        buildSchedule(d.sB, d.wB, 0, ug_dvec_size(d.wB), d.tableB);
+        const ug_bases* sets[2] = {d.Bc1, d.Bc2};
+        void* outsB[2] = {outB1, outB2};
+        ugCheck(ug_msm_batch_enqueue(ctx, 2, sets, d.sB, nullptr, outsB));
+        return;
+    }
     auto g2 = [&] {
         const ug_bases* sets[1] = {d.B2};
         void* outs[1] = {outB2};
@@ -701,7 +725,60 @@ private:
         // out of the group: as a set of its own it is marked empty and its product costs nothing)
         const bool anyEmpty = ug_points_all_infinity(pA, nw, 64) || ug_points_all_infinity(pB1, nw, 64) || ug_points_all_infinity(pC, cHi - cLo, 64);
         groupG1_ = fusedGroups() && !anyEmpty;
+        // SPARSE B (see DeviceProver): which signals have a real point in B1 or B2? Decided on a sample of every 257th signal first
+        // (a dense circuit -- every synthetic benchmark circuit -- pays 65 k record tests and nothing else), then counted exactly.
+        std::vector<uint32_t> bSupport;
+        std::vector<uint8_t> b1c, b2c;
+        {
+            const char* sb = getenv("ULTRAGROTH_SPARSE_B");
+            const bool allowed = !(sb && sb[0] == '0') && count == 1 && !haveLayout_ && !src.sliced && groupG1_ && nw >= ((uint64_t)1 << 14) &&
+                                 nw <= maxRange_ && nw < ((uint64_t)1 << 32);
+            auto real = [&](uint64_t i) {
+                // (the first words of x decide for any real point; the whole records are compared only when they are zero)
+                uint64_t a, b;
+                memcpy(&a, pB2 + i * 128, 8); memcpy(&b, pB1 + i * 64, 8);
+                if (a | b) return true;
+                return !(ug_points_all_infinity(pB2 + i * 128, 1, 128) && ug_points_all_infinity(pB1 + i * 64, 1, 64));
+            };
+            if (allowed) {
+                uint64_t seen = 0, hit = 0;
+                for (uint64_t i = 0; i < nw; i += 257) { seen++; hit += real(i) ? 1 : 0; }
+                if (hit * 10 <= seen * 8) {                       // the sample says at most ~80 % real: count them (eight host threads)
+                    const int T = 8;
+                    std::vector<std::vector<uint32_t>> found(T);
+                    {
+                        std::vector<std::thread> th;
+                        for (int t = 0; t < T; t++)
+                            th.emplace_back([&, t] {
+                                const uint64_t lo = nw * (uint64_t)t / T, hi = nw * (uint64_t)(t + 1) / T;
+                                found[t].reserve((size_t)((hi - lo) * hit / seen + 1024));
+                                for (uint64_t i = lo; i < hi; i++) if (real(i)) found[t].push_back((uint32_t)i);
+                            });
+                        for (auto& x : th) x.join();
+                    }
+                    size_t total = 0;
+                    for (auto& v : found) total += v.size();
+                    if ((uint64_t)total * 4 <= nw * 3 && total) {
+                        sparseB_ = true;
+                        bSupport.reserve(total);
+                        for (auto& v : found) bSupport.insert(bSupport.end(), v.begin(), v.end());
+                        b1c.resize(total * 64); b2c.resize(total * 128);
+                        std::vector<std::thread> th;
+                        for (int t = 0; t < T; t++)
+                            th.emplace_back([&, t] {
+                                for (size_t j = total * (size_t)t / T; j < total * (size_t)(t + 1) / T; j++) {
+                                    memcpy(b1c.data() + j * 64, pB1 + (uint64_t)bSupport[j] * 64, 64);
+                                    memcpy(b2c.data() + j * 128, pB2 + (uint64_t)bSupport[j] * 128, 128);
+                                }
+                            });
+                        for (auto& x : th) x.join();
+                    }
+                }
+            }
+            nB_ = sparseB_ ? bSupport.size() : 0;
+        }
         std::vector<int> ahead = planTableWidthsAhead(d_.ctx, tableGroups(), otherBytes);
+        ahead.resize(3, 0);
         bool withTables = true;
         if (bgTables_ && (ahead[0] || ahead[1])) {
             ugCheck(ug_ctx_defer_tables(d_.ctx, 1));
@@ -716,7 +793,23 @@ private:
             ugCheck(g2 ? ug_bases_create_g2(ctx, pts, n, first, out) : ug_bases_create_g1(ctx, pts, n, first, out));
         };
         traceStep("create: contexts made, coefficient matrix resident (background tables), point sets next");
-        if (groupG1_) {
+        if (groupG1_ && sparseB_) {
+            // [A | C]; B1 and B2 as compacted sets over the signals that have a real B point
+            const void* hosts[2] = {pA, pC};
+            const uint64_t counts[2] = {nw, cHi - cLo}, firsts[2] = {wr_.lo, cLo + hdr_.nPublic + 1};
+            int rc = UG_ERROR;
+            if (ahead[0]) rc = ug_bases_create_group_g1(d_.ctx, 2, hosts, counts, firsts, wr_.lo, nw, ahead[0], &d_.G);
+            if (rc != UG_OK) {
+                if (ahead[0]) withTables = false;
+                ugCheck(ug_bases_create_group_g1(d_.ctx, 2, hosts, counts, firsts, wr_.lo, nw, 0, &d_.G));
+            }
+            create(d_.ctx, false, b1c.data(), nB_, 0, ahead[2], &d_.Bc1);
+            create(d_.ctx, true, b2c.data(), nB_, 0, ahead[2], &d_.Bc2);
+            ugCheck(ug_index_create(d_.ctx, bSupport.data(), nB_, &d_.bIdx));
+            ugCheck(ug_dvec_create(d_.ctx, nB_, &d_.wB));
+            ugCheck(ug_schedule_create(d_.ctx, &d_.sB));
+            b1c = std::vector<uint8_t>(); b2c = std::vector<uint8_t>();
+        } else if (groupG1_) {
             // A, B1 and C (with its index shift folded into the slot numbers) as one interleaved group
             const void* hosts[3] = {pA, pB1, pC};
             const uint64_t counts[3] = {nw, nw, cHi - cLo}, firsts[3] = {wr_.lo, wr_.lo, cLo + hdr_.nPublic + 1};
@@ -731,22 +824,29 @@ private:
             create(d_.ctx, false, pB1, nw, wr_.lo, ahead[0], &d_.B1);
         }
         traceStep("create: G1 sets of the witness uploaded");
-        create(d_.ctx, true, pB2, nw, wr_.lo, ahead[0], &d_.B2);
+        if (!sparseB_) create(d_.ctx, true, pB2, nw, wr_.lo, ahead[0], &d_.B2);
         traceStep("create: B2 uploaded");
         if (!d_.G) create(d_.ctx, false, pC, cHi - cLo, cLo, ahead[0], &d_.C);
         const bool group0 = withTables && ahead[0];
         create(d_.ctx2, false, pH, nh, hr_.lo, ahead[1], &d_.H);
         traceStep("create: H uploaded");
         const bool group1 = withTables && ahead[1];
+        const bool group2 = sparseB_ && withTables && ahead[2];
         if (ahead[0] && !group0) {
             for (ug_bases* b : {d_.G, d_.A, d_.B1, d_.B2, d_.C}) if (b) ug_bases_drop_tables(b);
         }
+        if (sparseB_ && ahead[2] && !group2) { ug_bases_drop_tables(d_.Bc1); ug_bases_drop_tables(d_.Bc2); }
         tableW_ = group0 ? ahead[0] : 0;
         tableH_ = group1 ? ahead[1] : 0;
-        if (group0) tableBytes += (d_.G ? ug_bases_tables_bytes(3 * nw, 0, tableW_) : ug_bases_tables_bytes(nw, 0, tableW_) * 2 + ug_bases_tables_bytes(cHi - cLo, 0, tableW_)) +
-                                  ug_bases_tables_bytes(nw, 1, tableW_);
+        d_.tableB = group2 ? ahead[2] : 0;
+        if (group0) tableBytes += (d_.G ? ug_bases_tables_bytes((sparseB_ ? 2 : 3) * nw, 0, tableW_) : ug_bases_tables_bytes(nw, 0, tableW_) * 2 + ug_bases_tables_bytes(cHi - cLo, 0, tableW_)) +
+                                  (sparseB_ ? 0 : ug_bases_tables_bytes(nw, 1, tableW_));
         if (group1) tableBytes += ug_bases_tables_bytes(nh, 0, tableH_);
-        if (bgTables_) { pendingW_.store(tableW_); pendingH_.store(tableH_); tableW_ = tableH_ = 0; }     // classic windows until tableBuilder() has finished them
+        if (group2) tableBytes += ug_bases_tables_bytes(nB_, 0, d_.tableB) + ug_bases_tables_bytes(nB_, 1, d_.tableB);
+        if (bgTables_) {          // classic windows until tableBuilder() has finished them
+            pendingW_.store(tableW_); pendingH_.store(tableH_); pendingB_.store(d_.tableB);
+            tableW_ = tableH_ = 0; d_.tableB = 0;
+        }
         if (haveHpoly_ && !d_.hp) ugCheck(ug_hpoly_create(d_.ctx2, coefs, hdr_.nCoefs, hdr_.domainSize, hdr_.nVars, &d_.hp));
         ugCheck(ug_dvec_create(d_.ctx, M, &d_.w));
         wCur_ = d_.w;
@@ -787,10 +887,11 @@ public:
         // the A | B1 | C group, 836 ms for 16.7 M points of B2)
         const uint64_t pieceG1 = (uint64_t)1 << 19, pieceG2 = (uint64_t)3 << 16;
         try {
-            for (int group = 0; group < 2; group++) {
+            for (int group = 0; group < 3; group++) {
                 ug_bases* sets[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
                 if (group == 0) { if (!pendingW_.load()) continue; sets[0] = d_.G; sets[1] = d_.A; sets[2] = d_.B1; sets[3] = d_.C; sets[4] = d_.B2; }
-                else { if (!pendingH_.load()) continue; sets[0] = d_.H; }
+                else if (group == 1) { if (!pendingH_.load()) continue; sets[0] = d_.H; }
+                else { if (!pendingB_.load()) continue; sets[0] = d_.Bc1; sets[4] = d_.Bc2; }
                 for (ug_bases* b : sets) {
                     if (!b) continue;
                     for (;;) {
@@ -803,15 +904,17 @@ public:
                         // the gap between two calls): a proof on the tables is 20 ms faster, so finishing the build pays
                         const int pieces = (wantTurn_.load() > 0 || !builderHadLast_.load()) ? 4 : 1;
                         uint64_t left = 1;
-                        for (int i = 0; i < pieces && left; i++) ugCheck(ug_bases_tables_step(b, b == d_.B2 ? pieceG2 : pieceG1, &left));
+                        for (int i = 0; i < pieces && left; i++) ugCheck(ug_bases_tables_step(b, (b == d_.B2 || b == d_.Bc2) ? pieceG2 : pieceG1, &left));
                         builderHadLast_.store(true);
                         if (!left) break;
                     }
                 }
                 std::lock_guard<std::mutex> turn(proveMutex);             // a proof boundary: the next proof uses the tables
-                if (group == 0) { tableW_ = pendingW_.load(); pendingW_.store(0); } else { tableH_ = pendingH_.load(); pendingH_.store(0); }
+                if (group == 0) { tableW_ = pendingW_.load(); pendingW_.store(0); }
+                else if (group == 1) { tableH_ = pendingH_.load(); pendingH_.store(0); }
+                else { d_.tableB = pendingB_.load(); pendingB_.store(0); }
                 dropGraphs();
-                traceStep(group == 0 ? "window tables of the witness sets in use" : "window tables of H in use");
+                traceStep(group == 0 ? "window tables of the witness sets in use" : group == 1 ? "window tables of H in use" : "window tables of the B sets in use");
             }
         } catch (const std::exception& e) {
             builderError_ = e.what();                                     // the prover stays on the classic windows
@@ -827,7 +930,7 @@ public:
         while (wait && !builderDone_.load() && !stopBuilder_.load()) std::this_thread::sleep_for(std::chrono::milliseconds(1));
         // (no turn taken: a query must not wait for the builder's pieces; the error string is complete once builderDone_ is set)
         if (wait && builderDone_.load() && !builderError_.empty()) throw std::runtime_error("window tables: " + builderError_);
-        return !pendingW_.load() && !pendingH_.load();
+        return !pendingW_.load() && !pendingH_.load() && !pendingB_.load();
     }
     std::vector<TableGroup> tableGroups() override {
         std::vector<TableGroup> groups(2);
@@ -839,6 +942,14 @@ public:
         groups[1].g1 = {d_.H}; groups[1].n1 = {hr_.hi - hr_.lo};
         groups[1].scalars = hr_.hi - hr_.lo; groups[1].c = &tableH_;
         if (hr_.hi - hr_.lo > maxRange_) groups[1].scalars = 0;
+        if (sparseB_) {               // the group of the witness holds [A | C] only; B1 and B2 live compacted, with a schedule of their own
+            groups[0].g1 = {d_.G}; groups[0].n1 = {2 * (wr_.hi - wr_.lo)};
+            groups[0].g2.clear(); groups[0].n2.clear();
+            groups.resize(3);
+            groups[2].g1 = {d_.Bc1}; groups[2].n1 = {nB_};
+            groups[2].g2 = {d_.Bc2}; groups[2].n2 = {nB_};
+            groups[2].scalars = nB_; groups[2].c = &d_.tableB;
+        }
         return groups;
     }
     void trimWorkspaces() override {
@@ -846,11 +957,13 @@ public:
         std::lock_guard<std::mutex> turn(proveMutex);
         dropGraphs();                                   // (they hold pointers into what goes now)
         ug_schedule_trim(d_.sw); ug_schedule_trim(d_.sh);
+        if (d_.sB) ug_schedule_trim(d_.sB);
         ug_ctx_trim(d_.ctx); ug_ctx_trim(d_.ctx2);
         witness_.trim(wCur_);
     }
 
     const ZkeyHeader& header() const { return hdr_; }
+    bool sparseB() const { return sparseB_; }
 
     // the whole witness section of a .wtns buffer, checked against the circuit (src/prover.cpp:183-196)
     const uint8_t* witnessData(const BinFile& f) const {
@@ -967,7 +1080,7 @@ public:
             memset(part, 0, sizeof part);
             buildSchedule(d_.sw, wCur_, lo, n, tableW_);
             // S1-S4 (src/groth16.cpp:55,58,61,64): A, B1, B2, C over the witness schedule, queued back to back
-            enqueueWitnessProducts(d_, d_.ctx, d_.sw, out, out + 64, out + 128, out + 256, (int64_t)hdr_.nPublic + 1, false);
+            enqueueWitnessProducts(d_, d_.ctx, d_.sw, out, out + 64, out + 128, out + 256, (int64_t)hdr_.nPublic + 1, false, wCur_);
             ugCheck(ug_ctx_collect(d_.ctx));
             if (out == part && ug_groth16_partials_add(partials, part) != PROVER_OK) throw std::runtime_error("partial sum failed");
         }
@@ -997,7 +1110,7 @@ public:
         QueueGuard inFlight(d_.ctx);
         buildSchedule(d_.sw, wCur_, wr_.lo, n, tableW_);
         enqueueWitnessProducts(d_, d_.ctx, d_.sw, queuedParts_, queuedParts_ + 64, queuedParts_ + 128, queuedParts_ + 256,
-                               (int64_t)hdr_.nPublic + 1, false);
+                               (int64_t)hdr_.nPublic + 1, false, wCur_);
         inFlight.done();
         witnessQueued_ = 1;
     }
@@ -1113,7 +1226,7 @@ public:
             uint8_t* out = runParts_;
             buildSchedule(d_.sw, wCur_, wr_.lo, nw, tableW_);
             // S1-S4 (src/groth16.cpp:55,58,61,64): A, B1, B2, C over the witness schedule, queued back to back
-            enqueueWitnessProducts(d_, d_.ctx, d_.sw, out, out + 64, out + 128, out + 256, (int64_t)hdr_.nPublic + 1, overlap == 2);
+            enqueueWitnessProducts(d_, d_.ctx, d_.sw, out, out + 64, out + 128, out + 256, (int64_t)hdr_.nPublic + 1, overlap == 2, wCur_);
             if (overlap == 0) ugCheck(ug_ctx_wait(d_.ctx2, d_.ctx));
             ugCheck(ug_hpoly_run(d_.hp, wCur_, d_.h));                                          // S5-S9 :66-148
             buildSchedule(d_.sh, d_.h, hr_.lo, nh, tableH_);
@@ -1258,7 +1371,9 @@ private:
     static constexpr uint64_t MAX_RANGE = (uint64_t)1 << 26;       // 2^26 scalars * <= 16 windows < 2^31 entries
     uint64_t maxRange_ = MAX_RANGE;    // ULTRAGROTH_MAX_RANGE lowers it (tests: the piecewise path without a 2^27 circuit)
     int tableW_ = 0, tableH_ = 0;      // window widths of the fixed-base tables (0: classic windows), planWindowTables
-    std::atomic<int> pendingW_{0}, pendingH_{0};      // ... of tables that are still being built (tableBuilder)
+    std::atomic<int> pendingW_{0}, pendingH_{0}, pendingB_{0};      // ... of tables that are still being built (tableBuilder)
+    bool sparseB_ = false;             // B1 / B2 kept compacted over the signals with a real B point (DeviceProver)
+    uint64_t nB_ = 0;
     bool bgTables_ = false;
     std::thread builder_;
     std::atomic<bool> stopBuilder_{false}, builderDone_{false};

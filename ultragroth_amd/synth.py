@@ -120,10 +120,17 @@ def _section(sid, payload):
     return struct.pack("<IQ", sid, len(payload)) + payload
 
 
-def build_circuit(dev, log_domain, mix="U", seed=0x5EED0000, n_public=1, g1_only=False, coefs=None):
+def b_zero_mask(nvars, b_zero, seed=0x5EED0000):
+    """which signals have NO B-side point (B1 and B2 at infinity) in build_circuit(.., b_zero=fraction): a real circuit's B-side
+    polynomials vanish for the signals that never appear on the B side of a constraint"""
+    return np.random.Generator(np.random.PCG64(seed + 7)).random(nvars) < b_zero
+
+
+def build_circuit(dev, log_domain, mix="U", seed=0x5EED0000, n_public=1, g1_only=False, coefs=None, b_zero=0.0):
     """Returns (zkey, wtns_bytes, info). Sections are laid out as snarkjs does (1..10). The zkey comes back as a
     ctypes char array (buffer protocol, ``len``, accepted wherever the bindings take ``bytes``): every section is
-    generated in place, so the peak host footprint is one zkey (9.4 GB at 2^24), not two."""
+    generated in place, so the peak host footprint is one zkey (9.4 GB at 2^24), not two.
+    b_zero: fraction of the signals whose B1 and B2 points are the point at infinity (b_zero_mask; info["b_zero"])."""
     import ctypes as C
     domain = 1 << log_domain
     nvars = domain - 1
@@ -162,10 +169,14 @@ def build_circuit(dev, log_domain, mix="U", seed=0x5EED0000, n_public=1, g1_only
         synth_points(dev, nvars, SEEDS["B1"], out=view[at[6][0]:at[6][1]])
         synth_points(dev, nvars, SEEDS["B2"], g2=True, out=view[at[7][0]:at[7][1]])
         synth_points(dev, n_c, SEEDS["C"], out=view[at[8][0]:at[8][1]])
+        if b_zero:
+            mask = b_zero_mask(nvars, b_zero, seed)
+            np.frombuffer(view[at[6][0]:at[6][1]], dtype=np.uint8).reshape(nvars, 64)[mask] = 0
+            np.frombuffer(view[at[7][0]:at[7][1]], dtype=np.uint8).reshape(nvars, 128)[mask] = 0
     synth_points(dev, domain, SEEDS["H"], out=view[at[9][0]:at[9][1]])
     del view
     wtns = build_witness(log_domain, mix, seed)
-    info = dict(domainSize=domain, nVars=nvars, nPublic=n_public, nCoefs=n_coefs, mix=mix, seed=seed, g1_only=g1_only)
+    info = dict(domainSize=domain, nVars=nvars, nPublic=n_public, nCoefs=n_coefs, mix=mix, seed=seed, g1_only=g1_only, b_zero=b_zero)
     return zkey, wtns, info
 
 
