@@ -943,8 +943,10 @@ def main():
         # Algorithmic bytes per launch (restated in DESIGN.md): G1 accumulation 96 B per point of
         # the slice (64 B affine base + 32 B scalar, each read once), G2 160 B per point, one NTT pass 64 B per point
         g1_bytes, g2_bytes, ntt_bytes = 96.0 * n_local, 160.0 * n_local, 64.0 * info["domainSize"]
-        # the group launch reads three 64-byte bases and one 32-byte scalar per point: 224 B per point
-        grp_bytes = 224.0 * n_local
+        # the group launch reads three 64-byte bases and one 32-byte scalar per point: 224 B per point ([A | C], 160 B, when the
+        # prover keeps B1 / B2 compacted over the signals with a real B point: --b-zero from a quarter on)
+        grp_members = 2 if (single and args.b_zero >= 0.25 and os.environ.get("ULTRAGROTH_SPARSE_B", "1") != "0") else 3
+        grp_bytes = (32.0 + 64.0 * grp_members) * n_local
 
         def gbs(nbytes, ms):
             return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -979,7 +981,7 @@ def main():
         ntt_mads = 162.0 * (3.0 * log_domain + 6.0) / (6.0 * ntt_passes)
         kern = [entry("segment_accumulate_kernel<G1Cfg>", g1_bytes, acc_ms, launches, entries, 1467.0),
                 entry("segment_accumulate_kernel<G2Cfg>", g2_bytes, g2_ms, g2_launches, g2_entries, 4470.0),
-                entry("segment_accumulate_group_kernel<3>", grp_bytes, grp_ms, grp_launches, grp_entries, 1467.0, products_per_launch=3),
+                entry("segment_accumulate_group_kernel<%d>" % grp_members, grp_bytes, grp_ms, grp_launches, grp_entries, 1467.0, products_per_launch=grp_members),
                 entry("ntt_pass_kernel", ntt_bytes * (ntt_points / max(ntt_launches, 1) / info["domainSize"] if ntt_launches else 1.0), ntt_ms,
                       ntt_launches, ntt_points, ntt_mads, transforms_per_launch=(ntt_points / max(ntt_launches, 1) / info["domainSize"]) if ntt_launches else None)]
         kern = [e for e in kern if e["launches"]]
@@ -1024,7 +1026,7 @@ def main():
                                          "timed region: same process, same prover" if timed_overlap else "the K timed steps themselves")
         if timed_overlap:
             roofline["launch_ms_in_timed_region"] = {n: kstats_region[i][0] for i, n in
-                                                     ((3, "segment_accumulate_group_kernel<3>"), (1, "segment_accumulate_kernel<G2Cfg>"),
+                                                     ((3, "segment_accumulate_group_kernel<%d>" % grp_members), (1, "segment_accumulate_kernel<G2Cfg>"),
                                                       (0, "segment_accumulate_kernel<G1Cfg>"), (2, "ntt_pass_kernel")) if kstats_region[i][1]}
         roofline["board"] = board
         ms_per_step = 1e3 * elapsed / args.steps
