@@ -191,3 +191,8 @@ def test_sparse_b_circuits(device, monkeypatch, b_zero):
         assert ug.groth16_prover(zkey, wtns) == exp[0]
     finally:
         ug.set_test_blinding(b"")
+    # ... and the resident multi-circuit prover, which builds (and may drop) the tables of all three groups itself
+    with ug.Registry(0) as reg:
+        reg.load("sparse", zkey)
+        for k in range(3):
+            assert _fixed(ug, r + s, lambda: reg.prove("sparse", (wtns, wtns2)[k % 2])) == exp[k % 2]
