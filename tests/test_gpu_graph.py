@@ -196,3 +196,19 @@ def test_sparse_b_circuits(device, monkeypatch, b_zero):
         reg.load("sparse", zkey)
         for k in range(3):
             assert _fixed(ug, r + s, lambda: reg.prove("sparse", (wtns, wtns2)[k % 2])) == exp[k % 2]
+
+
+@pytest.mark.parametrize("b_zero", [0.5, 0.9])
+def test_sparse_b_ultragroth(device, monkeypatch, b_zero):
+    """the same for the UltraGroth prover (src/ultra_groth.cpp:201,214,227: A, B1, B2 over the completed witness): A alone over the
+    witness schedule, B1 / B2 compacted with a schedule of their own; the oracle's proof with and without the sparse form"""
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    zkey, uwtns, info = synth.build_ultra_circuit(device, 15, b_zero=b_zero)
+    rk, r, s = bytes(range(1, 32)), bytes(range(40, 71)), bytes(range(80, 111))
+    exp = O.ultra_groth_prove(zkey, uwtns, *(int.from_bytes(b, "little") for b in (rk, r, s)))
+    for sparse in ("1", "0"):
+        monkeypatch.setenv("ULTRAGROTH_SPARSE_B", sparse)
+        with ug.UltraGrothProver(zkey) as p:
+            for k in range(3):
+                assert _fixed(ug, rk + r + s, lambda: p.prove(uwtns)) == exp, (sparse, k)

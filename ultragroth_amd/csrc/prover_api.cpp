@@ -440,8 +440,14 @@ void enqueueWitnessProducts(DeviceProver& d, ug_ctx* ctx, const ug_schedule* sw,
         // sparse B: [A | C] over the witness schedule; the B scalars gathered by signal number, a schedule over them, B1 and B2
         // over that one (src/groth16.cpp:58,61 with the points at infinity left out: the sums are the same)
         if (!witness) throw std::logic_error("sparse B: the witness vector is needed");
-        void* outsG[2] = {outA, outC};
-        ugCheck(ug_msm_group_enqueue(ctx, d.G, sw, outsG));
+        if (d.G) {                                      // Groth16: [A | C]
+            void* outsG[2] = {outA, outC};
+            ugCheck(ug_msm_group_enqueue(ctx, d.G, sw, outsG));
+        } else {                                        // UltraGroth: A alone (its C sets have schedules of their own)
+            const ug_bases* setA[1] = {d.A};
+            void* outsA[1] = {outA};
+            ugCheck(ug_msm_batch_enqueue(ctx, 1, setA, sw, nullptr, outsA));
+        }
         ugCheck(ug_dvec_gather_index(d.wB, witness, d.bIdx));
         buildSchedule(d.sB, d.wB, 0, ug_dvec_size(d.wB), d.tableB);
         const ug_bases* sets[2] = {d.Bc1, d.Bc2};
@@ -479,6 +485,54 @@ void enqueueWitnessProducts(DeviceProver& d, ug_ctx* ctx, const ug_schedule* sw,
 void buildSchedule(ug_schedule* s, const ug_dvec* scalars, uint64_t first, uint64_t count, int tableC) {
     if (tableC) ugCheck(ug_schedule_build_tables(s, scalars, first, count, tableC));
     else ugCheck(ug_schedule_build(s, scalars, first, count));
+}
+
+// SPARSE B (see DeviceProver): which of the n signals have a real point in B1 or B2? Decided on a sample of every 257th signal first
+// (a dense circuit -- every synthetic benchmark circuit -- pays 65 k record tests and nothing else), then counted exactly on eight
+// host threads. True when at most three quarters of the points are real: `support` then lists their signal numbers in order and
+// b1c / b2c hold the compacted records. A signal is left out only when BOTH its records are all zero: exact for any zkey.
+bool sparseBSupport(const uint8_t* pB1, const uint8_t* pB2, uint64_t n, std::vector<uint32_t>& support, std::vector<uint8_t>& b1c,
+                    std::vector<uint8_t>& b2c) {
+    const char* sb = getenv("ULTRAGROTH_SPARSE_B");
+    if ((sb && sb[0] == '0') || !fusedGroups() || n < ((uint64_t)1 << 14) || n >= ((uint64_t)1 << 32)) return false;
+    auto real = [&](uint64_t i) {
+        // (the first words of x decide for any real point; the whole records are compared only when they are zero)
+        uint64_t a, b;
+        memcpy(&a, pB2 + i * 128, 8); memcpy(&b, pB1 + i * 64, 8);
+        if (a | b) return true;
+        return !(ug_points_all_infinity(pB2 + i * 128, 1, 128) && ug_points_all_infinity(pB1 + i * 64, 1, 64));
+    };
+    uint64_t seen = 0, hit = 0;
+    for (uint64_t i = 0; i < n; i += 257) { seen++; hit += real(i) ? 1 : 0; }
+    if (hit * 10 > seen * 8) return false;            // the sample says more than ~80 % real
+    const int T = 8;
+    std::vector<std::vector<uint32_t>> found(T);
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&, t] {
+                const uint64_t lo = n * (uint64_t)t / T, hi = n * (uint64_t)(t + 1) / T;
+                found[t].reserve((size_t)((hi - lo) * hit / seen + 1024));
+                for (uint64_t i = lo; i < hi; i++) if (real(i)) found[t].push_back((uint32_t)i);
+            });
+        for (auto& x : th) x.join();
+    }
+    size_t total = 0;
+    for (auto& v : found) total += v.size();
+    if (!total || (uint64_t)total * 4 > n * 3) return false;
+    support.clear(); support.reserve(total);
+    for (auto& v : found) support.insert(support.end(), v.begin(), v.end());
+    b1c.resize(total * 64); b2c.resize(total * 128);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+        th.emplace_back([&, t] {
+            for (size_t j = total * (size_t)t / T; j < total * (size_t)(t + 1) / T; j++) {
+                memcpy(b1c.data() + j * 64, pB1 + (uint64_t)support[j] * 64, 64);
+                memcpy(b2c.data() + j * 128, pB2 + (uint64_t)support[j] * 128, 128);
+            }
+        });
+    for (auto& x : th) x.join();
+    return true;
 }
 
 struct ProverBase {        // what the extern "C" layer stores behind the opaque handle
@@ -725,58 +779,11 @@ private:
         // out of the group: as a set of its own it is marked empty and its product costs nothing)
         const bool anyEmpty = ug_points_all_infinity(pA, nw, 64) || ug_points_all_infinity(pB1, nw, 64) || ug_points_all_infinity(pC, cHi - cLo, 64);
         groupG1_ = fusedGroups() && !anyEmpty;
-        // SPARSE B (see DeviceProver): which signals have a real point in B1 or B2? Decided on a sample of every 257th signal first
-        // (a dense circuit -- every synthetic benchmark circuit -- pays 65 k record tests and nothing else), then counted exactly.
+        // SPARSE B (see DeviceProver, sparseBSupport)
         std::vector<uint32_t> bSupport;
         std::vector<uint8_t> b1c, b2c;
-        {
-            const char* sb = getenv("ULTRAGROTH_SPARSE_B");
-            const bool allowed = !(sb && sb[0] == '0') && count == 1 && !haveLayout_ && !src.sliced && groupG1_ && nw >= ((uint64_t)1 << 14) &&
-                                 nw <= maxRange_ && nw < ((uint64_t)1 << 32);
-            auto real = [&](uint64_t i) {
-                // (the first words of x decide for any real point; the whole records are compared only when they are zero)
-                uint64_t a, b;
-                memcpy(&a, pB2 + i * 128, 8); memcpy(&b, pB1 + i * 64, 8);
-                if (a | b) return true;
-                return !(ug_points_all_infinity(pB2 + i * 128, 1, 128) && ug_points_all_infinity(pB1 + i * 64, 1, 64));
-            };
-            if (allowed) {
-                uint64_t seen = 0, hit = 0;
-                for (uint64_t i = 0; i < nw; i += 257) { seen++; hit += real(i) ? 1 : 0; }
-                if (hit * 10 <= seen * 8) {                       // the sample says at most ~80 % real: count them (eight host threads)
-                    const int T = 8;
-                    std::vector<std::vector<uint32_t>> found(T);
-                    {
-                        std::vector<std::thread> th;
-                        for (int t = 0; t < T; t++)
-                            th.emplace_back([&, t] {
-                                const uint64_t lo = nw * (uint64_t)t / T, hi = nw * (uint64_t)(t + 1) / T;
-                                found[t].reserve((size_t)((hi - lo) * hit / seen + 1024));
-                                for (uint64_t i = lo; i < hi; i++) if (real(i)) found[t].push_back((uint32_t)i);
-                            });
-                        for (auto& x : th) x.join();
-                    }
-                    size_t total = 0;
-                    for (auto& v : found) total += v.size();
-                    if ((uint64_t)total * 4 <= nw * 3 && total) {
-                        sparseB_ = true;
-                        bSupport.reserve(total);
-                        for (auto& v : found) bSupport.insert(bSupport.end(), v.begin(), v.end());
-                        b1c.resize(total * 64); b2c.resize(total * 128);
-                        std::vector<std::thread> th;
-                        for (int t = 0; t < T; t++)
-                            th.emplace_back([&, t] {
-                                for (size_t j = total * (size_t)t / T; j < total * (size_t)(t + 1) / T; j++) {
-                                    memcpy(b1c.data() + j * 64, pB1 + (uint64_t)bSupport[j] * 64, 64);
-                                    memcpy(b2c.data() + j * 128, pB2 + (uint64_t)bSupport[j] * 128, 128);
-                                }
-                            });
-                        for (auto& x : th) x.join();
-                    }
-                }
-            }
-            nB_ = sparseB_ ? bSupport.size() : 0;
-        }
+        sparseB_ = count == 1 && !haveLayout_ && !src.sliced && groupG1_ && nw <= maxRange_ && sparseBSupport(pB1, pB2, nw, bSupport, b1c, b2c);
+        nB_ = sparseB_ ? bSupport.size() : 0;
         std::vector<int> ahead = planTableWidthsAhead(d_.ctx, tableGroups(), otherBytes);
         ahead.resize(3, 0);
         bool withTables = true;
@@ -1509,7 +1516,22 @@ private:
         // many-GPU prover drives it beside its queued witness products (witnessMsmBegin), and ULTRAGROTH_OVERLAP=1 lets it run
         // beside them on one GPU as well; by default the second stream is ordered behind the first on the device
         ugCheck(ug_ctx_create(&d_.ctx2, device));
-        if (fusedGroups()) {                            // A and B1 share the witness scalars: one interleaved group
+        {   // SPARSE B (DeviceProver, sparseBSupport): as for Groth16 -- B1 and B2 compacted over the signals with a real B point
+            std::vector<uint32_t> bSupport;
+            std::vector<uint8_t> b1c, b2c;
+            sparseB_ = count == 1 && !src.sliced && sparseBSupport(pB1, pB2, wr_.hi - wr_.lo, bSupport, b1c, b2c);
+            nB_ = sparseB_ ? bSupport.size() : 0;
+            if (sparseB_) {
+                ugCheck(ug_bases_create_g1(d_.ctx, pA, wr_.hi - wr_.lo, wr_.lo, &d_.A));
+                ugCheck(ug_bases_create_g1(d_.ctx, b1c.data(), nB_, 0, &d_.Bc1));
+                ugCheck(ug_bases_create_g2(d_.ctx, b2c.data(), nB_, 0, &d_.Bc2));
+                ugCheck(ug_index_create(d_.ctx, bSupport.data(), nB_, &d_.bIdx));
+                ugCheck(ug_dvec_create(d_.ctx, nB_, &d_.wB));
+                ugCheck(ug_schedule_create(d_.ctx, &d_.sB));
+            }
+        }
+        if (sparseB_) {
+        } else if (fusedGroups()) {                     // A and B1 share the witness scalars: one interleaved group
             const void* hosts[2] = {pA, pB1};
             const uint64_t counts[2] = {wr_.hi - wr_.lo, wr_.hi - wr_.lo}, firsts[2] = {wr_.lo, wr_.lo};
             ugCheck(ug_bases_create_group_g1(d_.ctx, 2, hosts, counts, firsts, wr_.lo, wr_.hi - wr_.lo, 0, &d_.G));
@@ -1517,7 +1539,7 @@ private:
             ugCheck(ug_bases_create_g1(d_.ctx, pA, wr_.hi - wr_.lo, wr_.lo, &d_.A));
             ugCheck(ug_bases_create_g1(d_.ctx, pB1, wr_.hi - wr_.lo, wr_.lo, &d_.B1));
         }
-        ugCheck(ug_bases_create_g2(d_.ctx, pB2, wr_.hi - wr_.lo, wr_.lo, &d_.B2));
+        if (!sparseB_) ugCheck(ug_bases_create_g2(d_.ctx, pB2, wr_.hi - wr_.lo, wr_.lo, &d_.B2));
         // the round / final sets are multiplied with GATHERED scalars (position k of the slice's index list), so their
         // slices count from 0
         ugCheck(ug_bases_create_g1(d_.ctx, pFinalC, c2.hi - c2.lo, 0, &d_.C));
@@ -1549,11 +1571,20 @@ public:
         groups[1].g1 = {d_.roundC}; groups[1].n1 = {roundIdx_.size()}; groups[1].scalars = roundIdx_.size(); groups[1].c = &tableC1_;
         groups[2].g1 = {d_.C}; groups[2].n1 = {finalIdx_.size()}; groups[2].scalars = finalIdx_.size(); groups[2].c = &tableC2_;
         groups[3].g1 = {d_.H}; groups[3].n1 = {hr_.hi - hr_.lo}; groups[3].scalars = hr_.hi - hr_.lo; groups[3].c = &tableH_;
+        if (sparseB_) {               // A alone over the witness schedule; B1 and B2 compacted, with a schedule of their own
+            groups[0].g1 = {d_.A}; groups[0].n1 = {nw};
+            groups[0].g2.clear(); groups[0].n2.clear();
+            groups.resize(5);
+            groups[4].g1 = {d_.Bc1}; groups[4].n1 = {nB_};
+            groups[4].g2 = {d_.Bc2}; groups[4].n2 = {nB_};
+            groups[4].scalars = nB_; groups[4].c = &d_.tableB;
+        }
         return groups;
     }
     void trimWorkspaces() override {
         std::lock_guard<std::mutex> turn(proveMutex);
         ug_schedule_trim(d_.sw); ug_schedule_trim(d_.sh); ug_schedule_trim(d_.saux);
+        if (d_.sB) ug_schedule_trim(d_.sB);
         ug_ctx_trim(d_.ctx); ug_ctx_trim(d_.ctx2);
         witness_.trim(wCur_);
     }
@@ -1685,7 +1716,7 @@ public:
         if (witnessQueued_) throw std::invalid_argument("witness products are queued on this prover (ug_groth16_prover_witness_msm_end)");
         memset(partials, 0, UG_GROTH16_PARTIALS_SIZE);
         buildSchedule(d_.sw, wCur_, wr_.lo, wr_.hi - wr_.lo, tableW_);
-        enqueueWitnessProducts(d_, d_.ctx, d_.sw, partials, partials + 64, partials + 128, nullptr, 0, false);      // MSM1-3 :201,214,227
+        enqueueWitnessProducts(d_, d_.ctx, d_.sw, partials, partials + 64, partials + 128, nullptr, 0, false, wCur_);      // MSM1-3 :201,214,227
         ugCheck(ug_ctx_collect(d_.ctx));
         mark("A, B1, B2 MSMs");
         ugCheck(ug_dvec_gather_index(d_.aux, wCur_, d_.finalIdx));                           // :439-445
@@ -1721,7 +1752,7 @@ public:
     // MSM1-3 (:201,214,227), the gather of the final witnesses (:439-445) and MSM4 (:234), queued on the witness stream
     void queueFinalRoundProducts(uint8_t* sums) {
         buildSchedule(d_.sw, wCur_, wr_.lo, wr_.hi - wr_.lo, tableW_);
-        enqueueWitnessProducts(d_, d_.ctx, d_.sw, sums, sums + 64, sums + 128, nullptr, 0, false);
+        enqueueWitnessProducts(d_, d_.ctx, d_.sw, sums, sums + 64, sums + 128, nullptr, 0, false, wCur_);
         ugCheck(ug_dvec_gather_index(d_.aux, wCur_, d_.finalIdx));
         buildSchedule(d_.saux, d_.aux, 0, finalIdx_.size(), tableC2_);
         const ug_bases* setC[1] = {d_.C};
@@ -1910,6 +1941,8 @@ private:
     bool witnessLoaded_ = false, committed_ = false, haveRoundScalar_ = false, trace_ = false, haveHpoly_ = true;
     std::chrono::steady_clock::time_point tPhase_;
     int tableW_ = 0, tableC1_ = 0, tableC2_ = 0, tableH_ = 0;      // fixed-base table widths per schedule group (0: classic)
+    bool sparseB_ = false;             // B1 / B2 kept compacted over the signals with a real B point (DeviceProver)
+    uint64_t nB_ = 0;
     DeviceProver d_;
     double msmMs_ = 0, fftMs_ = 0, totalMs_ = 0;
     double m1_ = 0, f1_ = 0, m2_ = 0, f2_ = 0;                     // device ms per stream (witness stream, H branch)

@@ -298,7 +298,7 @@ def build_ultra_witness(log_domain, mix="C", seed=0x5EED0005, lookup_log=8):
     return _ultra_witness(log_domain, mix, seed, lookup_log, idx2, rng)[0]
 
 
-def build_ultra_circuit(dev, log_domain, mix="C", seed=0x5EED0005, lookup_log=8):
+def build_ultra_circuit(dev, log_domain, mix="C", seed=0x5EED0005, lookup_log=8, b_zero=0.0):
     """UltraGroth (protocol 1337) zkey + .uwtns of the same shapes: SURVEY.md section 8(d) config 5.
 
     nPublic = 2 with rand_indx = 2; the private signals are split into a round set C1 (a quarter of them) and a
@@ -310,11 +310,17 @@ def build_ultra_circuit(dev, log_domain, mix="C", seed=0x5EED0005, lookup_log=8)
     idx1, idx2, rng = _ultra_index_lists(log_domain, seed)
     header = _ultra_header(dev, log_domain, len(idx1), len(idx2), n_public, rand_indx)
     coefs = coefficients(domain, nvars, seed + 1)
+    b1, b2 = bytes(synth_points(dev, nvars, SEEDS["B1"])), bytes(synth_points(dev, nvars, SEEDS["B2"], g2=True))
+    if b_zero:                                   # (signals without a B-side point: B1 and B2 at infinity, as in build_circuit)
+        mask = b_zero_mask(nvars, b_zero, seed)
+        a1 = np.frombuffer(b1, dtype=np.uint8).reshape(nvars, 64).copy(); a1[mask] = 0
+        a2 = np.frombuffer(b2, dtype=np.uint8).reshape(nvars, 128).copy(); a2[mask] = 0
+        b1, b2 = a1.tobytes(), a2.tobytes()
     secs = [
         (1, struct.pack("<I", 1337)), (2, header), (3, bytes(64 * (n_public + 1))),
         (4, struct.pack("<I", len(coefs)) + coefs.tobytes()),
-        (5, bytes(synth_points(dev, nvars, SEEDS["A"]))), (6, bytes(synth_points(dev, nvars, SEEDS["B1"]))),
-        (7, bytes(synth_points(dev, nvars, SEEDS["B2"], g2=True))),
+        (5, bytes(synth_points(dev, nvars, SEEDS["A"]))), (6, b1),
+        (7, b2),
         (8, bytes(synth_points(dev, len(idx1), SEEDS["C"]))),                 # round points C1
         (9, bytes(synth_points(dev, len(idx2), SEEDS["C"] + (1 << 28)))),     # final points C2
         (10, idx1.tobytes()), (11, idx2.tobytes()),
