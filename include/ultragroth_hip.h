@@ -125,13 +125,18 @@ int      ug_bases_precompute(ug_bases* b, int c);
 int      ug_bases_drop_tables(ug_bases* b);
 int      ug_bases_table_window(const ug_bases* b);          /* width of the tables held, 0 = none */
 /* DEFERRED TABLE BUILDS (cold start of a created prover): after ug_ctx_defer_tables(ctx, 1) the sets made by
- * ug_bases_create_tables_* / ug_bases_create_group_g1 on this context get the room for their window tables and table 0, and
- * nothing is queued. ug_bases_tables_step(set, max_points, &remaining) builds the tables of the next max_points points on the
+ * ug_bases_create_tables_* / ug_bases_create_group_g1 on this context hold their points only and remember the width: nothing
+ * is queued, not even the tables' memory is allocated. ug_bases_tables_step(set, max_points, &remaining) builds the tables of the next max_points points on the
  * context's stream and waits for them: a bounded piece of device time that the caller puts between proofs. Until
  * ug_bases_tables_ready(set) returns 1 the set is a plain set (schedules without tables read table 0 only; products over a table
  * schedule fail). Why pieces and not one kernel on a side stream: a table kernel's workgroups live for 17-26 ms, and whenever a
  * proof's kernel ends they take the free compute units -- measured, the first proof beside such a build took 2.0 s instead of 0.17. */
 int      ug_ctx_defer_tables(ug_ctx* ctx, int on);
+/* the room for a deferred set's tables: _alloc is nothing but the device allocation (no stream touched: it may run beside proofs; a
+ * first allocation of 36 GiB was seen to take 1.1 s); _adopt, when nothing is queued on the set's context, moves the points into
+ * table 0 of the new array, swaps it in and frees the old one. Then the pieces: */
+int      ug_bases_tables_alloc(ug_bases* b, void** mem);
+int      ug_bases_tables_adopt(ug_bases* b, void* mem);
 int      ug_bases_tables_step(ug_bases* b, uint64_t max_points, uint64_t* remaining);
 int      ug_bases_tables_ready(const ug_bases* b);
 int      ug_ctx_mem_info(ug_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);

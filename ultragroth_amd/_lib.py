@@ -25,7 +25,7 @@ INNER_SYMBOLS = [
     "ug_fr_ntt", "ug_field_op", "ug_synth_points", "ug_ctx_timings", "ug_ctx_kernel_stats", "ug_ctx_abandon", "ug_test_inject_fault",
     "ug_bases_create_group_g1", "ug_bases_members", "ug_points_all_infinity", "ug_msm_group_enqueue", "ug_msm_witness_enqueue", "ug_dvec_device_ptr", "ug_dvec_copy", "ug_dvec_copy_via", "ug_sort_plan",
     "ug_bases_drop_tables", "ug_bases_table_window", "ug_schedule_trim", "ug_ctx_trim",
-    "ug_ctx_defer_tables", "ug_bases_tables_step", "ug_bases_tables_ready",
+    "ug_ctx_defer_tables", "ug_bases_tables_alloc", "ug_bases_tables_adopt", "ug_bases_tables_step", "ug_bases_tables_ready",
     "ug_graph_begin", "ug_graph_end", "ug_graph_abort", "ug_graph_valid", "ug_graph_nodes", "ug_graph_launch", "ug_graph_destroy",
 ]
 VERIFIER_SYMBOLS = ["groth16_verify", "ultra_groth_verify"]        # include/verifier.h

@@ -888,12 +888,38 @@ public:
     // ... and they alternate: under a steady stream of callers the builder still gets one piece between two of their turns (a
     // proof then waits ~10 ms; the tables arrive after ~190 proofs at 2^24 instead of never), and never two in a row while
     // somebody waits
-    void callerHasTheTurn() { builderHadLast_.store(false); }
+    void callerHasTheTurn() { builderHadLast_.store(false); turnsTaken_.fetch_add(1); }
     void tableBuilder() {
         // pieces of about 10 ms: the G1 table kernel makes ~60 k points per ms, the G2 one ~20 k (2^24: 840 ms for 50 M points of
         // the A | B1 | C group, 836 ms for 16.7 M points of B2)
         const uint64_t pieceG1 = (uint64_t)1 << 19, pieceG2 = (uint64_t)3 << 16;
         try {
+            // The tables' memory (72 GiB at 2^24) is not allocated by create either: the first allocation of tens of GiB on a device
+            // can take a second (seen: 36 GiB in 1.09 s on a box fresh from boot, 0.3 ms afterwards) and holds up every other HIP
+            // call of the process meanwhile. So the builder lets the FIRST proof through before it asks -- or starts after a quarter
+            // of a second without any caller --, allocates the room of all sets in one go, and swaps each in under the turn.
+            {
+                const auto born = std::chrono::steady_clock::now();
+                for (;;) {
+                    if (stopBuilder_.load()) return;
+                    const bool quiet = std::chrono::steady_clock::now() - born > std::chrono::milliseconds(250);
+                    if ((turnsTaken_.load() > 0 || quiet) && wantTurn_.load() == 0 && proveMutex.try_lock()) { proveMutex.unlock(); break; }
+                    std::this_thread::sleep_for(std::chrono::milliseconds(2));
+                }
+                ug_bases* all[8] = {d_.G, d_.A, d_.B1, d_.C, d_.B2, d_.H, d_.Bc1, d_.Bc2};
+                void* mem[8] = {nullptr};
+                for (int k = 0; k < 8; k++) if (all[k]) ugCheck(ug_bases_tables_alloc(all[k], &mem[k]));
+                for (int k = 0; k < 8; k++) {
+                    if (!all[k]) continue;
+                    while (wantTurn_.load() > 0 && builderHadLast_.load() && !stopBuilder_.load()) std::this_thread::sleep_for(std::chrono::microseconds(50));
+                    std::lock_guard<std::mutex> turn(proveMutex);
+                    ugCheck(ug_bases_tables_adopt(all[k], mem[k]));
+                    mem[k] = nullptr;
+                    dropGraphs();
+                    builderHadLast_.store(true);
+                }
+                traceStep("room for the window tables allocated and swapped in");
+            }
             for (int group = 0; group < 3; group++) {
                 ug_bases* sets[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
                 if (group == 0) { if (!pendingW_.load()) continue; sets[0] = d_.G; sets[1] = d_.A; sets[2] = d_.B1; sets[3] = d_.C; sets[4] = d_.B2; }
@@ -1385,6 +1411,7 @@ private:
     std::thread builder_;
     std::atomic<bool> stopBuilder_{false}, builderDone_{false};
     std::atomic<int> wantTurn_{0};
+    std::atomic<uint64_t> turnsTaken_{0};
     std::atomic<bool> builderHadLast_{true};       // (the first turns, before any caller: one piece each)
     std::string builderError_;
     int rank_, count_;

@@ -162,6 +162,7 @@ struct ug_bases {
     bool empty = false;       // every record is the point at infinity (e.g. the B2 section of a circuit without B-side wires): its
                               // products are the point at infinity and no kernel is launched for them
     u64 tables_built = ~(u64)0;   // deferred build (ug_ctx_defer_tables): points [0, tables_built) have their tables; >= n: all of them
+    int deferred_c = 0;           // ... the width the set will get: until ug_bases_tables_adopt the set holds its n points only
     bool tables_usable() const { return !table_c || tables_built >= n; }
 };
 struct ug_dvec {
@@ -416,6 +417,8 @@ static int bases_create(ug_ctx* c, const void* host, u64 n, u64 global_first, bo
     ug_bases* b = new ug_bases{c, g2, n, global_first, nullptr, 0};
     const size_t rec = g2 ? 128 : 64, bytes = (size_t)n * rec;
     b->empty = n != 0 && host_all_zero(host, bytes);          // (stops at the first point that is not infinity: the first record, normally)
+    const bool defer = table_c && c->defer_tables;            // the room for the tables comes later too (ug_bases_tables_alloc / _adopt):
+    if (defer) windows = 1;                                   // a first allocation of tens of GiB can take a second by itself
     if (hipMalloc(&b->pts, bytes ? bytes * (size_t)windows : 4) != hipSuccess) {
         (void)hipGetLastError();
         delete b;
@@ -429,11 +432,10 @@ static int bases_create(ug_ctx* c, const void* host, u64 n, u64 global_first, bo
                 u32* p = pts + off / 4;
                 if (g2) convert_points_g2(p, len / rec, st); else convert_points_g1(p, len / rec, st);
             }, /*fresh*/ true);
-            if (table_c && c->defer_tables) b->tables_built = 0;                  // (built later, in pieces: ug_bases_tables_step)
-            else if (table_c) build_window_tables(g2, pts, n, table_c, windows, c->stream);
+            if (table_c && !defer) build_window_tables(g2, pts, n, table_c, windows, c->stream);
         } catch (...) { hipFree(b->pts); delete b; throw; }
     }
-    b->table_c = table_c;
+    if (defer) b->deferred_c = table_c; else b->table_c = table_c;
     *out = b;
     UG_CATCH
 }
@@ -462,6 +464,8 @@ int ug_bases_create_group_g1(ug_ctx* c, int members, const void* const* host, co
     if (slots > ((u64)1 << TABLE_INDEX_BITS)) throw std::invalid_argument("a base group holds at most 2^27 scalars");
     ug_bases* b = new ug_bases{c, false, slots * (u64)members, group_first, nullptr, 0};
     b->members = members; b->slots = slots;
+    const bool defer = table_c && c->defer_tables;            // (as bases_create)
+    if (defer) windows = 1;
     const size_t bytes = (size_t)b->n * 64;
     u64 most = 0;
     for (int m = 0; m < members; m++) most = n[m] > most ? n[m] : most;
@@ -491,12 +495,11 @@ int ug_bases_create_group_g1(ug_ctx* c, int members, const void* const* host, co
                 interleave_points_g1(pts, stage + off / 4, len / 64, members, m, slot0 + off / 64, st);
             }, /*fresh*/ true);
         }
-        if (table_c && b->n && c->defer_tables) b->tables_built = 0;
-        else if (table_c && b->n) build_window_tables(false, pts, b->n, table_c, windows, c->stream);
+        if (table_c && b->n && !defer) build_window_tables(false, pts, b->n, table_c, windows, c->stream);
     } catch (...) { hipFree(stage); hipFree(b->pts); delete b; throw; }
     c->deferred_free.push_back(stage);      // (not hipFree here: it would wait for the table build just queued, and the caller's next
                                             // section could no longer be uploaded beside it)
-    b->table_c = table_c;
+    if (defer) b->deferred_c = table_c; else b->table_c = table_c;
     *out = b;
     UG_CATCH
 }
@@ -537,6 +540,7 @@ int ug_bases_precompute(ug_bases* b, int c) {
 int ug_bases_drop_tables(ug_bases* b) {
     UG_TRY
     if (!b) throw std::invalid_argument("null argument");
+    b->deferred_c = 0;                               // (a deferred build that has not got its room yet is simply called off)
     if (!b->table_c) return UG_OK;
     ug_ctx* ctx = b->ctx;
     ctx->use();
@@ -562,9 +566,47 @@ int ug_ctx_defer_tables(ug_ctx* c, int on) {
     c->defer_tables = on != 0;
     UG_CATCH
 }
+// The room for a deferred set's tables, in two calls: ug_bases_tables_alloc is nothing but the allocation -- it touches no stream and
+// may run beside proofs (a first allocation of 36 GiB was seen to take 1.1 s, which is why create no longer makes it) -- and
+// ug_bases_tables_adopt, for a moment when nothing is queued on the set's context (the caller's turn), moves the points into table
+// 0 of the new array, swaps it in and frees the old one. The pieces (ug_bases_tables_step) come after it.
+int ug_bases_tables_alloc(ug_bases* b, void** mem) {
+    UG_TRY
+    if (!b || !mem) throw std::invalid_argument("null argument");
+    *mem = nullptr;
+    if (!b->deferred_c || !b->n) return UG_OK;                       // nothing deferred (or nothing to build)
+    b->ctx->use();
+    const int windows = MsmGeometry::choose_tables(b->n, b->deferred_c).windows;
+    if (hipMalloc(mem, (size_t)windows * b->n * (b->g2 ? 128 : 64)) != hipSuccess) {
+        (void)hipGetLastError();
+        *mem = nullptr;
+        throw std::runtime_error("not enough device memory for the window tables");
+    }
+    UG_CATCH
+}
+int ug_bases_tables_adopt(ug_bases* b, void* mem) {
+    UG_TRY
+    if (!b) throw std::invalid_argument("null argument");
+    if (!b->deferred_c) { if (mem) hipFree(mem); return UG_OK; }
+    ug_ctx* c = b->ctx;
+    c->use();
+    if (b->n) {
+        if (!mem) throw std::invalid_argument("null argument");
+        UG_HIP(hipMemcpyAsync(mem, b->pts, (size_t)b->n * (b->g2 ? 128 : 64), hipMemcpyDeviceToDevice, c->stream));
+        UG_HIP(hipStreamSynchronize(c->stream));
+        alloc_epoch_bump();                          // (captured launch sequences that read the old array are stale now)
+        hipFree(b->pts);
+        b->pts = static_cast<u32*>(mem);
+    }
+    b->table_c = b->deferred_c;
+    b->deferred_c = 0;
+    b->tables_built = b->n ? 0 : ~(u64)0;
+    UG_CATCH
+}
 int ug_bases_tables_step(ug_bases* b, uint64_t max_points, uint64_t* remaining) {
     UG_TRY
     if (!b) throw std::invalid_argument("null argument");
+    if (b->deferred_c) throw std::logic_error("the set's tables have no room yet (ug_bases_tables_alloc / ug_bases_tables_adopt)");
     if (b->table_c && b->tables_built < b->n) {
         ug_ctx* c = b->ctx;
         c->use();
