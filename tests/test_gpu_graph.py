@@ -212,3 +212,44 @@ def test_sparse_b_ultragroth(device, monkeypatch, b_zero):
         with ug.UltraGrothProver(zkey) as p:
             for k in range(3):
                 assert _fixed(ug, rk + r + s, lambda: p.prove(uwtns)) == exp, (sparse, k)
+
+
+def test_sparse_b_on_the_ranks_of_a_many_device_prover(device, monkeypatch):
+    """every rank of a sharded prover keeps ITS range of B1 / B2 compacted when enough of its B points are at infinity (signal
+    numbers of the whole witness, the rank's own slice of the scalars): the reference API over four ranks on one device, and the
+    ranks made from their slices only (what bench.py --gpus N does), against the oracle"""
+    import os
+    import ultragroth_amd as ug
+    from ultragroth_amd import synth
+    log_domain = 17
+    zkey, wtns, info = synth.build_circuit(device, log_domain, mix="C", seed=0x5EED0C00, b_zero=0.6)
+    r, s = fixed_rs()
+    exp = O.groth16_prove(zkey, wtns, int.from_bytes(r, "little"), int.from_bytes(s, "little"))[:2]
+    for sparse in ("1", "0"):
+        monkeypatch.setenv("ULTRAGROTH_SPARSE_B", sparse)
+        monkeypatch.setenv("ULTRAGROTH_DEVICES", "0,0,0,0")
+        with ug.Groth16Prover(zkey) as p:
+            for k in range(2):
+                assert _fixed(ug, r + s, lambda: p.prove(wtns)) == exp, (sparse, k)
+        monkeypatch.delenv("ULTRAGROTH_DEVICES")
+    monkeypatch.setenv("ULTRAGROTH_SPARSE_B", "1")
+    world, n_dom, nv = 4, info["domainSize"], info["nVars"]
+    ranks = []
+    for k in range(world):
+        lay = ug.ShardedGroth16Prover.shard_layout(nv, 1, n_dom, k, world, world)
+        header, coefs, slices = synth.build_circuit_slices(device, log_domain, lay.ranges, with_coefs=bool(lay.chains), seed=0x5EED0C00, b_zero=0.6)
+        ranks.append(ug.ShardedGroth16Prover.from_slices(header, coefs, info["nCoefs"], slices, 0, k, world, public_size=86, layout=lay))
+    total = None
+    for p in ranks:
+        p.load_witness_part(wtns, 0)
+        part = p.run_witness_msm()
+        total = part if total is None else ug.ShardedGroth16Prover.add_partials(total, part)
+    # (A, B1, B2 and C of the whole proof; H is left out here: compare with the oracle's sums through a one-device prover's phases)
+    whole = ug.ShardedGroth16Prover(zkey, 0, 0, 1)
+    try:
+        whole.load_witness(wtns)
+        assert whole.run_witness_msm()[:320] == total[:320]
+    finally:
+        whole.close()
+        for p in ranks:
+            p.close()

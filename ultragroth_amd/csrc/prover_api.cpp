@@ -782,8 +782,11 @@ private:
         // SPARSE B (see DeviceProver, sparseBSupport)
         std::vector<uint32_t> bSupport;
         std::vector<uint8_t> b1c, b2c;
-        sparseB_ = count == 1 && !haveLayout_ && !src.sliced && groupG1_ && nw <= maxRange_ && sparseBSupport(pB1, pB2, nw, bSupport, b1c, b2c);
+        // (a rank of a many-device prover does the same over ITS range of the signals -- pB1 / pB2 are its slices here --, except in a
+        // bucket-class layout, whose classes belong to the witness schedule)
+        sparseB_ = !(haveLayout_ && layout_.qLog) && groupG1_ && nw <= maxRange_ && sparseBSupport(pB1, pB2, nw, bSupport, b1c, b2c);
         nB_ = sparseB_ ? bSupport.size() : 0;
+        if (sparseB_ && wr_.lo) for (uint32_t& i : bSupport) i += (uint32_t)wr_.lo;          // signal numbers of the whole witness
         std::vector<int> ahead = planTableWidthsAhead(d_.ctx, tableGroups(), otherBytes);
         ahead.resize(3, 0);
         bool withTables = true;

@@ -190,7 +190,7 @@ def zkey_header_section(dev, log_domain, n_public=1):
     return header + vk_g1[0:64] + vk_g1[64:128] + vk_g2[0:128] + vk_g2[128:256] + vk_g1[128:192] + vk_g2[256:384]
 
 
-def build_circuit_slices(dev, log_domain, ranges, with_coefs=True, seed=0x5EED0000, n_public=1, g1_only=False):
+def build_circuit_slices(dev, log_domain, ranges, with_coefs=True, seed=0x5EED0000, n_public=1, g1_only=False, b_zero=0.0):
     """What ONE rank of a sharded prover needs of build_circuit(log_domain, seed=seed), without ever materialising the rest:
     (header section, coefficient records or None, (A, B1, B2, C, H) slices) for ranges = ((w0, w1), (c0, c1), (h0, h1))
     as ShardedGroth16Prover.shard_ranges reports them. The points are the same generator walk, entered at the slice."""
@@ -208,6 +208,10 @@ def build_circuit_slices(dev, log_domain, ranges, with_coefs=True, seed=0x5EED00
             return (C.c_char * (n * (128 if g2 else 64)))()
         return synth_points(dev, n, SEEDS[name] + first, g2=g2)
     slices = (pts(w1 - w0, "A", w0), pts(w1 - w0, "B1", w0), pts(w1 - w0, "B2", w0, g2=True), pts(c1 - c0, "C", c0), pts(h1 - h0, "H", h0))
+    if b_zero and not g1_only and w1 > w0:       # (the same signals as build_circuit(.., b_zero): the mask is cut to the slice)
+        mask = b_zero_mask(nvars, b_zero, seed)[w0:w1]
+        np.frombuffer(memoryview(slices[1]).cast("B"), dtype=np.uint8).reshape(w1 - w0, 64)[mask] = 0
+        np.frombuffer(memoryview(slices[2]).cast("B"), dtype=np.uint8).reshape(w1 - w0, 128)[mask] = 0
     return zkey_header_section(dev, log_domain, n_public), coefs, slices
 
 
