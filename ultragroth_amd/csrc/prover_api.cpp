@@ -802,7 +802,7 @@ private:
             }
             ugCheck(g2 ? ug_bases_create_g2(ctx, pts, n, first, out) : ug_bases_create_g1(ctx, pts, n, first, out));
         };
-        traceStep("create: contexts made, coefficient matrix resident (background tables), point sets next");
+        traceStep("create: contexts made, point sets next");
         if (groupG1_ && sparseB_) {
             // [A | C]; B1 and B2 as compacted sets over the signals that have a real B point
             const void* hosts[2] = {pA, pC};
